@@ -1,0 +1,407 @@
+"""CPU oracle for the fish_vocoder generator forward path (numpy + oracle/libfv_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — see the header of ``fv_oracle.c``.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module; the product package ``vocoder_amd`` never does.
+
+Each ``*_forward`` below restates one reference ``forward`` (paths relative to
+``/root/reference``), walking a state dict that uses the *reference's* parameter
+names, so a checkpoint that loads into the reference loads here too.
+
+Pinning status:
+  * HiFiGAN, ConvNeXt, Snake/SnakeBeta, ISTFTHead pre-ISTFT arithmetic: pinned against
+    golden vectors produced by importing the reference in the build container
+    (``tests/golden/gen_golden.py``).
+  * alias_free_torch.Activation1d and vocos.spectral_ops.ISTFT are third-party packages
+    absent from /root/reference: restated from their published algorithm and pinned only
+    by known-answer tests — "parity unpinned" for those two pieces.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from math import prod
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfv_oracle.so")
+
+_f = ctypes.POINTER(ctypes.c_float)
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement (gcc via oracle/Makefile)."""
+    src = os.path.join(_HERE, "fv_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.fvo_num_threads.restype = _i
+        L.fvo_set_num_threads.argtypes = [_i]
+        L.fvo_weight_norm.argtypes = [_f, _f, _f, _i64, _i64]
+        L.fvo_conv1d.argtypes = [_f, _f, _f, _f] + [_i] * 8
+        L.fvo_conv_transpose1d.argtypes = [_f, _f, _f, _f] + [_i] * 7
+        for n in ("fvo_silu", "fvo_tanh", "fvo_gelu"):
+            getattr(L, n).argtypes = [_f, _f, _i64]
+        L.fvo_leaky_relu.argtypes = [_f, _f, _i64, ctypes.c_float]
+        L.fvo_snake.argtypes = [_f, _f, _f, _f, _i, _i, _i, _i]
+        L.fvo_kaiser_sinc_filter.argtypes = [ctypes.c_double, ctypes.c_double, _i, _f]
+        L.fvo_upsample_fir.argtypes = [_f, _f, _f, _i, _i, _i, _i, _i]
+        L.fvo_downsample_fir.argtypes = [_f, _f, _f, _i, _i, _i, _i, _i]
+        L.fvo_layernorm_cf.argtypes = [_f, _f, _f, _f, _i, _i, _i, ctypes.c_float]
+        L.fvo_scale_residual.argtypes = [_f, _f, _f, _f, _i, _i, _i]
+        L.fvo_istft_head_post.argtypes = [_f, _f, _f, _i, _i, _i]
+        L.fvo_istft_same.argtypes = [_f, _f, _f] + [_i] * 6
+        _lib = L
+    return _lib
+
+
+def _c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(_f)
+
+
+def num_threads() -> int:
+    return lib().fvo_num_threads()
+
+
+def set_num_threads(n: int) -> None:
+    lib().fvo_set_num_threads(int(n))
+
+
+# ------------------------------------------------------------------------------------------------
+# primitives
+# ------------------------------------------------------------------------------------------------
+def weight_norm(g, v) -> np.ndarray:
+    """torch._weight_norm(v, g, dim=0)  (hifigan.py:31 etc.)."""
+    g, v = _c(g).reshape(-1), _c(v)
+    w = np.empty_like(v)
+    lib().fvo_weight_norm(_p(g), _p(v), _p(w), v.shape[0], int(prod(v.shape[1:])))
+    return w
+
+
+def conv1d(x, w, b=None, dilation=1, padding=0, groups=1) -> np.ndarray:
+    x, w = _c(x), _c(w)
+    b = None if b is None else _c(b)
+    B, Cin, T = x.shape
+    Cout, cin_g, k = w.shape
+    assert cin_g * groups == Cin
+    Tout = T + 2 * padding - dilation * (k - 1)
+    y = np.empty((B, Cout, Tout), np.float32)
+    lib().fvo_conv1d(_p(x), _p(w), _p(b), _p(y), B, Cin, T, Cout, k, dilation, padding, groups)
+    return y
+
+
+def conv_transpose1d(x, w, b=None, stride=1, padding=0) -> np.ndarray:
+    x, w = _c(x), _c(w)
+    b = None if b is None else _c(b)
+    B, Cin, Tin = x.shape
+    cin2, Cout, k = w.shape
+    assert cin2 == Cin
+    Tout = (Tin - 1) * stride - 2 * padding + k
+    y = np.empty((B, Cout, Tout), np.float32)
+    lib().fvo_conv_transpose1d(_p(x), _p(w), _p(b), _p(y), B, Cin, Tin, Cout, k, stride, padding)
+    return y
+
+
+def _unary(name, x, *extra):
+    x = _c(x)
+    y = np.empty_like(x)
+    getattr(lib(), name)(_p(x), _p(y), x.size, *extra)
+    return y
+
+
+def silu(x):
+    return _unary("fvo_silu", x)
+
+
+def tanh(x):
+    return _unary("fvo_tanh", x)
+
+
+def gelu(x):
+    return _unary("fvo_gelu", x)
+
+
+def leaky_relu(x, slope):
+    return _unary("fvo_leaky_relu", x, ctypes.c_float(slope))
+
+
+def snake(x, alpha, beta=None, logscale=False) -> np.ndarray:
+    """Snake (beta=None) / SnakeBeta (bigvgan.py:60-71 / 121-135)."""
+    x, alpha = _c(x), _c(alpha)
+    beta = alpha if beta is None else _c(beta)
+    B, C, T = x.shape
+    y = np.empty_like(x)
+    lib().fvo_snake(_p(x), _p(alpha), _p(beta), _p(y), B, C, T, int(bool(logscale)))
+    return y
+
+
+def kaiser_sinc_filter(cutoff: float, half_width: float, kernel_size: int) -> np.ndarray:
+    taps = np.empty(kernel_size, np.float32)
+    lib().fvo_kaiser_sinc_filter(cutoff, half_width, kernel_size, _p(taps))
+    return taps
+
+
+def upsample_fir(x, taps, ratio=2) -> np.ndarray:
+    x, taps = _c(x), _c(taps)
+    B, C, T = x.shape
+    y = np.empty((B, C, T * ratio), np.float32)
+    lib().fvo_upsample_fir(_p(x), _p(taps), _p(y), B, C, T, ratio, taps.size)
+    return y
+
+
+def downsample_fir(x, taps, ratio=2) -> np.ndarray:
+    x, taps = _c(x), _c(taps)
+    B, C, T = x.shape
+    ks = taps.size
+    pl, pr = ks // 2 - int(ks % 2 == 0), ks // 2
+    Tout = (T + pl + pr - ks) // ratio + 1
+    y = np.empty((B, C, Tout), np.float32)
+    lib().fvo_downsample_fir(_p(x), _p(taps), _p(y), B, C, T, ratio, ks)
+    return y
+
+
+def activation1d(x, act, up_taps, down_taps, up_ratio=2, down_ratio=2) -> np.ndarray:
+    """alias_free_torch.Activation1d: upsample -> act -> downsample (restated, parity unpinned)."""
+    return downsample_fir(act(upsample_fir(x, up_taps, up_ratio)), down_taps, down_ratio)
+
+
+def layernorm_cf(x, w, b, eps=1e-6) -> np.ndarray:
+    x = _c(x)
+    B, C, T = x.shape
+    y = np.empty_like(x)
+    lib().fvo_layernorm_cf(_p(x), _p(_c(w)), _p(_c(b)), _p(y), B, C, T, ctypes.c_float(eps))
+    return y
+
+
+def scale_residual(x, gamma, res) -> np.ndarray:
+    x, res = _c(x), _c(res)
+    B, C, T = x.shape
+    y = np.empty_like(x)
+    lib().fvo_scale_residual(_p(x), _p(None if gamma is None else _c(gamma)), _p(res), _p(y), B, C, T)
+    return y
+
+
+def istft_same(re, im, n_fft, hop, win) -> np.ndarray:
+    """vocos.spectral_ops.ISTFT(padding='same') (restated, parity unpinned)."""
+    re, im = _c(re), _c(im)
+    B, NB, T = re.shape
+    assert win == n_fft, "the reference head always uses win_length == n_fft"
+    y = np.empty((B, T * hop), np.float32)
+    lib().fvo_istft_same(_p(re), _p(im), _p(y), B, NB, T, n_fft, hop, win)
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# state-dict helpers (reference key names)
+# ------------------------------------------------------------------------------------------------
+def _get_padding(k, d=1):  # hifigan.py:21-22
+    return (k * d - d) // 2
+
+
+def folded_weight(sd, prefix) -> np.ndarray:
+    """Weight of a (possibly weight-normed) conv: parametrizations.weight.original{0,1} or plain .weight."""
+    k0 = f"{prefix}.parametrizations.weight.original0"
+    if k0 in sd:
+        return weight_norm(sd[k0], sd[f"{prefix}.parametrizations.weight.original1"])
+    if f"{prefix}.weight_g" in sd:  # legacy torch.nn.utils.weight_norm naming
+        return weight_norm(sd[f"{prefix}.weight_g"], sd[f"{prefix}.weight_v"])
+    return _c(sd[f"{prefix}.weight"])
+
+
+def _bias(sd, prefix):
+    return _c(sd[f"{prefix}.bias"]) if f"{prefix}.bias" in sd else None
+
+
+def strip_prefix(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+# ------------------------------------------------------------------------------------------------
+# HiFiGAN (fish_vocoder/modules/generators/hifigan.py)
+# ------------------------------------------------------------------------------------------------
+def resblock1_forward(sd, prefix, x, k, dilations):
+    """ResBlock1.forward (hifigan.py:101-108)."""
+    for n, d in enumerate(dilations):
+        xt = silu(x)
+        xt = conv1d(xt, folded_weight(sd, f"{prefix}.convs1.{n}"), _bias(sd, f"{prefix}.convs1.{n}"),
+                    dilation=d, padding=_get_padding(k, d))
+        xt = silu(xt)
+        xt = conv1d(xt, folded_weight(sd, f"{prefix}.convs2.{n}"), _bias(sd, f"{prefix}.convs2.{n}"),
+                    dilation=1, padding=_get_padding(k, 1))
+        x = xt + x
+    return x
+
+
+def hifigan_forward(sd, cfg, mel, collect=None) -> np.ndarray:
+    """HiFiGANGenerator.forward with use_template=False (hifigan.py:226-249).
+
+    cfg keys = the reference ctor kwargs (hifigan.py:137-151).  `collect`, if a dict, receives
+    per-stage activations (for layer-level parity tests).
+    """
+    rates = list(cfg["upsample_rates"])
+    uks = list(cfg["upsample_kernel_sizes"])
+    rks = list(cfg["resblock_kernel_sizes"])
+    rds = [list(d) for d in cfg["resblock_dilation_sizes"]]
+    assert prod(rates) == cfg["hop_length"], f"hop_length must be {prod(rates)}"  # hifigan.py:154-156
+    if cfg.get("use_template", False):
+        raise NotImplementedError("use_template=True is out of scope (SURVEY §0.7)")
+    pk, qk = cfg.get("pre_conv_kernel_size", 7), cfg.get("post_conv_kernel_size", 7)
+
+    x = conv1d(mel, folded_weight(sd, "conv_pre"), _bias(sd, "conv_pre"), padding=_get_padding(pk))
+    if collect is not None:
+        collect["conv_pre"] = x
+    for i, (u, k) in enumerate(zip(rates, uks)):
+        x = silu(x)                                                           # hifigan.py:230
+        x = conv_transpose1d(x, folded_weight(sd, f"ups.{i}"), _bias(sd, f"ups.{i}"),
+                             stride=u, padding=(k - u) // 2)                  # hifigan.py:231
+        if collect is not None:
+            collect[f"ups.{i}"] = x
+        # ParralelBlock: stack(...).mean(0)  (hifigan.py:132-133)
+        outs = [resblock1_forward(sd, f"resblocks.{i}.blocks.{j}", x, rk, rd)
+                for j, (rk, rd) in enumerate(zip(rks, rds))]
+        x = np.mean(np.stack(outs, 0), axis=0, dtype=np.float32)
+        if collect is not None:
+            collect[f"resblocks.{i}"] = x
+    x = silu(x)                                                               # post_activation (hifigan.py:245)
+    x = conv1d(x, folded_weight(sd, "conv_post"), _bias(sd, "conv_post"), padding=_get_padding(qk))
+    return tanh(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# BigVGAN (fish_vocoder/modules/generators/bigvgan.py)
+# ------------------------------------------------------------------------------------------------
+def _aa_filters(sd, prefix):
+    """Activation1d filter taps: use the checkpoint's buffers when present, else the default
+    kaiser-sinc design (ratio 2, 12 taps: cutoff 0.25, half-width 0.3)."""
+    ku, kd = f"{prefix}.upsample.filter", f"{prefix}.downsample.lowpass.filter"
+    default = kaiser_sinc_filter(0.25, 0.3, 12)
+    up = _c(sd[ku]).reshape(-1) if ku in sd else default
+    dn = _c(sd[kd]).reshape(-1) if kd in sd else default
+    return up, dn
+
+
+def _aa_snakebeta(sd, prefix, x, logscale=True):
+    """Activation1d(SnakeBeta(C, alpha_logscale=True)) (bigvgan.py:226-233,335-337)."""
+    up, dn = _aa_filters(sd, prefix)
+    a, b = sd[f"{prefix}.act.alpha"], sd.get(f"{prefix}.act.beta")
+    return activation1d(x, lambda z: snake(z, a, b, logscale), up, dn)
+
+
+def ampblock_forward(sd, prefix, x, k, dilations):
+    """AMPBlock.forward (bigvgan.py:235-245): acts1 = activations[::2], acts2 = activations[1::2]."""
+    for n, d in enumerate(dilations):
+        xt = _aa_snakebeta(sd, f"{prefix}.activations.{2 * n}", x)
+        xt = conv1d(xt, folded_weight(sd, f"{prefix}.convs1.{n}"), _bias(sd, f"{prefix}.convs1.{n}"),
+                    dilation=d, padding=_get_padding(k, d))
+        xt = _aa_snakebeta(sd, f"{prefix}.activations.{2 * n + 1}", xt)
+        xt = conv1d(xt, folded_weight(sd, f"{prefix}.convs2.{n}"), _bias(sd, f"{prefix}.convs2.{n}"),
+                    dilation=1, padding=_get_padding(k, 1))
+        x = xt + x
+    return x
+
+
+def bigvgan_forward(sd, cfg, mel, collect=None) -> np.ndarray:
+    """BigVGANGenerator.forward with use_template=False (bigvgan.py:352-371)."""
+    rates = list(cfg["upsample_rates"])
+    uks = list(cfg["upsample_kernel_sizes"])
+    rks = list(cfg["resblock_kernel_sizes"])
+    rds = [list(d) for d in cfg["resblock_dilation_sizes"]]
+    assert prod(rates) == cfg["hop_length"], f"hop_length must be {prod(rates)}"
+    if cfg.get("use_template", False):
+        raise NotImplementedError("use_template=True is out of scope (SURVEY §0.7)")
+    pk, qk = cfg.get("pre_conv_kernel_size", 7), cfg.get("post_conv_kernel_size", 7)
+    nk = len(rks)
+
+    x = conv1d(mel, folded_weight(sd, "conv_pre"), _bias(sd, "conv_pre"), padding=_get_padding(pk))
+    for i, (u, k) in enumerate(zip(rates, uks)):
+        x = conv_transpose1d(x, folded_weight(sd, f"ups.{i}"), _bias(sd, f"ups.{i}"),
+                             stride=u, padding=(k - u) // 2)                  # no pre-activation (bigvgan.py:355-356)
+        outs = [ampblock_forward(sd, f"resblocks.{i * nk + j}", x, rk, rd)
+                for j, (rk, rd) in enumerate(zip(rks, rds))]
+        x = np.mean(np.stack(outs, 0), axis=0, dtype=np.float32)            # bigvgan.py:361-365
+        if collect is not None:
+            collect[f"stage.{i}"] = x
+    x = _aa_snakebeta(sd, "activation_post", x)                              # bigvgan.py:367
+    x = conv1d(x, folded_weight(sd, "conv_post"), _bias(sd, "conv_post"), padding=_get_padding(qk))
+    return tanh(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# ConvNeXt encoder + Vocos ISTFT head + UnifyGenerator
+# ------------------------------------------------------------------------------------------------
+def convnext_block_forward(sd, prefix, x, kernel_size=7):
+    """ConvNeXtBlock.forward (convnext.py:123-143); Linear layers applied as 1x1 convs on (B, C, T)."""
+    C = x.shape[1]
+    h = conv1d(x, sd[f"{prefix}.dwconv.weight"], sd[f"{prefix}.dwconv.bias"],
+               padding=(kernel_size - 1) // 2, groups=C)
+    h = layernorm_cf(h, sd[f"{prefix}.norm.weight"], sd[f"{prefix}.norm.bias"], 1e-6)
+    h = conv1d(h, _c(sd[f"{prefix}.pwconv1.weight"])[:, :, None], sd[f"{prefix}.pwconv1.bias"])
+    h = gelu(h)
+    h = conv1d(h, _c(sd[f"{prefix}.pwconv2.weight"])[:, :, None], sd[f"{prefix}.pwconv2.bias"])
+    return scale_residual(h, sd.get(f"{prefix}.gamma"), x)
+
+
+def convnext_forward(sd, cfg, x) -> np.ndarray:
+    """ConvNeXtEncoder.forward (convnext.py:206-214)."""
+    depths, dims = list(cfg["depths"]), list(cfg["dims"])
+    ks = cfg.get("kernel_size", 7)
+    for i in range(len(depths)):
+        if i == 0:   # stem: Conv1d(k) + LN_cf  (convnext.py:164-174)
+            x = conv1d(x, sd["downsample_layers.0.0.weight"], sd["downsample_layers.0.0.bias"], padding=ks // 2)
+            x = layernorm_cf(x, sd["downsample_layers.0.1.weight"], sd["downsample_layers.0.1.bias"], 1e-6)
+        else:        # LN_cf + 1x1 conv (convnext.py:177-182)
+            x = layernorm_cf(x, sd[f"downsample_layers.{i}.0.weight"], sd[f"downsample_layers.{i}.0.bias"], 1e-6)
+            x = conv1d(x, sd[f"downsample_layers.{i}.1.weight"], sd[f"downsample_layers.{i}.1.bias"])
+        for j in range(depths[i]):
+            x = convnext_block_forward(sd, f"stages.{i}.{j}", x, ks)
+    return layernorm_cf(x, sd["norm.weight"], sd["norm.bias"], 1e-6)
+
+
+def istft_head_pre(sd, x):
+    """ISTFTHead.forward up to (but excluding) self.istft (vocos.py:55-67): returns (re, im), each (B, n_fft, T)."""
+    h = conv1d(x, sd["out.weight"], sd["out.bias"])
+    B, C2, T = h.shape
+    n_fft = C2 // 2
+    re = np.empty((B, n_fft, T), np.float32)
+    im = np.empty((B, n_fft, T), np.float32)
+    lib().fvo_istft_head_post(_p(h), _p(re), _p(im), B, n_fft, T)
+    return re, im
+
+
+def istft_head_forward(sd, cfg, x) -> np.ndarray:
+    """ISTFTHead.forward (vocos.py:43-69) -> (B, T*hop)."""
+    re, im = istft_head_pre(sd, x)
+    return istft_same(re, im, cfg["n_fft"], cfg["hop_length"], cfg["win_length"])
+
+
+def vocos_forward(sd, cfg, mel) -> np.ndarray:
+    """UnifyGenerator(ConvNeXtEncoder, ISTFTHead).forward, intended semantics (unify.py:18-33):
+    head(backbone(x))[:, None, :]."""
+    h = convnext_forward(strip_prefix(sd, "backbone."), cfg["backbone"], mel)
+    y = istft_head_forward(strip_prefix(sd, "head."), cfg["head"], h)
+    return y[:, None, :]
+
+
+def firefly_forward(sd, cfg, mel) -> np.ndarray:
+    """UnifyGenerator(ConvNeXtEncoder, HiFiGANGenerator) (configs/model/generator/firefly-gan-base.yaml)."""
+    h = convnext_forward(strip_prefix(sd, "backbone."), cfg["backbone"], mel)
+    return hifigan_forward(strip_prefix(sd, "head."), cfg["head"], h)

@@ -1,0 +1,362 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory by IMPORTING THE REFERENCE on CPU.
+
+Runs only in the build container (needs /root/reference and torch); the fixtures it
+writes are plain data (inputs + expected outputs, .npz) and travel with the repo, the
+reference does not.  Usage:  python tests/golden/gen_golden.py
+
+Weights are not stored: every fixture records the seed and config, and both this script
+and the tests regenerate the state dict with ``vocoder_amd.synthetic`` (numpy PCG64 —
+platform-stable).
+
+Third-party stubs: ``alias_free_torch`` (0.0.6) and ``vocos`` (0.0.2) are not installed
+and not vendored in /root/reference, so ``bigvgan.py`` / ``vocos.py`` cannot be imported
+as-is.  This script injects stand-in modules that restate the two packages' published
+algorithms with torch ops (F.conv_transpose1d / F.conv1d / torch.fft.irfft / F.fold —
+a different code path from the C oracle's direct loops).  Fixtures that depend on those
+stand-ins are marked ``pinned=False`` ("parity unpinned"): they pin the
+reference's own wiring (AMPBlock order, stack-mean, head arithmetic) but not the
+third-party arithmetic itself.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+from vocoder_amd import synthetic as syn  # noqa: E402
+
+
+# --------------------------------------------------------------------------------------------
+# stand-ins for the two absent third-party packages
+# --------------------------------------------------------------------------------------------
+def _kaiser_sinc_filter1d(cutoff, half_width, kernel_size):
+    even = kernel_size % 2 == 0
+    half_size = kernel_size // 2
+    delta_f = 4 * half_width
+    A = 2.285 * (half_size - 1) * math.pi * delta_f + 7.95
+    if A > 50.0:
+        beta = 0.1102 * (A - 8.7)
+    elif A >= 21.0:
+        beta = 0.5842 * (A - 21) ** 0.4 + 0.07886 * (A - 21.0)
+    else:
+        beta = 0.0
+    window = torch.kaiser_window(kernel_size, beta=beta, periodic=False)
+    if even:
+        time = torch.arange(-half_size, half_size) + 0.5
+    else:
+        time = torch.arange(kernel_size) - half_size
+    if cutoff == 0:
+        filt = torch.zeros_like(time)
+    else:
+        filt = 2 * cutoff * window * torch.sinc(2 * cutoff * time)
+        filt = filt / filt.sum()
+    return filt.view(1, 1, kernel_size)
+
+
+class _LowPassFilter1d(nn.Module):
+    def __init__(self, cutoff=0.5, half_width=0.6, stride=1, kernel_size=12):
+        super().__init__()
+        self.even = kernel_size % 2 == 0
+        self.pad_left = kernel_size // 2 - int(self.even)
+        self.pad_right = kernel_size // 2
+        self.stride = stride
+        self.register_buffer("filter", _kaiser_sinc_filter1d(cutoff, half_width, kernel_size))
+
+    def forward(self, x):
+        C = x.shape[1]
+        x = F.pad(x, (self.pad_left, self.pad_right), mode="replicate")
+        return F.conv1d(x, self.filter.expand(C, -1, -1), stride=self.stride, groups=C)
+
+
+class _UpSample1d(nn.Module):
+    def __init__(self, ratio=2, kernel_size=None):
+        super().__init__()
+        self.ratio = ratio
+        self.kernel_size = int(6 * ratio // 2) * 2 if kernel_size is None else kernel_size
+        self.stride = ratio
+        self.pad = self.kernel_size // ratio - 1
+        self.pad_left = self.pad * self.stride + (self.kernel_size - self.stride) // 2
+        self.pad_right = self.pad * self.stride + (self.kernel_size - self.stride + 1) // 2
+        self.register_buffer("filter", _kaiser_sinc_filter1d(0.5 / ratio, 0.6 / ratio, self.kernel_size))
+
+    def forward(self, x):
+        C = x.shape[1]
+        x = F.pad(x, (self.pad, self.pad), mode="replicate")
+        x = self.ratio * F.conv_transpose1d(x, self.filter.expand(C, -1, -1), stride=self.stride, groups=C)
+        return x[..., self.pad_left:-self.pad_right]
+
+
+class _DownSample1d(nn.Module):
+    def __init__(self, ratio=2, kernel_size=None):
+        super().__init__()
+        ks = int(6 * ratio // 2) * 2 if kernel_size is None else kernel_size
+        self.lowpass = _LowPassFilter1d(0.5 / ratio, 0.6 / ratio, stride=ratio, kernel_size=ks)
+
+    def forward(self, x):
+        return self.lowpass(x)
+
+
+class _Activation1d(nn.Module):
+    def __init__(self, activation, up_ratio=2, down_ratio=2, up_kernel_size=12, down_kernel_size=12):
+        super().__init__()
+        self.act = activation
+        self.upsample = _UpSample1d(up_ratio, up_kernel_size)
+        self.downsample = _DownSample1d(down_ratio, down_kernel_size)
+
+    def forward(self, x):
+        return self.downsample(self.act(self.upsample(x)))
+
+
+class _ISTFT(nn.Module):
+    def __init__(self, n_fft, hop_length, win_length, padding="same"):
+        super().__init__()
+        self.padding, self.n_fft, self.hop_length, self.win_length = padding, n_fft, hop_length, win_length
+        self.register_buffer("window", torch.hann_window(win_length))
+        self.capture = None
+
+    def forward(self, spec):
+        self.capture = spec
+        assert self.padding == "same"
+        pad = (self.win_length - self.hop_length) // 2
+        B, N, T = spec.shape
+        ifft = torch.fft.irfft(spec, self.n_fft, dim=1, norm="backward")
+        ifft = ifft * self.window[None, :, None]
+        output_size = (T - 1) * self.hop_length + self.win_length
+        y = F.fold(ifft, output_size=(1, output_size), kernel_size=(1, self.win_length),
+                   stride=(1, self.hop_length))[:, 0, 0, pad:-pad]
+        window_sq = self.window.square().expand(1, T, -1).transpose(1, 2)
+        env = F.fold(window_sq, output_size=(1, output_size), kernel_size=(1, self.win_length),
+                     stride=(1, self.hop_length)).squeeze()[pad:-pad]
+        assert (env > 1e-11).all()
+        return y / env
+
+
+def _inject_stubs():
+    aft = types.ModuleType("alias_free_torch")
+    aft.Activation1d = _Activation1d
+    sys.modules["alias_free_torch"] = aft
+    voc = types.ModuleType("vocos")
+    so = types.ModuleType("vocos.spectral_ops")
+    so.ISTFT = _ISTFT
+    voc.spectral_ops = so
+    sys.modules["vocos"] = voc
+    sys.modules["vocos.spectral_ops"] = so
+
+
+_inject_stubs()
+
+from fish_vocoder.modules.encoders.convnext import ConvNeXtEncoder  # noqa: E402
+from fish_vocoder.modules.generators.bigvgan import BigVGANGenerator, Snake, SnakeBeta  # noqa: E402
+from fish_vocoder.modules.generators.hifigan import HiFiGANGenerator  # noqa: E402
+from fish_vocoder.modules.generators.vocos import ISTFTHead  # noqa: E402
+
+
+def _t(sd):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def _save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: " + ", ".join(f"{k}{tuple(np.asarray(v).shape)}" for k, v in arrays.items()),
+          f"[{os.path.getsize(path) / 1024:.1f} KiB]")
+
+
+def _cfg_arr(cfg):
+    return np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+
+
+@torch.no_grad()
+def gen_hifigan(name, cfg, seed, B, T, mel_seed, stages=True):
+    sd = syn.hifigan_state_dict(cfg, seed)
+    g = HiFiGANGenerator(**cfg).eval()
+    g.load_state_dict(_t(sd), strict=True)
+    mel = syn.synthetic_mel(B, cfg["num_mels"], T, mel_seed)
+    acts = {}
+    if stages:
+        for i in range(len(cfg["upsample_rates"])):
+            g.ups[i].register_forward_hook(lambda m, a, o, i=i: acts.__setitem__(f"ups{i}", o.numpy().copy()))
+            g.resblocks[i].register_forward_hook(
+                lambda m, a, o, i=i: acts.__setitem__(f"resblocks{i}", o.numpy().copy()))
+        g.conv_pre.register_forward_hook(lambda m, a, o: acts.__setitem__("conv_pre", o.numpy().copy()))
+    out = g(torch.from_numpy(mel)).numpy()
+    _save(name, cfg=_cfg_arr(cfg), seed=seed, mel=mel, out=out, pinned=True, **acts)
+
+
+@torch.no_grad()
+def gen_ops():
+    rng = np.random.default_rng(7)
+    arrs = {}
+    # weight-norm fold pairs: Conv1d (dim0 = C_out) and ConvTranspose1d (dim0 = C_in)  
+    for tag, shape in (("c1d", (6, 5, 3)), ("ct1d", (8, 4, 16))):
+        v = rng.normal(size=shape).astype(np.float32)
+        g = rng.uniform(0.5, 2.0, size=(shape[0], 1, 1)).astype(np.float32)
+        arrs[f"wn_{tag}_v"], arrs[f"wn_{tag}_g"] = v, g
+        arrs[f"wn_{tag}_w"] = torch._weight_norm(torch.from_numpy(v), torch.from_numpy(g), 0).numpy()
+    # dilated "same" conv, as every ResBlock1 conv (hifigan.py:31-57)
+    for k, d in ((3, 1), (7, 3), (11, 5)):
+        x = rng.normal(size=(2, 6, 61)).astype(np.float32)
+        w = rng.normal(size=(4, 6, k)).astype(np.float32)
+        b = rng.normal(size=4).astype(np.float32)
+        arrs[f"conv_k{k}d{d}_x"], arrs[f"conv_k{k}d{d}_w"], arrs[f"conv_k{k}d{d}_b"] = x, w, b
+        arrs[f"conv_k{k}d{d}_y"] = F.conv1d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b),
+                                            dilation=d, padding=(k * d - d) // 2).numpy()
+    # transposed convs with the reference's (k, u) pairs (hifigan.py:177-187; firefly-gan-base.yaml:13)
+    for k, u in ((16, 8), (8, 2), (2, 2), (4, 4), (4, 2)):
+        x = rng.normal(size=(2, 6, 9)).astype(np.float32)
+        w = rng.normal(size=(6, 4, k)).astype(np.float32)
+        b = rng.normal(size=4).astype(np.float32)
+        arrs[f"convT_k{k}u{u}_x"], arrs[f"convT_k{k}u{u}_w"], arrs[f"convT_k{k}u{u}_b"] = x, w, b
+        arrs[f"convT_k{k}u{u}_y"] = F.conv_transpose1d(torch.from_numpy(x), torch.from_numpy(w),
+                                                       torch.from_numpy(b), stride=u, padding=(k - u) // 2).numpy()
+    # depthwise conv (convnext.py:103-109)
+    x = rng.normal(size=(2, 5, 23)).astype(np.float32)
+    w = rng.normal(size=(5, 1, 7)).astype(np.float32)
+    b = rng.normal(size=5).astype(np.float32)
+    arrs["dw_x"], arrs["dw_w"], arrs["dw_b"] = x, w, b
+    arrs["dw_y"] = F.conv1d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), padding=3, groups=5).numpy()
+    # elementwise
+    x = rng.normal(scale=3.0, size=(1000,)).astype(np.float32)
+    arrs["ew_x"] = x
+    arrs["ew_silu"] = F.silu(torch.from_numpy(x)).numpy()
+    arrs["ew_tanh"] = torch.tanh(torch.from_numpy(x)).numpy()
+    arrs["ew_gelu"] = F.gelu(torch.from_numpy(x)).numpy()
+    _save("ops.npz", pinned=True, **arrs)
+
+
+@torch.no_grad()
+def gen_snake():
+    rng = np.random.default_rng(11)
+    x = rng.normal(scale=2.0, size=(2, 6, 40)).astype(np.float32)
+    arrs = {"x": x}
+    for cls, tag in ((Snake, "snake"), (SnakeBeta, "snakebeta")):
+        for logscale in (False, True):
+            m = cls(6, alpha_logscale=logscale)
+            a = rng.normal(0.0 if logscale else 1.0, 0.4, size=6).astype(np.float32)
+            m.alpha.data = torch.from_numpy(a)
+            arrs[f"{tag}_ls{int(logscale)}_alpha"] = a
+            if hasattr(m, "beta"):
+                b = rng.normal(0.0 if logscale else 1.0, 0.4, size=6).astype(np.float32)
+                m.beta.data = torch.from_numpy(b)
+                arrs[f"{tag}_ls{int(logscale)}_beta"] = b
+            arrs[f"{tag}_ls{int(logscale)}_y"] = m(torch.from_numpy(x)).numpy()
+    _save("snake.npz", pinned=True, **arrs)
+
+
+@torch.no_grad()
+def gen_convnext(name, cfg, seed, B, T, mel_seed):
+    sd = syn.convnext_state_dict(cfg, seed)
+    m = ConvNeXtEncoder(**cfg).eval()
+    m.load_state_dict(_t(sd), strict=True)
+    x = syn.synthetic_mel(B, cfg["input_channels"], T, mel_seed)
+    out = m(torch.from_numpy(x)).numpy()
+    _save(name, cfg=_cfg_arr(cfg), seed=seed, mel=x, out=out, pinned=True)
+
+
+@torch.no_grad()
+def gen_istft_head(name, cfg, seed, B, T):
+    """ISTFTHead up to the ISTFT call is reference arithmetic (pinned); the waveform goes through the
+    stand-in ISTFT (unpinned)."""
+    sd = syn.istft_head_state_dict(cfg, seed)
+    m = ISTFTHead(**cfg).eval()
+    m.load_state_dict(_t(sd), strict=True)
+    rng = np.random.default_rng(seed + 100)
+    x = rng.normal(size=(B, cfg["dim"], T)).astype(np.float32)
+    wave = m(torch.from_numpy(x)).numpy()
+    S = m.istft.capture
+    _save(name, cfg=_cfg_arr(cfg), seed=seed, x=x, re=S.real.numpy().copy(), im=S.imag.numpy().copy(),
+          wave=wave, pinned_pre=True, pinned_wave=False)
+
+
+@torch.no_grad()
+def gen_bigvgan(name, cfg, seed, B, T, mel_seed):
+    sd = syn.bigvgan_state_dict(cfg, seed)
+    g = BigVGANGenerator(**cfg).eval()
+    missing, unexpected = g.load_state_dict(_t(sd), strict=False)
+    assert not unexpected and all(k.endswith("filter") for k in missing), (missing, unexpected)
+    mel = syn.synthetic_mel(B, cfg["num_mels"], T, mel_seed)
+    out = g(torch.from_numpy(mel)).numpy()
+    _save(name, cfg=_cfg_arr(cfg), seed=seed, mel=mel, out=out, pinned=False)
+
+
+@torch.no_grad()
+def gen_activation1d():
+    """Stand-in Activation1d(SnakeBeta) + the filter taps it designs (unpinned; KAT material)."""
+    rng = np.random.default_rng(5)
+    x = rng.normal(scale=1.5, size=(2, 4, 37)).astype(np.float32)
+    act = SnakeBeta(4, alpha_logscale=True)
+    a = rng.normal(0, 0.3, size=4).astype(np.float32)
+    b = rng.normal(0, 0.3, size=4).astype(np.float32)
+    act.alpha.data, act.beta.data = torch.from_numpy(a), torch.from_numpy(b)
+    m = _Activation1d(act)
+    xt = torch.from_numpy(x)
+    _save("activation1d.npz", x=x, alpha=a, beta=b, taps=m.upsample.filter.reshape(-1).numpy(),
+          up=m.upsample(xt).numpy(), down=m.downsample(m.upsample(xt)).numpy(), y=m(xt).numpy(), pinned=False)
+
+
+@torch.no_grad()
+def gen_vocos(name, cfg, seed, B, T, mel_seed):
+    """Intended UnifyGenerator semantics head(backbone(x))[:, None, :] (the YAML as shipped
+    raises TypeError on template=)."""
+    sd = syn.vocos_state_dict(cfg, seed)
+    bb = ConvNeXtEncoder(**cfg["backbone"]).eval()
+    hd = ISTFTHead(**cfg["head"]).eval()
+    bb.load_state_dict(_t({k[9:]: v for k, v in sd.items() if k.startswith("backbone.")}), strict=True)
+    hd.load_state_dict(_t({k[5:]: v for k, v in sd.items() if k.startswith("head.")}), strict=True)
+    mel = syn.synthetic_mel(B, cfg["backbone"]["input_channels"], T, mel_seed)
+    h = bb(torch.from_numpy(mel))
+    out = hd(h)[:, None, :].numpy()
+    _save(name, cfg=_cfg_arr(cfg), seed=seed, mel=mel, hidden=h.numpy(), out=out, pinned=False)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    tiny = dict(hop_length=16, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4],
+                resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
+                num_mels=20, upsample_initial_channel=64, use_template=False,
+                pre_conv_kernel_size=7, post_conv_kernel_size=7)
+    gen_hifigan("hifigan_tiny.npz", tiny, seed=3, B=2, T=13, mel_seed=21)
+    # narrow channels down to C=2 and odd kernel / rate mixes (edge cases for channel padding)
+    narrow = dict(hop_length=32, upsample_rates=[2, 2, 2, 2, 2], upsample_kernel_sizes=[4, 4, 2, 2, 4],
+                  resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2, 3], [2, 6, 1]],
+                  num_mels=10, upsample_initial_channel=64, use_template=False,
+                  pre_conv_kernel_size=5, post_conv_kernel_size=3)
+    gen_hifigan("hifigan_narrow.npz", narrow, seed=4, B=3, T=7, mel_seed=22)
+    # the BASELINE config (HiFiGAN-V1-44k, 80 mel) on a short clip; weights regenerate from the seed
+    gen_hifigan("hifigan_v1_t12.npz", dict(syn.HIFIGAN_V1_44K), seed=0, B=1, T=12, mel_seed=1234, stages=False)
+    # single-frame clip (ragged minimum)
+    gen_hifigan("hifigan_tiny_t1.npz", tiny, seed=3, B=1, T=1, mel_seed=23, stages=False)
+    gen_ops()
+    gen_snake()
+    cn = dict(input_channels=20, depths=[1, 2], dims=[16, 32], drop_path_rate=0.1, kernel_size=7)
+    gen_convnext("convnext_small.npz", cn, seed=5, B=2, T=17, mel_seed=24)
+    gen_istft_head("istft_head.npz", dict(dim=24, n_fft=64, hop_length=16, win_length=64, padding="same"),
+                   seed=6, B=2, T=9)
+    bv = dict(hop_length=16, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4],
+              resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
+              num_mels=20, upsample_initial_channel=64, use_template=False,
+              pre_conv_kernel_size=7, post_conv_kernel_size=7)
+    gen_bigvgan("bigvgan_tiny.npz", bv, seed=8, B=2, T=11, mel_seed=25)
+    gen_activation1d()
+    vc = dict(backbone=dict(input_channels=20, depths=[1, 1, 2, 1], dims=[16, 32, 48, 64], drop_path_rate=0.4,
+                            kernel_size=7),
+              head=dict(dim=64, n_fft=64, hop_length=16, win_length=64, padding="same"))
+    gen_vocos("vocos_tiny.npz", vc, seed=9, B=2, T=15, mel_seed=26)
+
+
+if __name__ == "__main__":
+    main()
