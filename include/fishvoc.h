@@ -1,0 +1,187 @@
+/*
+ * fishvoc.h — C ABI of libfishvoc_hip.so, the MI355X (gfx950) vocoder inference engine.
+ *
+ * The reference (fishaudio/vocoder, /root/reference) has NO FFI: its generator hot path is
+ * `nn.Module.forward` built by Hydra `_target_` (fish_vocoder/test.py:31,89 ->
+ * fish_vocoder/models/gan.py:282-288 -> fish_vocoder/modules/generators/).  This header is
+ * therefore the boundary a maintainer would bind from Python (ctypes) to replace that forward:
+ * each entry point names the reference interface it stands in for.  INTEGRATION.md shows the
+ * reference-side stub.
+ *
+ * Conventions
+ *   - plain C types only; tensors are contiguous fp32, layout (B, C, T) with T fastest — the
+ *     reference's own layout (hifigan.py:226, forward(x: (B, num_mels, T_mel))).
+ *   - `const float* host_*` pointers are HOST memory and are copied during the call (the caller keeps
+ *     ownership); `d_*` pointers are DEVICE memory borrowed for the duration of the asynchronous
+ *     work enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *   - every function returns FV_OK (0) or a negative fv_status; fv_last_error() returns a
+ *     thread-local message.  Nothing throws across the ABI.
+ *   - one engine per device/model; fv_forward on one engine is re-entrant only with distinct
+ *     workspaces and streams.
+ */
+#ifndef FISHVOC_H
+#define FISHVOC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FV_ABI_VERSION 1
+
+/* every entry point below is exported with default visibility (the library is built -fvisibility=hidden) */
+#if defined(__GNUC__)
+#define FV_API __attribute__((visibility("default")))
+#else
+#define FV_API
+#endif
+
+typedef int fv_status;
+enum {
+    FV_OK = 0,
+    FV_ERR_INVALID = -1,      /* bad argument / config (e.g. prod(upsample_rates) != hop_length) */
+    FV_ERR_UNSUPPORTED = -2,  /* valid in the reference but out of scope here (use_template=True) */
+    FV_ERR_MISSING_WEIGHT = -3,
+    FV_ERR_SHAPE = -4,
+    FV_ERR_HIP = -5,          /* a HIP runtime call failed */
+    FV_ERR_STATE = -6         /* e.g. fv_forward before fv_finalize */
+};
+
+/* Model families == the reference generator classes reachable from configs/model/generator/ YAMLs */
+typedef enum fv_model_kind {
+    FV_MODEL_HIFIGAN = 1,  /* fish_vocoder.modules.generators.hifigan.HiFiGANGenerator (hifigan.py:136) */
+    FV_MODEL_BIGVGAN = 2,  /* fish_vocoder.modules.generators.bigvgan.BigVGANGenerator (bigvgan.py:255) */
+    FV_MODEL_VOCOS = 3,    /* UnifyGenerator(ConvNeXtEncoder, ISTFTHead) (unify.py:5, convnext.py:146, vocos.py:6) */
+    FV_MODEL_FIREFLY = 4,  /* UnifyGenerator(ConvNeXtEncoder, HiFiGANGenerator) (firefly-gan-base.yaml) */
+    FV_MODEL_CONVNEXT = 5, /* ConvNeXtEncoder alone: (B, C_in, T) -> (B, dims[-1], T) */
+    FV_MODEL_ISTFT_HEAD = 6 /* ISTFTHead alone: (B, dim, T) -> (B, 1, T*hop) (vocos.py:43-69) */
+} fv_model_kind;
+
+#define FV_MAX_STAGES 8
+#define FV_MAX_KERNELS 8
+#define FV_MAX_DILATIONS 3 /* ResBlock1 / AMPBlock hard-code three (c1, c2) pairs (hifigan.py:29-93) */
+
+/* Activation selector for the fused conv kernels (the reference "HiFiGAN" uses SiLU). */
+typedef enum fv_act {
+    FV_ACT_NONE = 0,
+    FV_ACT_SILU = 1,       /* F.silu (hifigan.py:103,105,230) */
+    FV_ACT_LEAKY_RELU = 2, /* slope in fv_conv_desc.act_slope (refinegan.py:89; kept for completeness) */
+    FV_ACT_GELU = 3,       /* nn.GELU() exact erf (convnext.py:114) */
+    FV_ACT_TANH = 4        /* torch.tanh (hifigan.py:247) */
+} fv_act;
+
+/* HiFiGANGenerator / BigVGANGenerator ctor kwargs (hifigan.py:137-151, bigvgan.py:256-270). */
+typedef struct fv_upsampler_config {
+    int32_t hop_length;
+    int32_t num_upsamples;
+    int32_t upsample_rates[FV_MAX_STAGES];
+    int32_t upsample_kernel_sizes[FV_MAX_STAGES];
+    int32_t num_kernels;
+    int32_t resblock_kernel_sizes[FV_MAX_KERNELS];
+    int32_t resblock_dilation_sizes[FV_MAX_KERNELS][FV_MAX_DILATIONS];
+    int32_t num_mels;
+    int32_t upsample_initial_channel;
+    int32_t use_template; /* must be 0: every shipped YAML sets use_template: false (hifigan.yaml:9) */
+    int32_t pre_conv_kernel_size;
+    int32_t post_conv_kernel_size;
+} fv_upsampler_config;
+
+/* ConvNeXtEncoder ctor kwargs (convnext.py:147-155); drop_path is identity in eval and not represented. */
+typedef struct fv_convnext_config {
+    int32_t input_channels;
+    int32_t num_stages;
+    int32_t depths[FV_MAX_STAGES];
+    int32_t dims[FV_MAX_STAGES];
+    int32_t kernel_size;
+} fv_convnext_config;
+
+/* ISTFTHead ctor kwargs (vocos.py:19-26); padding must be "same" (vocos.yaml:15). */
+typedef struct fv_istft_head_config {
+    int32_t dim;
+    int32_t n_fft;
+    int32_t hop_length;
+    int32_t win_length;
+} fv_istft_head_config;
+
+typedef struct fv_config {
+    int32_t abi_version; /* = FV_ABI_VERSION */
+    int32_t model;       /* fv_model_kind */
+    fv_upsampler_config ups;   /* HIFIGAN, BIGVGAN, FIREFLY(head) */
+    fv_convnext_config backbone; /* VOCOS, FIREFLY, CONVNEXT */
+    fv_istft_head_config head;   /* VOCOS */
+} fv_config;
+
+typedef struct fv_engine fv_engine;
+
+/* -------- engine lifecycle: replaces `instantiate(cfg.model)` + `load_state_dict` (test.py:31-38) -------- */
+
+/* Validates the config exactly as the reference ctor does (assert prod(upsample_rates) == hop_length,
+ * hifigan.py:154-156 -> FV_ERR_INVALID) and allocates an engine on the current HIP device. */
+FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out);
+
+/* Feed one tensor of the reference state dict, by its reference name (keys as produced by the reference
+ * modules, e.g. "conv_pre.parametrizations.weight.original0", "ups.0.bias",
+ * "resblocks.1.blocks.2.convs2.0.parametrizations.weight.original1"; legacy "weight_g"/"weight_v" and plain
+ * "weight" are accepted too).  Unknown names -> FV_ERR_INVALID; wrong shape -> FV_ERR_SHAPE.  Data is copied. */
+FV_API fv_status fv_load_weight(fv_engine* e, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+
+/* Fold weight-norm (w = g * v / ||v||, dim 0 — hifigan.py:31; C_in for ConvTranspose1d), re-lay-out weights
+ * into MFMA fragment order and upload.  FV_ERR_MISSING_WEIGHT names the first absent tensor (strict load,
+ * like test.py:37). */
+FV_API fv_status fv_finalize(fv_engine* e);
+
+FV_API void fv_destroy(fv_engine* e);
+
+/* -------- forward: replaces `self.generator(input_spec)` (gan.py:286) -------- */
+
+/* Output length per clip for T_in input frames (T_mel * hop_length for the generators). */
+FV_API int64_t fv_output_length(const fv_engine* e, int32_t t_in);
+/* Output channels (1 for the generators, dims[-1] for FV_MODEL_CONVNEXT). */
+FV_API int32_t fv_output_channels(const fv_engine* e);
+/* Input channels (num_mels / input_channels). */
+FV_API int32_t fv_input_channels(const fv_engine* e);
+
+/* Bytes of device scratch fv_forward needs for a (batch, t_in) call. */
+FV_API size_t fv_workspace_bytes(const fv_engine* e, int32_t batch, int32_t t_in);
+
+/* d_in: (batch, C_in, t_in) fp32; d_out: (batch, C_out, fv_output_length) fp32; d_workspace: >= fv_workspace_bytes,
+ * 256-byte aligned.  Asynchronous on `stream`. */
+FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32_t batch, int32_t t_in, void* d_workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* -------- single fused conv layer (the hot kernel on its own; used by the parity tests and the roofline
+ *          bench).  Stands in for one weight-normed nn.Conv1d / nn.ConvTranspose1d call plus the elementwise
+ *          ops the reference runs around it (F.silu before, residual add after: hifigan.py:101-108). -------- */
+typedef struct fv_conv_desc {
+    int32_t transposed; /* 0: Conv1d weight (C_out, C_in, k); 1: ConvTranspose1d weight (C_in, C_out, k) */
+    int32_t c_in, c_out, kernel_size;
+    int32_t dilation; /* Conv1d only */
+    int32_t padding;  /* Conv1d: zero padding each side; ConvTranspose1d: `padding` argument */
+    int32_t stride;   /* ConvTranspose1d only (Conv1d stride is always 1 on this path) */
+    int32_t pre_act;  /* fv_act applied to the input (fused into the LDS staging) */
+    int32_t post_act; /* fv_act applied after bias (+ residual) */
+    float act_slope;
+} fv_conv_desc;
+
+typedef struct fv_conv fv_conv;
+
+/* host_weight: already-folded weight in the torch layout named by `transposed`; host_bias may be NULL. */
+FV_API fv_status fv_conv_create(const fv_conv_desc* desc, const float* host_weight, const float* host_bias, fv_conv** out);
+FV_API int64_t fv_conv_output_length(const fv_conv* c, int32_t t_in);
+/* y = post_act(conv(pre_act(x)) + bias [+ d_residual]); d_residual may be NULL or alias d_y. */
+FV_API fv_status fv_conv_forward(fv_conv* c, const float* d_x, float* d_y, const float* d_residual, int32_t batch,
+                          int32_t t_in, void* stream);
+FV_API void fv_conv_destroy(fv_conv* c);
+
+/* -------- misc -------- */
+FV_API const char* fv_last_error(void);
+FV_API int32_t fv_abi_version(void);
+/* Name of the device kernel variant the last fv_conv_forward on this thread dispatched (diagnostics). */
+FV_API const char* fv_last_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FISHVOC_H */

@@ -1,0 +1,143 @@
+"""GPU: the fused MFMA conv kernel (through the C ABI, fv_conv_*) against the CPU oracle on seeded inputs.
+Tolerance: |d| <= 1e-4 absolute (north_star) — in practice ~1e-6 since the MFMA path is exact fp32."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test on a box without a GPU"
+    return torch.device("cuda:0")
+
+
+def _run(w, b, x, res=None, **kw):
+    from vocoder_amd.engine import FusedConv
+    conv = FusedConv(w, b, **kw)
+    xt = torch.from_numpy(x).to(_dev())
+    rt = None if res is None else torch.from_numpy(res).to(_dev())
+    y = conv(xt, rt)
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+def _check(y, ref, atol=1e-4):
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    err = np.abs(y - ref).max()
+    scale = np.abs(ref).max()
+    assert err <= atol, f"max|d|={err:.3e} (ref max {scale:.3f})"
+    assert err <= 2e-5 * max(scale, 1.0), f"max|d|={err:.3e} looks too large for an exact-fp32 path (ref max {scale:.3f})"
+
+
+CONV_CASES = [
+    # (Cin, Cout, k, dil, B, T)
+    (256, 256, 3, 1, 2, 200), (256, 256, 7, 3, 1, 130), (256, 256, 11, 5, 1, 97),
+    (128, 128, 3, 3, 2, 300), (128, 128, 11, 1, 1, 517),
+    (64, 64, 7, 5, 2, 700), (64, 64, 3, 5, 1, 1025),
+    (32, 32, 11, 3, 2, 1500), (32, 32, 7, 1, 1, 640),
+    (16, 16, 3, 1, 3, 2100), (16, 16, 11, 5, 1, 515),
+    (80, 512, 7, 1, 2, 86),          # conv_pre of HiFiGAN-V1 (C_in not a multiple of 8 chunks? 80 = 10 chunks)
+    (10, 64, 5, 1, 2, 33),           # odd C_in -> zero-padded channel chunk, generic (k=5) kernel
+    (6, 4, 5, 2, 2, 61), (2, 2, 3, 2, 1, 9), (1, 3, 13, 1, 1, 40),
+    (512, 512, 13, 1, 1, 50),        # firefly pre conv
+    (128, 512, 1, 1, 2, 94), (512, 128, 1, 1, 2, 94),   # ConvNeXt pointwise
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,d,B,T", CONV_CASES)
+def test_conv1d_silu_residual_matches_oracle(cin, cout, k, d, B, T):
+    from vocoder_amd import _lib
+    rng = np.random.default_rng(cin * 1000 + cout + k * 7 + d)
+    x = rng.normal(size=(B, cin, T)).astype(np.float32)
+    w = (rng.normal(size=(cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)   # asymmetric, transpose-detecting
+    b = rng.normal(size=cout).astype(np.float32)
+    pad = (k * d - d) // 2
+    ref = orc.conv1d(orc.silu(x), w, b, dilation=d, padding=pad)
+    res = rng.normal(size=ref.shape).astype(np.float32)
+    y = _run(w, b, x, res, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
+    _check(y, ref + res)
+    # plain conv, no activation / residual / bias
+    y2 = _run(w, None, x, None, dilation=d, padding=pad)
+    _check(y2, orc.conv1d(x, w, None, dilation=d, padding=pad))
+
+
+def test_conv1d_post_activations():
+    from vocoder_amd import _lib
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(2, 32, 300)).astype(np.float32)
+    w = (rng.normal(size=(32, 32, 3)) / 8).astype(np.float32)
+    b = rng.normal(size=32).astype(np.float32)
+    lin = orc.conv1d(x, w, b, padding=1)
+    _check(_run(w, b, x, padding=1, post_act=_lib.FV_ACT_SILU), orc.silu(lin))
+    _check(_run(w, b, x, padding=1, post_act=_lib.FV_ACT_GELU), orc.gelu(lin))
+    _check(_run(w, b, x, padding=1, post_act=_lib.FV_ACT_TANH), orc.tanh(lin))
+    _check(_run(w, b, x, padding=1, pre_act=_lib.FV_ACT_LEAKY_RELU, act_slope=0.2),
+           orc.conv1d(orc.leaky_relu(x, 0.2), w, b, padding=1))
+
+
+CONVT_CASES = [
+    # (Cin, Cout, k, u, B, T)
+    (512, 256, 16, 8, 2, 86), (256, 128, 16, 8, 1, 100), (128, 64, 8, 2, 2, 300), (64, 32, 2, 2, 1, 700),
+    (32, 16, 2, 2, 2, 1111), (128, 64, 4, 2, 1, 257), (64, 32, 4, 4, 1, 50), (8, 4, 4, 2, 2, 17), (4, 2, 7, 3, 1, 11),
+    (16, 8, 3, 2, 1, 21),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,u,B,T", CONVT_CASES)
+def test_conv_transpose1d_matches_oracle(cin, cout, k, u, B, T):
+    from vocoder_amd import _lib
+    rng = np.random.default_rng(cin + cout * 3 + k + u)
+    x = rng.normal(size=(B, cin, T)).astype(np.float32)
+    w = (rng.normal(size=(cin, cout, k)) / np.sqrt(cin * max(k // u, 1))).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    pad = (k - u) // 2
+    ref = orc.conv_transpose1d(orc.silu(x), w, b, stride=u, padding=pad)
+    y = _run(w, b, x, transposed=True, stride=u, padding=pad, pre_act=_lib.FV_ACT_SILU)
+    _check(y, ref)
+
+
+def test_golden_ops_through_hip():
+    """The same golden vectors that pin the oracle (captured from torch / the reference), straight through HIP."""
+    from conftest import load_golden
+    g = load_golden("ops.npz")
+    for k, d in ((3, 1), (7, 3), (11, 5)):
+        y = _run(g[f"conv_k{k}d{d}_w"], g[f"conv_k{k}d{d}_b"], g[f"conv_k{k}d{d}_x"], dilation=d, padding=(k * d - d) // 2)
+        _check(y, g[f"conv_k{k}d{d}_y"])
+    for k, u in ((16, 8), (8, 2), (2, 2), (4, 4), (4, 2)):
+        y = _run(g[f"convT_k{k}u{u}_w"], g[f"convT_k{k}u{u}_b"], g[f"convT_k{k}u{u}_x"], transposed=True, stride=u,
+                 padding=(k - u) // 2)
+        _check(y, g[f"convT_k{k}u{u}_y"])
+
+
+def test_linearity_at_full_size():
+    """Size-independent property at the BASELINE stage-1 shape (C=128, T=5504, B=4): conv(a*x1 + x2) - conv(x2)
+    == a * (conv(x1) - bias-free) to fp32 round-off; checks the large-grid tiling paths the oracle is too slow for."""
+    rng = np.random.default_rng(0)
+    C, T, B, k, d = 128, 5504, 4, 7, 3
+    w = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    x1 = rng.normal(size=(B, C, T)).astype(np.float32)
+    x2 = rng.normal(size=(B, C, T)).astype(np.float32)
+    pad = (k * d - d) // 2
+    y1 = _run(w, None, x1, dilation=d, padding=pad)
+    y2 = _run(w, None, x2, dilation=d, padding=pad)
+    y12 = _run(w, None, (0.5 * x1 + x2).astype(np.float32), dilation=d, padding=pad)
+    assert np.abs(y12 - (0.5 * y1 + y2)).max() < 2e-5
+    # spot-check a slab against the oracle
+    ref = orc.conv1d(x1[:1, :, :700], w, None, dilation=d, padding=pad)
+    assert np.abs(y1[:1, :, :600] - ref[:, :, :600]).max() < 1e-5
+
+
+def test_errors_are_reported():
+    from vocoder_amd.engine import FusedConv, FishVocError
+    w = np.zeros((4, 4, 3), np.float32)
+    conv = FusedConv(w, None, padding=1)
+    with pytest.raises(RuntimeError):
+        conv(torch.zeros(1, 4, 8))            # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        conv(torch.zeros(1, 5, 8, device=_dev()))
+    with pytest.raises(FishVocError):
+        FusedConv(np.zeros((4, 4, 3), np.float32), None, padding=-1)

@@ -1,0 +1,151 @@
+"""GPU: whole-generator parity through fv_forward against (a) the golden fixtures captured from the reference and
+(b) the CPU oracle on seeded inputs.  Bar: |d| <= 1e-4 on the waveform (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle as orc
+from vocoder_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _hifigan_engine(cfg, sd, kind=None):
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, upsampler_config
+    return Engine(kind or _lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**cfg), state_dict=sd)
+
+
+def _fwd(eng, x):
+    y = eng(torch.from_numpy(x).to(_dev()))
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["hifigan_tiny.npz", "hifigan_narrow.npz", "hifigan_tiny_t1.npz", "hifigan_v1_t12.npz"])
+def test_hifigan_golden(name):
+    g = load_golden(name)
+    sd = syn.hifigan_state_dict(g["cfg"], g["seed"])
+    y = _fwd(_hifigan_engine(g["cfg"], sd), g["mel"])
+    assert y.shape == g["out"].shape
+    err = np.abs(y - g["out"]).max()
+    assert err <= TOL, f"waveform max|d| = {err:.3e} vs reference golden"
+
+
+def test_hifigan_v1_vs_oracle_seeded_batch():
+    cfg = dict(syn.HIFIGAN_V1_44K)
+    sd = syn.hifigan_state_dict(cfg, seed=11)
+    mel = syn.synthetic_mel(2, 80, 9, seed=77)     # ragged-ish small T, B=2
+    ref = orc.hifigan_forward(sd, cfg, mel)
+    y = _fwd(_hifigan_engine(cfg, sd), mel)
+    err = np.abs(y - ref).max()
+    assert err <= TOL, f"max|d| = {err:.3e}"
+
+
+def test_hifigan_full_size_properties():
+    """BASELINE config[1] size (B=32, T_mel=86): checks that need no oracle at that size —
+    batch independence (item i of the batch == the same clip run alone), determinism, range of tanh."""
+    cfg = dict(syn.HIFIGAN_V1_44K)
+    sd = syn.hifigan_state_dict(cfg, seed=0)
+    eng = _hifigan_engine(cfg, sd)
+    mel = syn.synthetic_mel(32, 80, 86, seed=1234)
+    y = _fwd(eng, mel)
+    assert y.shape == (32, 1, 86 * 512)
+    assert np.isfinite(y).all() and np.abs(y).max() <= 1.0
+    y_again = _fwd(eng, mel)
+    assert np.array_equal(y, y_again)
+    for i in (0, 17, 31):
+        yi = _fwd(eng, mel[i:i + 1])
+        assert np.abs(yi[0] - y[i]).max() <= 1e-6
+    # first clip against the oracle on a prefix: the receptive field is finite (one-sided reach of the whole stack is
+    # ~9 mel frames, dominated by the k=11, d=5 ResBlocks of stage 0), so a T=28 prefix run agrees with the full run
+    # on the first 8 frames.
+    ref = orc.hifigan_forward(sd, cfg, mel[:1, :, :28])
+    assert np.abs(ref[0, 0, :8 * 512] - y[0, 0, :8 * 512]).max() <= TOL
+
+
+def test_strict_loading_errors():
+    from vocoder_amd.engine import FishVocError
+    g = load_golden("hifigan_tiny.npz")
+    sd = syn.hifigan_state_dict(g["cfg"], g["seed"])
+    bad = dict(sd)
+    bad.pop("ups.0.bias")
+    with pytest.raises(FishVocError, match="missing weight 'ups.0.bias'"):
+        _hifigan_engine(g["cfg"], bad)
+    extra = dict(sd)
+    extra["bogus.weight"] = np.zeros(3, np.float32)
+    with pytest.raises(FishVocError, match="unexpected key"):
+        _hifigan_engine(g["cfg"], extra)
+    wrong = dict(sd)
+    wrong["conv_pre.bias"] = np.zeros(5, np.float32)
+    with pytest.raises(FishVocError, match="shape"):
+        _hifigan_engine(g["cfg"], wrong)
+    with pytest.raises(FishVocError, match="hop_length must be"):
+        _hifigan_engine(dict(g["cfg"], hop_length=17), sd)
+    with pytest.raises(FishVocError, match="use_template"):
+        _hifigan_engine(dict(g["cfg"], use_template=True), sd)
+
+
+def test_bigvgan_golden_and_oracle():
+    from vocoder_amd import _lib
+    g = load_golden("bigvgan_tiny.npz")
+    sd = syn.bigvgan_state_dict(g["cfg"], g["seed"])
+    y = _fwd(_hifigan_engine(g["cfg"], sd, _lib.FV_MODEL_BIGVGAN), g["mel"])
+    err = np.abs(y - g["out"]).max()
+    assert err <= TOL, f"max|d| = {err:.3e} vs (stand-in backed) golden"
+    cfg = dict(syn.BIGVGAN_24K)
+    sd = syn.bigvgan_state_dict(cfg, seed=2)
+    mel = syn.synthetic_mel(1, 80, 7, seed=5)
+    ref = orc.bigvgan_forward(sd, cfg, mel)
+    y = _fwd(_hifigan_engine(cfg, sd, _lib.FV_MODEL_BIGVGAN), mel)
+    err = np.abs(y - ref).max()
+    assert err <= TOL, f"max|d| = {err:.3e} vs oracle"
+
+
+def test_convnext_and_vocos():
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config
+    g = load_golden("convnext_small.npz")
+    sd = syn.convnext_state_dict(g["cfg"], g["seed"])
+    eng = Engine(_lib.FV_MODEL_CONVNEXT, backbone=convnext_config(**g["cfg"]), state_dict=sd)
+    y = _fwd(eng, g["mel"])
+    err = np.abs(y - g["out"]).max()
+    assert err <= TOL, f"convnext max|d| = {err:.3e}"
+
+    g = load_golden("istft_head.npz")
+    sd = syn.istft_head_state_dict(g["cfg"], g["seed"])
+    eng = Engine(_lib.FV_MODEL_ISTFT_HEAD, head=istft_head_config(**g["cfg"]), state_dict=sd)
+    y = _fwd(eng, g["x"])
+    err = np.abs(y[:, 0] - g["wave"]).max()
+    assert err <= TOL, f"istft head max|d| = {err:.3e}"
+
+    g = load_golden("vocos_tiny.npz")
+    sd = syn.vocos_state_dict(g["cfg"], g["seed"])
+    eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**g["cfg"]["backbone"]),
+                 head=istft_head_config(**g["cfg"]["head"]), state_dict=sd)
+    y = _fwd(eng, g["mel"])
+    err = np.abs(y - g["out"]).max()
+    assert err <= TOL, f"vocos max|d| = {err:.3e}"
+
+
+def test_vocos_24k_vs_oracle():
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config
+    cfg = dict(backbone=dict(input_channels=80, depths=[1, 1, 2, 1], dims=[128, 256, 512, 1024], kernel_size=7),
+               head=dict(dim=1024, n_fft=1024, hop_length=256, win_length=1024, padding="same"))
+    sd = syn.vocos_state_dict(cfg, seed=3)
+    mel = syn.synthetic_mel(2, 80, 10, seed=9)
+    ref = orc.vocos_forward(sd, cfg, mel)
+    eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), head=istft_head_config(**cfg["head"]),
+                 state_dict=sd)
+    y = _fwd(eng, mel)
+    err = np.abs(y - ref).max()
+    assert err <= TOL, f"vocos-24k max|d| = {err:.3e}"

@@ -1,0 +1,12 @@
+// Specialisations of the fused conv kernel for kernel size 3 (one translation unit per size: parallel builds).
+#include "conv_mfma_impl.h"
+namespace fv {
+bool launch_conv_k3(const ConvParams& p, int cfg, int batch, hipStream_t s) {
+    switch (p.dil) {
+        case 1: return launch_cfg<3, 1>(p, cfg, batch, s);
+        case 3: return launch_cfg<3, 3>(p, cfg, batch, s);
+        case 5: return launch_cfg<3, 5>(p, cfg, batch, s);
+        default: return false;
+    }
+}
+}  // namespace fv

@@ -1,0 +1,209 @@
+// Host side of the fused conv layer: weight re-layout into MFMA fragment order, tile selection, dispatch.
+#include <algorithm>
+#include <cstring>
+
+#include "fv_internal.h"
+
+namespace fv {
+
+void tile_dims(int cfg, int* m_blk, int* n_blk) {
+    static const int dims[TILE_COUNT][2] = {{128, 128}, {64, 256}, {32, 512}, {128, 64}, {32, 128}, {64, 128}};
+    *m_blk = dims[cfg][0];
+    *n_blk = dims[cfg][1];
+}
+
+// Packed layout (float4 units):  [(m_tile * nchunk + chunk) * ks + tap] * 64 + lane
+//   .{x,y,z,w}[pp] = Wc[m_tile*32 + (lane & 31)][chunk*8 + 2*pp + (lane >> 5)][tap]     (0 outside M x Cin)
+// i.e. exactly the A fragment of v_mfma_f32_32x32x2_f32 for k-step (tap, channel pair pp): lane l supplies
+// row l&31, k-half l>>5 — one coalesced 1 KiB global_load_dwordx4 per wave per tap.
+static void pack_conv_weights(const std::vector<float>& wc, int M, int Cin, int ks, int m_pad, int nchunk,
+                              std::vector<float>& out) {
+    const int mtiles = m_pad / 32;
+    out.assign((size_t)mtiles * nchunk * ks * 64 * 4, 0.f);
+    for (int mt = 0; mt < mtiles; ++mt)
+        for (int c = 0; c < nchunk; ++c)
+            for (int j = 0; j < ks; ++j)
+                for (int l = 0; l < 64; ++l) {
+                    const int m = mt * 32 + (l & 31);
+                    if (m >= M) continue;
+                    float* dst = &out[((((size_t)mt * nchunk + c) * ks + j) * 64 + l) * 4];
+                    for (int pp = 0; pp < 4; ++pp) {
+                        const int ci = c * kChunk + 2 * pp + (l >> 5);
+                        if (ci < Cin) dst[pp] = wc[((size_t)m * Cin + ci) * ks + j];
+                    }
+                }
+}
+
+fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, int k, int dil, int padding,
+                            int stride, const float* host_w, const float* host_bias) {
+    if (c_in <= 0 || c_out <= 0 || k <= 0 || dil <= 0 || stride <= 0 || padding < 0) {
+        set_error("conv_layer_create: invalid geometry (c_in=%d c_out=%d k=%d dil=%d pad=%d stride=%d)", c_in, c_out,
+                  k, dil, padding, stride);
+        return FV_ERR_INVALID;
+    }
+    L.transposed = transposed;
+    L.c_in = c_in;
+    L.c_out = c_out;
+    L.k = k;
+    L.dil = transposed ? 1 : dil;
+    L.padding = padding;
+    L.stride = transposed ? stride : 1;
+
+    std::vector<float> wc, bias;
+    if (!transposed) {
+        L.M = c_out;
+        L.ks = k;
+        L.pad_l = padding;
+        wc.assign(host_w, host_w + (size_t)c_out * c_in * k);
+        bias.assign(c_out, 0.f);
+        if (host_bias) std::copy(host_bias, host_bias + c_out, bias.begin());
+    } else {
+        // polyphase: row (co, r), taps j' = 0..ks'-1 reading x[q + j' - (ks'-1)]; torch weight is (C_in, C_out, k)
+        const int u = stride;
+        const int ksp = (k + u - 1) / u;
+        L.M = c_out * u;
+        L.ks = ksp;
+        L.pad_l = ksp - 1;
+        wc.assign((size_t)L.M * c_in * ksp, 0.f);
+        bias.assign(L.M, 0.f);
+        for (int co = 0; co < c_out; ++co)
+            for (int r = 0; r < u; ++r) {
+                const int m = co * u + r;
+                if (host_bias) bias[m] = host_bias[co];
+                for (int ci = 0; ci < c_in; ++ci)
+                    for (int jp = 0; jp < ksp; ++jp) {
+                        const int tap = r + (ksp - 1 - jp) * u;
+                        if (tap < k) wc[((size_t)m * c_in + ci) * ksp + jp] = host_w[((size_t)ci * c_out + co) * k + tap];
+                    }
+            }
+    }
+    L.nchunk = (c_in + kChunk - 1) / kChunk;
+    L.m_pad = (L.M + 127) / 128 * 128;
+    std::vector<float> packed;
+    pack_conv_weights(wc, L.M, c_in, L.ks, L.m_pad, L.nchunk, packed);
+    bias.resize(L.m_pad, 0.f);
+    L.wp_bytes = packed.size() * sizeof(float);
+    FV_HIP_CHECK(hipMalloc((void**)&L.d_wp, L.wp_bytes));
+    FV_HIP_CHECK(hipMalloc((void**)&L.d_bias, bias.size() * sizeof(float)));
+    FV_HIP_CHECK(hipMemcpy(L.d_wp, packed.data(), L.wp_bytes, hipMemcpyHostToDevice));
+    FV_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    return FV_OK;
+}
+
+void conv_layer_destroy(ConvLayer& L) {
+    if (L.d_wp) (void)hipFree(L.d_wp);
+    if (L.d_bias) (void)hipFree(L.d_bias);
+    L.d_wp = nullptr;
+    L.d_bias = nullptr;
+}
+
+static int choose_tile(int M, long long N, int batch) {
+    int big, small;
+    if (M <= 32) {
+        big = TILE_32x512;
+        small = TILE_32x128;
+    } else if (M <= 64) {
+        big = TILE_64x256;
+        small = TILE_64x128;
+    } else {
+        big = TILE_128x128;
+        small = TILE_128x64;
+    }
+    int mb, nb_big, nb_small;
+    tile_dims(big, &mb, &nb_big);
+    tile_dims(small, &mb, &nb_small);
+    const long long m_blks = (M + mb - 1) / mb;
+    const long long tiles_big = (N + nb_big - 1) / nb_big, tiles_small = (N + nb_small - 1) / nb_small;
+    const double cols_big = (double)tiles_big * nb_big, cols_small = (double)tiles_small * nb_small * 1.04;
+    const long long blocks_big = tiles_big * m_blks * batch;
+    // not enough workgroups to fill 256 CUs twice over, or a lot of padded columns -> smaller tile
+    if (blocks_big < 512 || cols_small < cols_big) return small;
+    return big;
+}
+
+static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128"};
+
+fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t stream) {
+    if (!L.d_wp) {
+        set_error("conv_layer_run: layer not initialised");
+        return FV_ERR_STATE;
+    }
+    if (r.batch <= 0 || r.t_in <= 0) {
+        set_error("conv_layer_run: empty input (batch=%d, t_in=%d)", r.batch, r.t_in);
+        return FV_ERR_INVALID;
+    }
+    const long long tout = L.out_len(r.t_in);
+    if (tout <= 0) {
+        set_error("conv_layer_run: non-positive output length %lld", tout);
+        return FV_ERR_INVALID;
+    }
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = r.x;
+    p.wp = L.d_wp;
+    p.bias = L.d_bias;
+    p.y = r.y;
+    p.res = r.res;
+    p.gamma = r.gamma;
+    p.Cin = L.c_in;
+    p.Tin = r.t_in;
+    p.M = L.M;
+    p.N = (int)L.gemm_cols(r.t_in);
+    p.nchunk = L.nchunk;
+    p.pad_l = L.pad_l;
+    p.ks = L.ks;
+    p.dil = L.dil;
+    p.pre_act = r.pre_act;
+    p.post_act = r.post_act;
+    p.slope = r.slope;
+    p.out_mode = r.out_mode;
+    p.out_scale = r.out_scale;
+    p.convt = L.transposed ? 1 : 0;
+    p.u = L.stride;
+    p.pad_t = L.padding;
+    p.Tout = (int)tout;
+    p.Cout = L.c_out;
+    p.x_bstride = (long long)L.c_in * r.t_in;
+    p.y_bstride = (long long)L.c_out * tout;
+
+    int cfg = choose_tile(L.M, p.N, r.batch);
+    bool ok = false;
+    bool specialised = true;
+    auto try_launch = [&](int c) {
+        int mb, nb;
+        tile_dims(c, &mb, &nb);
+        p.m_blks = (L.M + mb - 1) / mb;
+        p.n_tiles = (p.N + nb - 1) / nb;
+        switch (L.ks) {
+            case 1: return launch_conv_k1(p, c, r.batch, stream);
+            case 3: return launch_conv_k3(p, c, r.batch, stream);
+            case 7: return launch_conv_k7(p, c, r.batch, stream);
+            case 11: return launch_conv_k11(p, c, r.batch, stream);
+            default: return launch_conv_misc(p, c, r.batch, stream);
+        }
+    };
+    ok = try_launch(cfg);
+    if (!ok) {
+        specialised = false;
+        cfg = TILE_64x128;
+        int mb, nb;
+        tile_dims(cfg, &mb, &nb);
+        p.m_blks = (L.M + mb - 1) / mb;
+        p.n_tiles = (p.N + nb - 1) / nb;
+        size_t lds = 0;
+        ok = launch_conv_generic(p, cfg, r.batch, stream, &lds);
+        if (!ok) {
+            set_error("conv_layer_run: (k=%d, dilation=%d) needs %zu B of LDS staging, above the 64 KiB generic limit",
+                      L.ks, L.dil, lds);
+            return FV_ERR_UNSUPPORTED;
+        }
+    }
+    static thread_local char name[96];
+    std::snprintf(name, sizeof(name), "conv_mfma<%s k=%d d=%d tile=%s>", specialised ? "spec" : "generic", L.ks, L.dil,
+                  kTileNames[cfg]);
+    set_last_kernel(name);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
+}  // namespace fv

@@ -1,0 +1,1000 @@
+// libfishvoc_hip.so — C ABI (include/fishvoc.h) and the model-level forward orchestration.
+//
+// The engine owns: folded + MFMA-packed weights in HBM, and the static launch plan of a generator forward.
+// Per forward it only enqueues kernels on the caller's stream into the caller's workspace (no allocation, no sync).
+//
+// Reference call stack replaced (paths under /root/reference/fish_vocoder):
+//   test.py:89 -> models/gan.py:286 -> modules/generators/hifigan.py:226-249 (HiFiGAN)
+//                                       modules/generators/bigvgan.py:352-371 (BigVGAN)
+//                                       modules/generators/unify.py:18-33 + encoders/convnext.py:206-214
+//                                       + generators/vocos.py:43-69 (Vocos)
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+
+#include "fv_internal.h"
+
+namespace fv {
+
+static thread_local std::string g_err;
+static thread_local std::string g_kernel;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+void set_last_kernel(const char* name) { g_kernel = name; }
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+// alias_free_torch.kaiser_sinc_filter1d (third-party 0.0.6; restated from the published algorithm)
+static double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    const double q = x * x / 4.0;
+    for (int k = 1; k < 200; ++k) {
+        term *= q / ((double)k * k);
+        sum += term;
+        if (term < 1e-20 * sum) break;
+    }
+    return sum;
+}
+static std::vector<float> kaiser_sinc_filter(double cutoff, double half_width, int ks) {
+    const bool even = ks % 2 == 0;
+    const int half = ks / 2;
+    const double delta_f = 4.0 * half_width;
+    const double A = 2.285 * (half - 1) * M_PI * delta_f + 7.95;
+    const double beta = A > 50.0 ? 0.1102 * (A - 8.7) : (A >= 21.0 ? 0.5842 * std::pow(A - 21.0, 0.4) + 0.07886 * (A - 21.0) : 0.0);
+    std::vector<double> f(ks);
+    double sum = 0.0;
+    for (int n = 0; n < ks; ++n) {
+        const double r = ks > 1 ? 2.0 * n / (ks - 1.0) - 1.0 : 0.0;
+        const double win = bessel_i0(beta * std::sqrt(std::max(0.0, 1.0 - r * r))) / bessel_i0(beta);
+        const double tm = even ? (n - half) + 0.5 : (double)(n - half);
+        const double xs = 2.0 * cutoff * tm;
+        const double sinc = xs == 0.0 ? 1.0 : std::sin(M_PI * xs) / (M_PI * xs);
+        f[n] = 2.0 * cutoff * win * sinc;
+        sum += f[n];
+    }
+    std::vector<float> out(ks);
+    for (int n = 0; n < ks; ++n) out[n] = (float)(f[n] / sum);
+    return out;
+}
+
+template <typename T>
+static fv_status upload(const std::vector<T>& h, T** d) {
+    FV_HIP_CHECK(hipMalloc((void**)d, std::max<size_t>(h.size(), 1) * sizeof(T)));
+    if (!h.empty()) FV_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct AASnake {  // Activation1d(SnakeBeta(C, alpha_logscale=True))
+    float* d_alpha = nullptr;    // exp(alpha)
+    float* d_inv_beta = nullptr; // 1 / (exp(beta) + 1e-9)
+    float* d_up = nullptr;
+    float* d_down = nullptr;
+    int C = 0;
+    void destroy() {
+        for (float* p : {d_alpha, d_inv_beta, d_up, d_down})
+            if (p) (void)hipFree(p);
+        d_alpha = d_inv_beta = d_up = d_down = nullptr;
+    }
+};
+
+struct ResBranch {
+    int k = 0;
+    int dil[FV_MAX_DILATIONS] = {1, 1, 1};
+    ConvLayer c1[FV_MAX_DILATIONS], c2[FV_MAX_DILATIONS];
+    AASnake act[2 * FV_MAX_DILATIONS];  // BigVGAN only
+};
+
+struct UpStage {
+    ConvLayer up;
+    int ch = 0;
+    std::vector<std::unique_ptr<ResBranch>> branches;
+};
+
+struct UpsamplerModel {
+    bool bigvgan = false;
+    fv_upsampler_config cfg{};
+    ConvLayer conv_pre;
+    std::vector<std::unique_ptr<UpStage>> stages;
+    AASnake act_post;  // BigVGAN only
+    float* d_wpost = nullptr;
+    float* d_bpost = nullptr;
+    int post_cin = 0;
+
+    int64_t out_len(int t_in) const {
+        int64_t t = conv_pre.out_len(t_in);
+        for (auto& st : stages) t = st->up.out_len((int)t);
+        return t;
+    }
+    // largest (C * T) of any intermediate activation, per batch item
+    int64_t max_elems(int t_in) const {
+        int64_t t = conv_pre.out_len(t_in);
+        int64_t m = (int64_t)conv_pre.c_out * t;
+        for (auto& st : stages) {
+            t = st->up.out_len((int)t);
+            m = std::max<int64_t>(m, (int64_t)st->ch * t);
+        }
+        return m;
+    }
+    void destroy() {
+        conv_layer_destroy(conv_pre);
+        for (auto& st : stages) {
+            conv_layer_destroy(st->up);
+            for (auto& br : st->branches) {
+                for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
+                    conv_layer_destroy(br->c1[n]);
+                    conv_layer_destroy(br->c2[n]);
+                }
+                for (auto& a : br->act) a.destroy();
+            }
+        }
+        act_post.destroy();
+        if (d_wpost) (void)hipFree(d_wpost);
+        if (d_bpost) (void)hipFree(d_bpost);
+        d_wpost = d_bpost = nullptr;
+    }
+};
+
+struct CnxBlock {
+    float *d_dw_w = nullptr, *d_dw_b = nullptr, *d_ln_w = nullptr, *d_ln_b = nullptr, *d_gamma = nullptr;
+    ConvLayer pw1, pw2;
+    int dim = 0;
+};
+struct CnxStage {
+    // transition: i == 0: stem conv(k) then LN ; i > 0: LN then 1x1 conv
+    ConvLayer conv;
+    float *d_ln_w = nullptr, *d_ln_b = nullptr;
+    int ln_dim = 0;
+    std::vector<std::unique_ptr<CnxBlock>> blocks;
+};
+struct ConvNeXtModel {
+    fv_convnext_config cfg{};
+    std::vector<std::unique_ptr<CnxStage>> stages;
+    float *d_norm_w = nullptr, *d_norm_b = nullptr;
+    int out_dim() const { return cfg.dims[cfg.num_stages - 1]; }
+    int max_dim() const {
+        int m = cfg.input_channels;
+        for (int i = 0; i < cfg.num_stages; ++i) m = std::max(m, cfg.dims[i]);
+        return m;
+    }
+    void destroy() {
+        for (auto& st : stages) {
+            conv_layer_destroy(st->conv);
+            for (float* p : {st->d_ln_w, st->d_ln_b})
+                if (p) (void)hipFree(p);
+            for (auto& b : st->blocks) {
+                conv_layer_destroy(b->pw1);
+                conv_layer_destroy(b->pw2);
+                for (float* p : {b->d_dw_w, b->d_dw_b, b->d_ln_w, b->d_ln_b, b->d_gamma})
+                    if (p) (void)hipFree(p);
+            }
+        }
+        for (float* p : {d_norm_w, d_norm_b})
+            if (p) (void)hipFree(p);
+        stages.clear();
+        d_norm_w = d_norm_b = nullptr;
+    }
+};
+
+struct IstftHeadModel {
+    fv_istft_head_config cfg{};
+    ConvLayer out;    // 1x1 conv dim -> rows: only the 2*nb live rows are packed
+    ConvLayer idft;   // (n_fft) x (2*nb) windowed inverse real-DFT basis as a 1x1 conv
+    float* d_win2 = nullptr;
+    int nb = 0;
+    void destroy() {
+        conv_layer_destroy(out);
+        conv_layer_destroy(idft);
+        if (d_win2) (void)hipFree(d_win2);
+        d_win2 = nullptr;
+    }
+};
+
+}  // namespace fv
+
+using namespace fv;
+
+struct fv_engine {
+    fv_config cfg{};
+    std::map<std::string, HostTensor> raw;
+    std::set<std::string> used;
+    bool finalized = false;
+    UpsamplerModel ups;
+    ConvNeXtModel cnx;
+    IstftHeadModel head;
+    bool has_ups = false, has_cnx = false, has_head = false;
+
+    // ---- weight lookup helpers (reference state-dict names) ----
+    const HostTensor* find(const std::string& name) {
+        auto it = raw.find(name);
+        if (it == raw.end()) return nullptr;
+        used.insert(name);
+        return &it->second;
+    }
+    fv_status need(const std::string& name, const std::vector<int64_t>& shape, const HostTensor** out,
+                   bool allow_flat = false) {
+        const HostTensor* t = find(name);
+        if (!t) {
+            set_error("missing weight '%s'", name.c_str());
+            return FV_ERR_MISSING_WEIGHT;
+        }
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        const bool same = t->shape == shape || (allow_flat && t->numel() == n);
+        if (!same) {
+            std::string got, want;
+            for (auto s : t->shape) got += std::to_string(s) + ",";
+            for (auto s : shape) want += std::to_string(s) + ",";
+            set_error("weight '%s' has shape (%s), expected (%s)", name.c_str(), got.c_str(), want.c_str());
+            return FV_ERR_SHAPE;
+        }
+        *out = t;
+        return FV_OK;
+    }
+    // Folded conv weight: weight-norm g * v / ||v|| over all dims but 0 (torch._weight_norm(v, g, 0); for
+    // ConvTranspose1d dim 0 is C_in — SURVEY §0.4), or a plain ".weight".
+    fv_status conv_weight(const std::string& prefix, const std::vector<int64_t>& shape, std::vector<float>& w) {
+        const int64_t n0 = shape[0];
+        int64_t inner = 1;
+        for (size_t i = 1; i < shape.size(); ++i) inner *= shape[i];
+        std::string gk = prefix + ".parametrizations.weight.original0", vk = prefix + ".parametrizations.weight.original1";
+        if (!raw.count(gk) && raw.count(prefix + ".weight_g")) {
+            gk = prefix + ".weight_g";
+            vk = prefix + ".weight_v";
+        }
+        if (raw.count(gk)) {
+            const HostTensor *g, *v;
+            fv_status st = need(gk, {n0}, &g, true);
+            if (st) return st;
+            st = need(vk, shape, &v);
+            if (st) return st;
+            w.resize((size_t)n0 * inner);
+            for (int64_t i = 0; i < n0; ++i) {
+                const float* vi = v->data.data() + i * inner;
+                double s = 0.0;
+                for (int64_t j = 0; j < inner; ++j) s += (double)vi[j] * vi[j];
+                const float scale = g->data[i] / (float)std::sqrt(s);
+                for (int64_t j = 0; j < inner; ++j) w[i * inner + j] = vi[j] * scale;
+            }
+            return FV_OK;
+        }
+        const HostTensor* t;
+        fv_status st = need(prefix + ".weight", shape, &t, true);
+        if (st) return st;
+        w = t->data;
+        return FV_OK;
+    }
+    fv_status vec(const std::string& name, int64_t n, std::vector<float>& out) {
+        const HostTensor* t;
+        fv_status st = need(name, {n}, &t, true);
+        if (st) return st;
+        out = t->data;
+        return FV_OK;
+    }
+    fv_status make_conv(ConvLayer& L, const std::string& prefix, bool transposed, int c_in, int c_out, int k, int dil,
+                        int padding, int stride) {
+        std::vector<float> w, b;
+        const std::vector<int64_t> shape = transposed ? std::vector<int64_t>{c_in, c_out, k} : std::vector<int64_t>{c_out, c_in, k};
+        fv_status st = conv_weight(prefix, shape, w);
+        if (st) return st;
+        st = vec(prefix + ".bias", c_out, b);
+        if (st) return st;
+        return conv_layer_create(L, transposed, c_in, c_out, k, dil, padding, stride, w.data(), b.data());
+    }
+    fv_status make_dev_vec(const std::string& name, int64_t n, float** d) {
+        std::vector<float> v;
+        fv_status st = vec(name, n, v);
+        if (st) return st;
+        return upload(v, d);
+    }
+    fv_status make_aasnake(AASnake& a, const std::string& prefix, int C) {
+        std::vector<float> al, be;
+        fv_status st = vec(prefix + ".act.alpha", C, al);
+        if (st) return st;
+        st = vec(prefix + ".act.beta", C, be);
+        if (st) return st;
+        for (int c = 0; c < C; ++c) {  // alpha_logscale=True (bigvgan.py:128-133,229,336)
+            al[c] = std::exp(al[c]);
+            be[c] = 1.0f / (std::exp(be[c]) + 0.000000001f);
+        }
+        std::vector<float> up = kaiser_sinc_filter(0.25, 0.3, 12), down = up;
+        if (const HostTensor* t = find(prefix + ".upsample.filter")) {
+            if (t->numel() != 12) {
+                set_error("'%s.upsample.filter' must have 12 taps", prefix.c_str());
+                return FV_ERR_SHAPE;
+            }
+            up = t->data;
+        }
+        if (const HostTensor* t = find(prefix + ".downsample.lowpass.filter")) {
+            if (t->numel() != 12) {
+                set_error("'%s.downsample.lowpass.filter' must have 12 taps", prefix.c_str());
+                return FV_ERR_SHAPE;
+            }
+            down = t->data;
+        }
+        a.C = C;
+        if ((st = upload(al, &a.d_alpha))) return st;
+        if ((st = upload(be, &a.d_inv_beta))) return st;
+        if ((st = upload(up, &a.d_up))) return st;
+        return upload(down, &a.d_down);
+    }
+
+    fv_status build_upsampler(const std::string& pfx, bool bigvgan);
+    fv_status build_convnext(const std::string& pfx);
+    fv_status build_head(const std::string& pfx);
+
+    fv_status run_upsampler(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
+    fv_status run_convnext(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
+    fv_status run_head(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
+
+    ~fv_engine() {
+        ups.destroy();
+        cnx.destroy();
+        head.destroy();
+    }
+};
+
+static int get_padding(int k, int d = 1) { return (k * d - d) / 2; }  // hifigan.py:21-22
+
+fv_status fv_engine::build_upsampler(const std::string& pfx, bool bigvgan) {
+    const fv_upsampler_config& c = cfg.ups;
+    ups.cfg = c;
+    ups.bigvgan = bigvgan;
+    fv_status st;
+    const int c0 = c.upsample_initial_channel;
+    if ((st = make_conv(ups.conv_pre, pfx + "conv_pre", false, c.num_mels, c0, c.pre_conv_kernel_size, 1,
+                        get_padding(c.pre_conv_kernel_size), 1)))
+        return st;
+    int ch = c0;
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+        const int cin = c0 >> i;
+        ch = c0 >> (i + 1);
+        if (ch < 1) {
+            set_error("upsample_initial_channel=%d too small for %d upsampling stages", c0, c.num_upsamples);
+            return FV_ERR_INVALID;
+        }
+        auto stg = std::make_unique<UpStage>();
+        stg->ch = ch;
+        if ((st = make_conv(stg->up, pfx + "ups." + std::to_string(i), true, cin, ch, k, 1, (k - u) / 2, u))) return st;
+        for (int j = 0; j < c.num_kernels; ++j) {
+            auto br = std::make_unique<ResBranch>();
+            br->k = c.resblock_kernel_sizes[j];
+            // HiFiGAN: resblocks.{i}.blocks.{j}  (hifigan.py:206-211);  BigVGAN: flat resblocks.{i*nk+j} (bigvgan.py:327-332)
+            const std::string bp = bigvgan ? pfx + "resblocks." + std::to_string(i * c.num_kernels + j)
+                                           : pfx + "resblocks." + std::to_string(i) + ".blocks." + std::to_string(j);
+            for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
+                const int d = c.resblock_dilation_sizes[j][n];
+                br->dil[n] = d;
+                if ((st = make_conv(br->c1[n], bp + ".convs1." + std::to_string(n), false, ch, ch, br->k, d,
+                                    get_padding(br->k, d), 1)))
+                    return st;
+                if ((st = make_conv(br->c2[n], bp + ".convs2." + std::to_string(n), false, ch, ch, br->k, 1,
+                                    get_padding(br->k, 1), 1)))
+                    return st;
+            }
+            if (bigvgan)
+                for (int m = 0; m < 2 * FV_MAX_DILATIONS; ++m)
+                    if ((st = make_aasnake(br->act[m], bp + ".activations." + std::to_string(m), ch))) return st;
+            stg->branches.push_back(std::move(br));
+        }
+        ups.stages.push_back(std::move(stg));
+    }
+    if (bigvgan && (st = make_aasnake(ups.act_post, pfx + "activation_post", ch))) return st;
+    // conv_post: (1, ch, k) -> narrow VALU kernel, plain layout
+    std::vector<float> w, b;
+    if ((st = conv_weight(pfx + "conv_post", {1, ch, c.post_conv_kernel_size}, w))) return st;
+    if ((st = vec(pfx + "conv_post.bias", 1, b))) return st;
+    ups.post_cin = ch;
+    if ((st = upload(w, &ups.d_wpost))) return st;
+    if ((st = upload(b, &ups.d_bpost))) return st;
+    has_ups = true;
+    return FV_OK;
+}
+
+fv_status fv_engine::build_convnext(const std::string& pfx) {
+    const fv_convnext_config& c = cfg.backbone;
+    cnx.cfg = c;
+    fv_status st;
+    const int ks = c.kernel_size;
+    for (int i = 0; i < c.num_stages; ++i) {
+        auto stg = std::make_unique<CnxStage>();
+        const std::string dp = pfx + "downsample_layers." + std::to_string(i);
+        if (i == 0) {  // stem: Conv1d(k, pad k//2) + LN_cf (convnext.py:164-174)
+            if ((st = make_conv(stg->conv, dp + ".0", false, c.input_channels, c.dims[0], ks, 1, ks / 2, 1))) return st;
+            stg->ln_dim = c.dims[0];
+            if ((st = make_dev_vec(dp + ".1.weight", c.dims[0], &stg->d_ln_w))) return st;
+            if ((st = make_dev_vec(dp + ".1.bias", c.dims[0], &stg->d_ln_b))) return st;
+        } else {  // LN_cf + 1x1 conv (convnext.py:177-182)
+            stg->ln_dim = c.dims[i - 1];
+            if ((st = make_dev_vec(dp + ".0.weight", c.dims[i - 1], &stg->d_ln_w))) return st;
+            if ((st = make_dev_vec(dp + ".0.bias", c.dims[i - 1], &stg->d_ln_b))) return st;
+            if ((st = make_conv(stg->conv, dp + ".1", false, c.dims[i - 1], c.dims[i], 1, 1, 0, 1))) return st;
+        }
+        const int dim = c.dims[i];
+        for (int j = 0; j < c.depths[i]; ++j) {
+            auto blk = std::make_unique<CnxBlock>();
+            blk->dim = dim;
+            const std::string bp = pfx + "stages." + std::to_string(i) + "." + std::to_string(j);
+            std::vector<float> w;
+            const HostTensor* t;
+            if ((st = need(bp + ".dwconv.weight", {dim, 1, ks}, &t, true))) return st;
+            if ((st = upload(t->data, &blk->d_dw_w))) return st;
+            if ((st = make_dev_vec(bp + ".dwconv.bias", dim, &blk->d_dw_b))) return st;
+            if ((st = make_dev_vec(bp + ".norm.weight", dim, &blk->d_ln_w))) return st;
+            if ((st = make_dev_vec(bp + ".norm.bias", dim, &blk->d_ln_b))) return st;
+            // nn.Linear(dim, 4*dim) weight (4*dim, dim) == Conv1d weight (4*dim, dim, 1)  (convnext.py:111-115)
+            if ((st = make_conv(blk->pw1, bp + ".pwconv1", false, dim, 4 * dim, 1, 1, 0, 1))) return st;
+            if ((st = make_conv(blk->pw2, bp + ".pwconv2", false, 4 * dim, dim, 1, 1, 0, 1))) return st;
+            if (raw.count(bp + ".gamma"))
+                if ((st = make_dev_vec(bp + ".gamma", dim, &blk->d_gamma))) return st;
+            stg->blocks.push_back(std::move(blk));
+        }
+        cnx.stages.push_back(std::move(stg));
+    }
+    const int last = c.dims[c.num_stages - 1];
+    if ((st = make_dev_vec(pfx + "norm.weight", last, &cnx.d_norm_w))) return st;
+    if ((st = make_dev_vec(pfx + "norm.bias", last, &cnx.d_norm_b))) return st;
+    has_cnx = true;
+    return FV_OK;
+}
+
+fv_status fv_engine::build_head(const std::string& pfx) {
+    const fv_istft_head_config& c = cfg.head;
+    head.cfg = c;
+    const int N = c.n_fft, nb = N / 2 + 1;
+    head.nb = nb;
+    fv_status st;
+    // out: Conv1d(dim, 2*n_fft, 1); keep rows [0, nb) (log-magnitude) and [n_fft, n_fft + nb) (phase): the other
+    // bins are discarded by irfft (vocos.py:40-41,57).  Packed as a 2*nb-row layer.
+    const HostTensor *w, *b;
+    if ((st = need(pfx + "out.weight", {2 * N, c.dim, 1}, &w, true))) return st;
+    if ((st = need(pfx + "out.bias", {2 * N}, &b))) return st;
+    std::vector<float> wl((size_t)2 * nb * c.dim), bl(2 * nb);
+    for (int r = 0; r < nb; ++r) {
+        std::copy_n(w->data.data() + (size_t)r * c.dim, c.dim, wl.data() + (size_t)r * c.dim);
+        std::copy_n(w->data.data() + (size_t)(N + r) * c.dim, c.dim, wl.data() + (size_t)(nb + r) * c.dim);
+        bl[r] = b->data[r];
+        bl[nb + r] = b->data[N + r];
+    }
+    if ((st = conv_layer_create(head.out, false, c.dim, 2 * nb, 1, 1, 0, 1, wl.data(), bl.data()))) return st;
+    // window: checkpoint buffer "istft.window" if present, else torch.hann_window(win) (periodic)
+    std::vector<float> win(c.win_length);
+    if (const HostTensor* t = find(pfx + "istft.window")) {
+        if (t->numel() != c.win_length) {
+            set_error("'%sistft.window' has %lld taps, expected %d", pfx.c_str(), (long long)t->numel(), c.win_length);
+            return FV_ERR_SHAPE;
+        }
+        win = t->data;
+    } else {
+        for (int n = 0; n < c.win_length; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / c.win_length));
+    }
+    // windowed inverse real DFT as a (n_fft) x (2 nb) matrix: frame[n] = win[n]/N * sum_k c_k (Re_k cos - Im_k sin),
+    // c_0 = c_{N/2} = 1, else 2  == torch.fft.irfft(S, n_fft, norm="backward") * window  (vocos ISTFT, restated)
+    std::vector<float> basis((size_t)N * 2 * nb);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < nb; ++k) {
+            const double ck = (k == 0 || k == N / 2) ? 1.0 : 2.0;
+            const double ang = 2.0 * M_PI * (double)(((int64_t)k * n) % N) / N;
+            basis[(size_t)n * 2 * nb + k] = (float)(ck * std::cos(ang) / N * win[n]);
+            basis[(size_t)n * 2 * nb + nb + k] = (float)(-ck * std::sin(ang) / N * win[n]);
+        }
+    if ((st = conv_layer_create(head.idft, false, 2 * nb, N, 1, 1, 0, 1, basis.data(), nullptr))) return st;
+    std::vector<float> win2(N);
+    for (int n = 0; n < N; ++n) win2[n] = win[n] * win[n];
+    if ((st = upload(win2, &head.d_win2))) return st;
+    has_head = true;
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward passes
+// ------------------------------------------------------------------------------------------------
+fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s) {
+    const int64_t me = (ups.max_elems(T) * B + 63) / 64 * 64;
+    float* buf[6];
+    for (int i = 0; i < 6; ++i) buf[i] = ws + (size_t)i * me;
+    float *cur = buf[0], *S = buf[1], *XB = buf[2], *XT = buf[3], *XA = buf[4], *Y = buf[5];
+    fv_status st;
+    ConvRun r;
+    r.batch = B;
+    // conv_pre (hifigan.py:227)
+    r.x = d_in;
+    r.y = cur;
+    r.t_in = T;
+    if ((st = conv_layer_run(ups.conv_pre, r, s))) return st;
+    int t = (int)ups.conv_pre.out_len(T);
+    const int nk = ups.cfg.num_kernels;
+    for (auto& stg : ups.stages) {
+        // x = ups[i](silu(x))  — HiFiGAN (hifigan.py:230-231); BigVGAN has no pre-activation (bigvgan.py:355-356)
+        r = ConvRun();
+        r.batch = B;
+        r.x = cur;
+        r.y = S;
+        r.t_in = t;
+        r.pre_act = ups.bigvgan ? FV_ACT_NONE : FV_ACT_SILU;
+        if ((st = conv_layer_run(stg->up, r, s))) return st;
+        t = (int)stg->up.out_len(t);
+        const int ch = stg->ch;
+        // ParralelBlock / stack-mean of the three ResBlock1 / AMPBlock branches (hifigan.py:132-133, bigvgan.py:358-365)
+        for (int j = 0; j < nk; ++j) {
+            ResBranch& br = *stg->branches[j];
+            for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
+                const float* src = n == 0 ? S : XB;
+                const bool last = n == FV_MAX_DILATIONS - 1;
+                const float* c1_in = src;
+                if (ups.bigvgan) {
+                    if ((st = launch_aa_snake(src, XA, br.act[2 * n].d_alpha, br.act[2 * n].d_inv_beta, br.act[2 * n].d_up,
+                                              br.act[2 * n].d_down, B, ch, t, s)))
+                        return st;
+                    c1_in = XA;
+                }
+                // xt = c1(act(x)); the second activation is fused into c1's epilogue for SiLU
+                r = ConvRun();
+                r.batch = B;
+                r.t_in = t;
+                r.x = c1_in;
+                r.y = XT;
+                r.pre_act = ups.bigvgan ? FV_ACT_NONE : FV_ACT_SILU;
+                r.post_act = ups.bigvgan ? FV_ACT_NONE : FV_ACT_SILU;
+                if ((st = conv_layer_run(br.c1[n], r, s))) return st;
+                const float* c2_in = XT;
+                if (ups.bigvgan) {
+                    if ((st = launch_aa_snake(XT, XA, br.act[2 * n + 1].d_alpha, br.act[2 * n + 1].d_inv_beta,
+                                              br.act[2 * n + 1].d_up, br.act[2 * n + 1].d_down, B, ch, t, s)))
+                        return st;
+                    c2_in = XA;
+                }
+                // x = c2(act(xt)) + x ; the last pair of each branch accumulates the branch mean into Y
+                r = ConvRun();
+                r.batch = B;
+                r.t_in = t;
+                r.x = c2_in;
+                r.res = src;
+                if (!last) {
+                    r.y = XB;
+                } else {
+                    r.y = Y;
+                    r.out_mode = j == 0 ? OUT_SET : OUT_ACCUM;
+                    r.out_scale = (j == nk - 1) ? 1.0f / (float)nk : 1.0f;
+                    if (nk == 1) r.out_mode = OUT_SET;
+                }
+                if ((st = conv_layer_run(br.c2[n], r, s))) return st;
+            }
+        }
+        std::swap(cur, Y);
+    }
+    // activation_post -> conv_post -> tanh (hifigan.py:245-247 / bigvgan.py:367-369)
+    const float* post_in = cur;
+    int pre = FV_ACT_SILU;
+    if (ups.bigvgan) {
+        if ((st = launch_aa_snake(cur, XA, ups.act_post.d_alpha, ups.act_post.d_inv_beta, ups.act_post.d_up,
+                                  ups.act_post.d_down, B, ups.post_cin, t, s)))
+            return st;
+        post_in = XA;
+        pre = FV_ACT_NONE;
+    }
+    const int qk = ups.cfg.post_conv_kernel_size;
+    return launch_conv_narrow(post_in, ups.d_wpost, ups.d_bpost, d_out, B, ups.post_cin, t, 1, qk, get_padding(qk), pre,
+                              FV_ACT_TANH, 0.f, s);
+}
+
+fv_status fv_engine::run_convnext(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s) {
+    const int64_t me = ((int64_t)cnx.max_dim() * T * B + 63) / 64 * 64;
+    float* X = ws;               // running activation (dim, T)
+    float* H = ws + me;          // LN output (dim, T)
+    float* G = ws + 2 * me;      // hidden (4*dim, T)
+    fv_status st;
+    const int ks = cnx.cfg.kernel_size;
+    ConvRun r;
+    for (int i = 0; i < cnx.cfg.num_stages; ++i) {
+        CnxStage& stg = *cnx.stages[i];
+        const int dim = cnx.cfg.dims[i];
+        if (i == 0) {
+            r = ConvRun();
+            r.batch = B;
+            r.t_in = T;
+            r.x = d_in;
+            r.y = H;
+            if ((st = conv_layer_run(stg.conv, r, s))) return st;
+            if ((st = launch_dwconv_ln(H, nullptr, nullptr, stg.d_ln_w, stg.d_ln_b, X, B, dim, T, 1, 1e-6f, s))) return st;
+        } else {
+            if ((st = launch_dwconv_ln(X, nullptr, nullptr, stg.d_ln_w, stg.d_ln_b, H, B, stg.ln_dim, T, 1, 1e-6f, s)))
+                return st;
+            r = ConvRun();
+            r.batch = B;
+            r.t_in = T;
+            r.x = H;
+            r.y = X;
+            if ((st = conv_layer_run(stg.conv, r, s))) return st;
+        }
+        for (auto& bp : stg.blocks) {
+            CnxBlock& blk = *bp;
+            // dwconv -> LN (convnext.py:126-129)
+            if ((st = launch_dwconv_ln(X, blk.d_dw_w, blk.d_dw_b, blk.d_ln_w, blk.d_ln_b, H, B, dim, T, ks, 1e-6f, s)))
+                return st;
+            // pwconv1 + GELU (convnext.py:130-131)
+            r = ConvRun();
+            r.batch = B;
+            r.t_in = T;
+            r.x = H;
+            r.y = G;
+            r.post_act = FV_ACT_GELU;
+            if ((st = conv_layer_run(blk.pw1, r, s))) return st;
+            // pwconv2, * gamma, + input (convnext.py:132-141)
+            r = ConvRun();
+            r.batch = B;
+            r.t_in = T;
+            r.x = G;
+            r.y = X;
+            r.res = X;
+            r.gamma = blk.d_gamma;
+            if ((st = conv_layer_run(blk.pw2, r, s))) return st;
+        }
+    }
+    return launch_dwconv_ln(X, nullptr, nullptr, cnx.d_norm_w, cnx.d_norm_b, d_out, B, cnx.out_dim(), T, 1, 1e-6f, s);
+}
+
+fv_status fv_engine::run_head(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s) {
+    const int N = head.cfg.n_fft, nb = head.nb;
+    const int64_t rows = std::max<int64_t>(2 * nb, N);
+    const int64_t me = (rows * T * B + 63) / 64 * 64;
+    float* Hh = ws;            // (2nb, T) log-mag / phase
+    float* Sp = ws + me;       // (2nb, T) Re / Im
+    float* Fr = ws + 2 * me;   // (n_fft, T) windowed frames
+    fv_status st;
+    ConvRun r;
+    r.batch = B;
+    r.t_in = T;
+    r.x = d_in;
+    r.y = Hh;
+    if ((st = conv_layer_run(head.out, r, s))) return st;
+    // Hh is already compacted to 2*nb rows: reuse the spec kernel with n_fft' = nb (rows [0,nb) mag, [nb,2nb) phase)
+    if ((st = launch_istft_spec(Hh, Sp, B, nb, T, nb, nb, s))) return st;
+    r = ConvRun();
+    r.batch = B;
+    r.t_in = T;
+    r.x = Sp;
+    r.y = Fr;
+    if ((st = conv_layer_run(head.idft, r, s))) return st;
+    const int pad = (head.cfg.win_length - head.cfg.hop_length) / 2;
+    return launch_istft_ola(Fr, head.d_win2, d_out, B, N, T, head.cfg.hop_length, pad, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static fv_status validate_ups(const fv_upsampler_config& c) {
+    if (c.num_upsamples < 1 || c.num_upsamples > FV_MAX_STAGES || c.num_kernels < 1 || c.num_kernels > FV_MAX_KERNELS) {
+        set_error("num_upsamples=%d / num_kernels=%d out of range", c.num_upsamples, c.num_kernels);
+        return FV_ERR_INVALID;
+    }
+    int64_t prod = 1;
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        if (c.upsample_rates[i] < 1 || c.upsample_kernel_sizes[i] < c.upsample_rates[i]) {
+            set_error("stage %d: upsample rate %d / kernel %d invalid", i, c.upsample_rates[i], c.upsample_kernel_sizes[i]);
+            return FV_ERR_INVALID;
+        }
+        prod *= c.upsample_rates[i];
+    }
+    if (prod != c.hop_length) {  // hifigan.py:154-156
+        set_error("hop_length must be %lld", (long long)prod);
+        return FV_ERR_INVALID;
+    }
+    if (c.use_template) {
+        set_error("use_template=True is not supported (every shipped config sets use_template: false)");
+        return FV_ERR_UNSUPPORTED;
+    }
+    if (c.num_mels < 1 || c.upsample_initial_channel < 1 || c.pre_conv_kernel_size < 1 || c.post_conv_kernel_size < 1 ||
+        c.pre_conv_kernel_size % 2 == 0 || c.post_conv_kernel_size % 2 == 0) {
+        set_error("invalid num_mels / upsample_initial_channel / pre,post kernel sizes (must be odd)");
+        return FV_ERR_INVALID;
+    }
+    for (int j = 0; j < c.num_kernels; ++j) {
+        if (c.resblock_kernel_sizes[j] < 1 || c.resblock_kernel_sizes[j] % 2 == 0) {
+            set_error("resblock kernel size %d must be odd", c.resblock_kernel_sizes[j]);
+            return FV_ERR_INVALID;
+        }
+        for (int n = 0; n < FV_MAX_DILATIONS; ++n)
+            if (c.resblock_dilation_sizes[j][n] < 1) {
+                set_error("resblock dilation must be >= 1");
+                return FV_ERR_INVALID;
+            }
+    }
+    return FV_OK;
+}
+
+extern "C" {
+
+FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
+    if (!cfg || !out) {
+        set_error("fv_create: null argument");
+        return FV_ERR_INVALID;
+    }
+    if (cfg->abi_version != FV_ABI_VERSION) {
+        set_error("fv_create: ABI version %d, library is %d", cfg->abi_version, FV_ABI_VERSION);
+        return FV_ERR_INVALID;
+    }
+    fv_status st = FV_OK;
+    switch (cfg->model) {
+        case FV_MODEL_HIFIGAN:
+        case FV_MODEL_BIGVGAN: st = validate_ups(cfg->ups); break;
+        case FV_MODEL_FIREFLY:
+            st = validate_ups(cfg->ups);
+            if (!st && cfg->ups.num_mels != cfg->backbone.dims[cfg->backbone.num_stages - 1]) {
+                set_error("firefly: head num_mels (%d) must equal the backbone output dim (%d)", cfg->ups.num_mels,
+                          cfg->backbone.dims[cfg->backbone.num_stages - 1]);
+                st = FV_ERR_INVALID;
+            }
+            break;
+        case FV_MODEL_VOCOS:
+        case FV_MODEL_ISTFT_HEAD:
+            if (cfg->head.win_length != cfg->head.n_fft || cfg->head.hop_length < 1 || cfg->head.n_fft < 2 ||
+                cfg->head.n_fft % 2 || cfg->head.hop_length > cfg->head.win_length || cfg->head.dim < 1 ||
+                (cfg->head.win_length - cfg->head.hop_length) % 2 ||
+                (cfg->model == FV_MODEL_VOCOS &&
+                 cfg->head.dim != cfg->backbone.dims[cfg->backbone.num_stages > 0 ? cfg->backbone.num_stages - 1 : 0])) {
+                set_error("istft head: need even n_fft == win_length >= hop_length, even (win-hop), dim == backbone dims[-1]");
+                st = FV_ERR_INVALID;
+            }
+            break;
+        case FV_MODEL_CONVNEXT: break;
+        default: set_error("fv_create: unknown model kind %d", cfg->model); st = FV_ERR_INVALID;
+    }
+    if (!st && cfg->model != FV_MODEL_HIFIGAN && cfg->model != FV_MODEL_BIGVGAN && cfg->model != FV_MODEL_ISTFT_HEAD) {
+        const fv_convnext_config& b = cfg->backbone;
+        if (b.num_stages < 1 || b.num_stages > FV_MAX_STAGES || b.input_channels < 1 || b.kernel_size < 1 || b.kernel_size % 2 == 0) {
+            set_error("convnext: invalid num_stages / input_channels / kernel_size");
+            st = FV_ERR_INVALID;
+        }
+        for (int i = 0; !st && i < b.num_stages; ++i)
+            if (b.depths[i] < 0 || b.dims[i] < 1) {
+                set_error("convnext: invalid depths/dims at stage %d", i);
+                st = FV_ERR_INVALID;
+            }
+    }
+    if (st) return st;
+    fv_engine* e = new (std::nothrow) fv_engine();
+    if (!e) {
+        set_error("out of host memory");
+        return FV_ERR_INVALID;
+    }
+    e->cfg = *cfg;
+    *out = e;
+    return FV_OK;
+}
+
+FV_API fv_status fv_load_weight(fv_engine* e, const char* name, const float* host_data, const int64_t* shape, int32_t ndim) {
+    if (!e || !name || !host_data || ndim < 0 || ndim > 8 || (ndim > 0 && !shape)) {
+        set_error("fv_load_weight: invalid argument");
+        return FV_ERR_INVALID;
+    }
+    if (e->finalized) {
+        set_error("fv_load_weight: engine already finalized");
+        return FV_ERR_STATE;
+    }
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    const int64_t n = t.numel();
+    if (n < 0) {
+        set_error("fv_load_weight: negative dimension");
+        return FV_ERR_SHAPE;
+    }
+    t.data.assign(host_data, host_data + n);
+    e->raw[name] = std::move(t);
+    return FV_OK;
+}
+
+FV_API fv_status fv_finalize(fv_engine* e) {
+    if (!e) {
+        set_error("fv_finalize: null engine");
+        return FV_ERR_INVALID;
+    }
+    if (e->finalized) return FV_OK;
+    fv_status st = FV_OK;
+    switch (e->cfg.model) {
+        case FV_MODEL_HIFIGAN: st = e->build_upsampler("", false); break;
+        case FV_MODEL_BIGVGAN: st = e->build_upsampler("", true); break;
+        case FV_MODEL_CONVNEXT: st = e->build_convnext(""); break;
+        case FV_MODEL_ISTFT_HEAD: st = e->build_head(""); break;
+        case FV_MODEL_VOCOS:
+            st = e->build_convnext("backbone.");
+            if (!st) st = e->build_head("head.");
+            break;
+        case FV_MODEL_FIREFLY:
+            st = e->build_convnext("backbone.");
+            if (!st) st = e->build_upsampler("head.", false);
+            break;
+    }
+    if (st) return st;
+    // strict load: unexpected keys are an error, as load_state_dict(strict=True) (test.py:37)
+    for (auto& kv : e->raw)
+        if (!e->used.count(kv.first)) {
+            set_error("unexpected key '%s' in state dict", kv.first.c_str());
+            return FV_ERR_INVALID;
+        }
+    e->raw.clear();
+    e->finalized = true;
+    return FV_OK;
+}
+
+FV_API void fv_destroy(fv_engine* e) { delete e; }
+
+FV_API int32_t fv_input_channels(const fv_engine* e) {
+    if (!e) return 0;
+    if (e->cfg.model == FV_MODEL_ISTFT_HEAD) return e->cfg.head.dim;
+    return (e->cfg.model == FV_MODEL_HIFIGAN || e->cfg.model == FV_MODEL_BIGVGAN) ? e->cfg.ups.num_mels
+                                                                                    : e->cfg.backbone.input_channels;
+}
+FV_API int32_t fv_output_channels(const fv_engine* e) {
+    if (!e) return 0;
+    return e->cfg.model == FV_MODEL_CONVNEXT ? e->cfg.backbone.dims[e->cfg.backbone.num_stages - 1] : 1;
+}
+FV_API int64_t fv_output_length(const fv_engine* e, int32_t t_in) {
+    if (!e || !e->finalized || t_in < 1) return 0;
+    switch (e->cfg.model) {
+        case FV_MODEL_HIFIGAN:
+        case FV_MODEL_BIGVGAN:
+        case FV_MODEL_FIREFLY: return e->ups.out_len(t_in);
+        case FV_MODEL_VOCOS:
+        case FV_MODEL_ISTFT_HEAD: return (int64_t)t_in * e->cfg.head.hop_length;
+        default: return t_in;
+    }
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static size_t ups_ws_elems(const fv_engine* e, int B, int T) { return (size_t)6 * ((e->ups.max_elems(T) * B + 63) / 64 * 64); }
+static size_t cnx_ws_elems(const fv_engine* e, int B, int T) {
+    const size_t me = ((size_t)e->cnx.max_dim() * T * B + 63) / 64 * 64;
+    return 2 * me + 4 * me;  // X, H, and the 4x hidden
+}
+static size_t head_ws_elems(const fv_engine* e, int B, int T) {
+    const size_t rows = std::max<size_t>(2 * e->head.nb, e->cfg.head.n_fft);
+    return 3 * ((rows * T * B + 63) / 64 * 64);
+}
+
+FV_API size_t fv_workspace_bytes(const fv_engine* e, int32_t batch, int32_t t_in) {
+    if (!e || !e->finalized || batch < 1 || t_in < 1) return 0;
+    size_t elems = 0;
+    switch (e->cfg.model) {
+        case FV_MODEL_HIFIGAN:
+        case FV_MODEL_BIGVGAN: elems = ups_ws_elems(e, batch, t_in); break;
+        case FV_MODEL_CONVNEXT: elems = cnx_ws_elems(e, batch, t_in); break;
+        case FV_MODEL_ISTFT_HEAD: elems = head_ws_elems(e, batch, t_in); break;
+        case FV_MODEL_VOCOS: {
+            const size_t mid = align_up((size_t)e->cnx.out_dim() * t_in * batch, 64);
+            elems = mid + std::max(cnx_ws_elems(e, batch, t_in), head_ws_elems(e, batch, t_in));
+            break;
+        }
+        case FV_MODEL_FIREFLY: {
+            const size_t mid = align_up((size_t)e->cnx.out_dim() * t_in * batch, 64);
+            elems = mid + std::max(cnx_ws_elems(e, batch, t_in), ups_ws_elems(e, batch, t_in));
+            break;
+        }
+    }
+    return align_up(elems * sizeof(float), 256);
+}
+
+FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32_t batch, int32_t t_in, void* d_workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (!e || !d_in || !d_out) {
+        set_error("fv_forward: null argument");
+        return FV_ERR_INVALID;
+    }
+    if (!e->finalized) {
+        set_error("fv_forward: call fv_finalize first");
+        return FV_ERR_STATE;
+    }
+    if (batch < 1 || t_in < 1) {
+        set_error("fv_forward: empty input (batch=%d, t_in=%d)", batch, t_in);
+        return FV_ERR_INVALID;
+    }
+    const size_t need = fv_workspace_bytes(e, batch, t_in);
+    if (!d_workspace || workspace_bytes < need) {
+        set_error("fv_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+        return FV_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)d_workspace;
+    switch (e->cfg.model) {
+        case FV_MODEL_HIFIGAN:
+        case FV_MODEL_BIGVGAN: return e->run_upsampler(d_in, d_out, batch, t_in, ws, s);
+        case FV_MODEL_CONVNEXT: return e->run_convnext(d_in, d_out, batch, t_in, ws, s);
+        case FV_MODEL_ISTFT_HEAD: return e->run_head(d_in, d_out, batch, t_in, ws, s);
+        case FV_MODEL_VOCOS: {
+            const size_t mid = align_up((size_t)e->cnx.out_dim() * t_in * batch, 64);
+            fv_status st = e->run_convnext(d_in, ws, batch, t_in, ws + mid, s);
+            if (st) return st;
+            return e->run_head(ws, d_out, batch, t_in, ws + mid, s);
+        }
+        case FV_MODEL_FIREFLY: {
+            const size_t mid = align_up((size_t)e->cnx.out_dim() * t_in * batch, 64);
+            fv_status st = e->run_convnext(d_in, ws, batch, t_in, ws + mid, s);
+            if (st) return st;
+            return e->run_upsampler(ws, d_out, batch, t_in, ws + mid, s);
+        }
+    }
+    set_error("fv_forward: unknown model");
+    return FV_ERR_INVALID;
+}
+
+// ---- single conv layer ----
+struct fv_conv {
+    ConvLayer L;
+    fv_conv_desc desc;
+};
+
+FV_API fv_status fv_conv_create(const fv_conv_desc* d, const float* host_weight, const float* host_bias, fv_conv** out) {
+    if (!d || !host_weight || !out) {
+        set_error("fv_conv_create: null argument");
+        return FV_ERR_INVALID;
+    }
+    fv_conv* c = new (std::nothrow) fv_conv();
+    if (!c) {
+        set_error("out of host memory");
+        return FV_ERR_INVALID;
+    }
+    c->desc = *d;
+    fv_status st = conv_layer_create(c->L, d->transposed != 0, d->c_in, d->c_out, d->kernel_size,
+                                     d->transposed ? 1 : d->dilation, d->padding, d->transposed ? d->stride : 1,
+                                     host_weight, host_bias);
+    if (st) {
+        conv_layer_destroy(c->L);
+        delete c;
+        return st;
+    }
+    *out = c;
+    return FV_OK;
+}
+
+FV_API int64_t fv_conv_output_length(const fv_conv* c, int32_t t_in) { return c ? c->L.out_len(t_in) : 0; }
+
+FV_API fv_status fv_conv_forward(fv_conv* c, const float* d_x, float* d_y, const float* d_residual, int32_t batch, int32_t t_in,
+                          void* stream) {
+    if (!c || !d_x || !d_y) {
+        set_error("fv_conv_forward: null argument");
+        return FV_ERR_INVALID;
+    }
+    ConvRun r;
+    r.x = d_x;
+    r.y = d_y;
+    r.res = d_residual;
+    r.batch = batch;
+    r.t_in = t_in;
+    r.pre_act = c->desc.pre_act;
+    r.post_act = c->desc.post_act;
+    r.slope = c->desc.act_slope;
+    return conv_layer_run(c->L, r, (hipStream_t)stream);
+}
+
+FV_API void fv_conv_destroy(fv_conv* c) {
+    if (!c) return;
+    conv_layer_destroy(c->L);
+    delete c;
+}
+
+FV_API const char* fv_last_error(void) { return g_err.c_str(); }
+FV_API int32_t fv_abi_version(void) { return FV_ABI_VERSION; }
+FV_API const char* fv_last_kernel(void) { return g_kernel.c_str(); }
+
+}  // extern "C"

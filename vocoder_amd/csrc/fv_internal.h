@@ -1,0 +1,140 @@
+// Internal declarations shared by the host engine and the HIP kernels of libfishvoc_hip.so.
+// gfx950 (MI355X / CDNA4) only: 64-wide wavefronts, v_mfma_f32_32x32x2_f32, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "fishvoc.h"
+
+namespace fv {
+
+void set_error(const char* fmt, ...);
+void set_last_kernel(const char* name);
+
+#define FV_HIP_CHECK(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            ::fv::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return FV_ERR_HIP;                                                                   \
+        }                                                                                        \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Fused conv layer ("implicit GEMM on fp32 MFMA").
+//
+//   out[b][m][n] = post( bias[m] + sum_{ci<Cin} sum_{j<ks} W[m][ci][j] * pre(x[b][ci][n + j*dil - pad_l]) )
+//
+// Conv1d:           m = c_out, n = t, pad_l = padding.
+// ConvTranspose1d:  polyphase form.  m = (c_out, r) with r = output phase in [0, stride), n = q, ks' = ceil(k/stride),
+//                   dil = 1, pad_l = ks'-1, and the result lands at t = q*stride + r - padding (scatter store).
+// ---------------------------------------------------------------------------------------------
+constexpr int kChunk = 8;  // input channels staged per LDS chunk (= 4 MFMA k-steps of 2 per tap)
+
+enum OutMode : int { OUT_SET = 0, OUT_ACCUM = 1 };  // OUT_ACCUM: y = (y_old + v) * out_scale  (MRF stack-mean)
+
+struct ConvParams {
+    const float* x;      // (B, Cin, Tin)
+    const float4* wp;    // packed weights, see pack_conv_weights()
+    const float* bias;   // (m_pad) zero padded, never NULL
+    float* y;
+    const float* res;    // residual, same indexing as y (may be NULL, may alias y)
+    const float* gamma;  // per-row scale applied before the residual (ConvNeXt layer-scale), may be NULL
+    int Cin, Tin;
+    int M, N;            // valid GEMM rows / columns per batch item
+    int nchunk;          // ceil(Cin / kChunk)
+    int n_tiles, m_blks; // grid = B * m_blks * n_tiles
+    int pad_l;
+    int ks, dil;         // runtime copies (used by the generic variant)
+    int pre_act, post_act;
+    float slope;
+    int out_mode;
+    float out_scale;
+    int convt;           // scatter store for the transposed conv
+    int u, pad_t, Tout, Cout;
+    long long x_bstride, y_bstride;
+};
+
+struct ConvLayer {
+    // logical description
+    bool transposed = false;
+    int c_in = 0, c_out = 0, k = 0, dil = 1, padding = 0, stride = 1;
+    // GEMM view
+    int M = 0, ks = 0, pad_l = 0, nchunk = 0, m_pad = 0;
+    float4* d_wp = nullptr;
+    float* d_bias = nullptr;
+    size_t wp_bytes = 0;
+
+    int64_t out_len(int t_in) const {
+        return transposed ? (int64_t)(t_in - 1) * stride - 2 * padding + k
+                          : (int64_t)t_in + 2 * padding - (int64_t)dil * (k - 1);
+    }
+    // number of GEMM columns per item
+    int64_t gemm_cols(int t_in) const {
+        if (!transposed) return out_len(t_in);
+        const int64_t tout = out_len(t_in);
+        return (tout + padding + stride - 1) / stride;  // q in [0, ceil((Tout+pad)/u))
+    }
+};
+
+// Builds the device-side layer from an already-folded torch-layout weight (host).  bias may be NULL.
+fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, int k, int dil, int padding,
+                            int stride, const float* host_w, const float* host_bias);
+void conv_layer_destroy(ConvLayer& L);
+
+struct ConvRun {
+    const float* x = nullptr;
+    float* y = nullptr;
+    const float* res = nullptr;
+    const float* gamma = nullptr;
+    int batch = 0, t_in = 0;
+    int pre_act = FV_ACT_NONE, post_act = FV_ACT_NONE;
+    float slope = 0.f;
+    int out_mode = OUT_SET;
+    float out_scale = 1.f;
+};
+fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t stream);
+
+// Per-(kernel size) translation units (parallel builds): return false if (ks, dil) has no specialisation.
+bool launch_conv_k1(const ConvParams& p, int cfg, int batch, hipStream_t s);
+bool launch_conv_k3(const ConvParams& p, int cfg, int batch, hipStream_t s);
+bool launch_conv_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
+bool launch_conv_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
+bool launch_conv_misc(const ConvParams& p, int cfg, int batch, hipStream_t s);   // k=2, 4, 5, 13 ...
+bool launch_conv_generic(const ConvParams& p, int cfg, int batch, hipStream_t s, size_t* lds_bytes);
+
+// Tile configurations (block = 4 waves): rows = WM*MT*32, cols = WN*NT*32.
+enum TileCfg : int { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2, TILE_128x64 = 3, TILE_32x128 = 4, TILE_64x128 = 5, TILE_COUNT };
+void tile_dims(int cfg, int* m_blk, int* n_blk);
+
+// ---------------------------------------------------------------------------------------------
+// Small fused kernels (elementwise / narrow-output / reduction)
+// ---------------------------------------------------------------------------------------------
+// y[b][co][t] = post( bias[co] + sum_{ci,j} w[co][ci][j] * pre(x[b][ci][t + j - pad]) ), c_out <= 4 (conv_post).
+fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int T,
+                             int Cout, int k, int pad, int pre_act, int post_act, float slope, hipStream_t s);
+
+// Anti-aliased SnakeBeta: y = down2(snake(up2(x))) with 12-tap kaiser-sinc filters (alias_free_torch Activation1d).
+// alpha_eff/inv_beta are per-channel, already exp()'d / inverted on the host.
+fv_status launch_aa_snake(const float* x, float* y, const float* alpha_eff, const float* inv_beta, const float* up_taps,
+                          const float* down_taps, int B, int C, int T, hipStream_t s);
+
+// Depthwise conv (k taps, zero pad) + LayerNorm over channels, fused: y = LN_c(dwconv(x)) * w + b.
+// With dw_w == NULL: plain channels-first LayerNorm.
+fv_status launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                           float* y, int B, int C, int T, int k, float eps, hipStream_t s);
+
+// ISTFT head glue: h (B, 2*n_fft, T) rows [0,nb) = log-mag, [n_fft, n_fft+nb) = phase -> spec (B, 2*nbp, T):
+// rows [0,nb) = Re, [nbp, nbp+nb) = Im, zero padded to nbp = round_up(nb, 8)
+fv_status launch_istft_spec(const float* h, float* spec, int B, int n_fft, int T, int nb, int nbp, hipStream_t s);
+// frames (B, n_fft, T) (already windowed by the synthesis basis) -> overlap-add, crop, divide by the envelope.
+fv_status launch_istft_ola(const float* frames, const float* inv_env, float* y, int B, int n_fft, int T, int hop, int pad,
+                           hipStream_t s);
+
+}  // namespace fv

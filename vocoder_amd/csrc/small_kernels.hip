@@ -1,0 +1,320 @@
+// HBM-bound helper kernels around the MFMA conv: narrow-output conv (conv_post), anti-aliased SnakeBeta,
+// depthwise-conv + LayerNorm, ISTFT spectrum / overlap-add.  All are coalesced along T (the contiguous axis of
+// the reference's (B, C, T) layout) and stage their reuse windows in LDS.
+#include "conv_mfma_impl.h"
+
+namespace fv {
+
+// ---------------------------------------------------------------------------------------------
+// conv_post: y[b][co][t] = post(bias[co] + sum_{ci,j} w[co][ci][j] * pre(x[b][ci][t + j - pad])), Cout <= 4.
+// Replaces activation_post -> conv_post -> tanh (fish_vocoder/modules/generators/hifigan.py:245-247).
+// One workgroup = 1024 consecutive t of one batch item; 8-channel slabs of pre-activated x go through LDS so the
+// activation is evaluated once per element instead of once per tap.
+// ---------------------------------------------------------------------------------------------
+constexpr int NARROW_TT = 1024;
+constexpr int NARROW_CH = 8;
+constexpr int NARROW_MAXCO = 4;
+
+__global__ __launch_bounds__(256) void conv_narrow_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int Cin, int T, int Cout, int k, int pad, int pre_act,
+                                                          int post_act, float slope, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int W = NARROW_TT + k - 1;
+    float* xs = sm;                       // [NARROW_CH][W]
+    float* ws = sm + NARROW_CH * W;       // [Cout][NARROW_CH][k] for the current slab
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
+    const int t0 = tile * NARROW_TT;
+    const float* xb = x + (long long)b * Cin * T;
+
+    float acc[NARROW_MAXCO][4];
+#pragma unroll
+    for (int co = 0; co < NARROW_MAXCO; ++co)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[co][i] = 0.f;
+
+    for (int c0 = 0; c0 < Cin; c0 += NARROW_CH) {
+        __syncthreads();
+        for (int e = tid; e < NARROW_CH * W; e += 256) {
+            const int r = e / W, col = e - r * W;
+            const int ci = c0 + r, t = t0 - pad + col;
+            float v = 0.f;
+            if (ci < Cin && t >= 0 && t < T) v = act_apply(xb[(long long)ci * T + t], pre_act, slope);
+            xs[e] = v;
+        }
+        for (int e = tid; e < Cout * NARROW_CH * k; e += 256) {
+            const int j = e % k, r = (e / k) % NARROW_CH, co = e / (k * NARROW_CH);
+            ws[e] = (c0 + r < Cin) ? w[((long long)co * Cin + c0 + r) * k + j] : 0.f;
+        }
+        __syncthreads();
+        for (int r = 0; r < NARROW_CH; ++r) {
+            for (int j = 0; j < k; ++j) {
+                float xv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[i] = xs[r * W + tid + i * 256 + j];
+#pragma unroll
+                for (int co = 0; co < NARROW_MAXCO; ++co) {
+                    if (co < Cout) {
+                        const float wv = ws[(co * NARROW_CH + r) * k + j];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[co][i] = fmaf(wv, xv[i], acc[co][i]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < NARROW_MAXCO; ++co) {
+        if (co >= Cout) break;
+        const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = t0 + tid + i * 256;
+            if (t < T) y[((long long)b * Cout + co) * T + t] = act_apply(acc[co][i] + bv, post_act, slope);
+        }
+    }
+}
+
+fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int T,
+                             int Cout, int k, int pad, int pre_act, int post_act, float slope, hipStream_t s) {
+    if (Cout > NARROW_MAXCO || 2 * pad != k - 1) {
+        set_error("conv_narrow: needs c_out <= %d and 'same' padding (c_out=%d k=%d pad=%d)", NARROW_MAXCO, Cout, k, pad);
+        return FV_ERR_UNSUPPORTED;
+    }
+    const int n_tiles = (T + NARROW_TT - 1) / NARROW_TT;
+    const size_t lds = ((size_t)NARROW_CH * (NARROW_TT + k - 1) + (size_t)Cout * NARROW_CH * k) * sizeof(float);
+    hipLaunchKernelGGL(conv_narrow_kernel, dim3(B * n_tiles), dim3(256), lds, s, x, w, bias, y, Cin, T, Cout, k, pad,
+                       pre_act, post_act, slope, n_tiles);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Anti-aliased SnakeBeta (alias_free_torch.Activation1d around bigvgan.py:121-135), fused:
+//   u = 2 * up-FIR(replicate-padded x)  (12-tap kaiser-sinc, polyphase: 6 taps per output phase)
+//   a = u + inv_beta * sin(alpha * u)^2
+//   y[t] = sum_j down[j] * a[clamp(2t + j - 5)]
+// One workgroup = one (b, c) row tile of AA_TT outputs; x window and the activated 2x signal live in LDS, so the
+// 2T-long intermediate never touches HBM (the reference makes ~9 tensor passes per activation).
+// ---------------------------------------------------------------------------------------------
+constexpr int AA_TT = 1024;
+
+__global__ __launch_bounds__(256) void aa_snake_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ alpha_eff,
+                                                       const float* __restrict__ inv_beta,
+                                                       const float* __restrict__ up_taps,
+                                                       const float* __restrict__ down_taps, int C, int T, int n_tiles) {
+    __shared__ float xs[AA_TT + 16];
+    __shared__ float as[2 * AA_TT + 16];
+    __shared__ float tp[24];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x % n_tiles;
+    const long long row = blockIdx.x / n_tiles;  // b * C + c
+    const int c = (int)(row % C);
+    const int t0 = tile * AA_TT;
+    const float* xr = x + row * T;
+    if (tid < 12) tp[tid] = up_taps[tid];
+    else if (tid < 24) tp[tid] = down_taps[tid - 12];
+    // x window: indices t0-6 .. t0+AA_TT+6 (clamped = replicate padding)
+    for (int e = tid; e < AA_TT + 13; e += 256) {
+        int t = t0 - 6 + e;
+        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+        xs[e] = xr[t];
+    }
+    __syncthreads();
+    const float al = alpha_eff[c], ib = inv_beta[c];
+    // activated up-sampled signal for n in [2*t0 - 5, 2*(t0+AA_TT) + 6): as[e] <-> n = 2*t0 - 5 + e
+    const int T2 = 2 * T;
+    for (int e = tid; e < 2 * AA_TT + 11; e += 256) {
+        int n = 2 * t0 - 5 + e;
+        n = n < 0 ? 0 : (n > T2 - 1 ? T2 - 1 : n);   // replicate padding of the down-sampler input
+        const int h = n >> 1;
+        // polyphase taps: even n uses odd taps j=1,3,..,11 at x[h + (5-j)/2 ...]; odd n uses even taps
+        float u = 0.f;
+        const int xi = h - t0 + 6;  // position of x[h] in xs
+        if ((n & 1) == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) u = fmaf(tp[2 * q + 1], xs[xi + 2 - q], u);   // j=2q+1 -> src h + 2 - q
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) u = fmaf(tp[2 * q], xs[xi + 3 - q], u);       // j=2q   -> src h + 3 - q
+        }
+        u *= 2.0f;
+        const float sn = sinf(u * al);
+        as[e] = fmaf(ib, sn * sn, u);
+    }
+    __syncthreads();
+    for (int i = tid; i < AA_TT; i += 256) {
+        const int t = t0 + i;
+        if (t >= T) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc = fmaf(tp[12 + j], as[2 * i + j], acc);   // n = 2t + j - 5 -> e = 2i + j
+        y[row * T + t] = acc;
+    }
+}
+
+fv_status launch_aa_snake(const float* x, float* y, const float* alpha_eff, const float* inv_beta, const float* up_taps,
+                          const float* down_taps, int B, int C, int T, hipStream_t s) {
+    const int n_tiles = (T + AA_TT - 1) / AA_TT;
+    hipLaunchKernelGGL(aa_snake_kernel, dim3((unsigned)((long long)B * C * n_tiles)), dim3(256), 0, s, x, y, alpha_eff,
+                       inv_beta, up_taps, down_taps, C, T, n_tiles);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise Conv1d(k, 'same' zero pad, groups=C) + LayerNorm over channels (ConvNeXtBlock head,
+// fish_vocoder/modules/encoders/convnext.py:126-129; also the channels_first LayerNorm, convnext.py:71-74,
+// when dw_w == NULL).  Workgroup = 32 time columns x 8 channel groups; two-pass mean / variance (same arithmetic as
+// the reference: mean of squared deviations), the 7-tap FIR is recomputed per pass instead of spilling C x 32 values.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dw_value(const float* __restrict__ xr, const float* __restrict__ w, float bias, int t,
+                                          int T, int k, int pad) {
+    if (!w) return xr[t];
+    float v = bias;
+    for (int j = 0; j < k; ++j) {
+        const int tt = t + j - pad;
+        if (tt >= 0 && tt < T) v = fmaf(w[j], xr[tt], v);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
+                                                        const float* __restrict__ dw_b, const float* __restrict__ ln_w,
+                                                        const float* __restrict__ ln_b, float* __restrict__ y, int C,
+                                                        int T, int k, float eps, int n_tiles) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
+    const int t = tile * 32 + col;
+    const bool live = t < T;
+    const int pad = (k - 1) / 2;
+    const float* xb = x + (long long)b * C * T;
+    float s = 0.f;
+    if (live)
+        for (int c = cg; c < C; c += 8)
+            s += dw_value(xb + (long long)c * T, dw_w ? dw_w + (long long)c * k : nullptr, dw_b ? dw_b[c] : 0.f, t, T, k, pad);
+    red[cg][col] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) mean += red[g][col];
+    mean /= (float)C;
+    __syncthreads();
+    float q = 0.f;
+    if (live)
+        for (int c = cg; c < C; c += 8) {
+            const float d = dw_value(xb + (long long)c * T, dw_w ? dw_w + (long long)c * k : nullptr, dw_b ? dw_b[c] : 0.f, t, T, k, pad) - mean;
+            q = fmaf(d, d, q);
+        }
+    red[cg][col] = q;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) var += red[g][col];
+    var /= (float)C;
+    const float inv = 1.0f / sqrtf(var + eps);
+    if (live) {
+        float* yb = y + (long long)b * C * T;
+        for (int c = cg; c < C; c += 8) {
+            const float h = dw_value(xb + (long long)c * T, dw_w ? dw_w + (long long)c * k : nullptr, dw_b ? dw_b[c] : 0.f, t, T, k, pad);
+            yb[(long long)c * T + t] = (h - mean) * inv * ln_w[c] + ln_b[c];
+        }
+    }
+}
+
+fv_status launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                           float* y, int B, int C, int T, int k, float eps, hipStream_t s) {
+    const int n_tiles = (T + 31) / 32;
+    hipLaunchKernelGGL(dwconv_ln_kernel, dim3(B * n_tiles), dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, k, eps,
+                       n_tiles);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ISTFT head glue (fish_vocoder/modules/generators/vocos.py:57-67): mag = min(exp(h_mag), 100), S = mag * e^{i p}.
+// Only bins [0, nb = n_fft/2+1) survive torch.fft.irfft, so only those rows are produced:
+// spec rows [0, nb) = Re, [nb, 2nb) = Im -> the K dimension of the inverse-DFT GEMM.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void istft_spec_kernel(const float* __restrict__ h, float* __restrict__ spec,
+                                                         int n_fft, int T, int nb, int nbp) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per = (long long)nb * T;
+    const int b = blockIdx.y;
+    if (i >= per) return;
+    const int kbin = (int)(i / T), t = (int)(i - (long long)kbin * T);
+    const float* hb = h + (long long)b * 2 * n_fft * T;
+    float m = __expf(hb[(long long)kbin * T + t]);
+    m = m > 100.0f ? 100.0f : m;
+    const float ph = hb[(long long)(n_fft + kbin) * T + t];
+    float sn, cs;
+    sincosf(ph, &sn, &cs);
+    float* sb = spec + (long long)b * 2 * nbp * T;
+    sb[(long long)kbin * T + t] = m * cs;
+    sb[(long long)(nbp + kbin) * T + t] = m * sn;
+}
+
+fv_status launch_istft_spec(const float* h, float* spec, int B, int n_fft, int T, int nb, int nbp, hipStream_t s) {
+    const long long per = (long long)nb * T;
+    hipLaunchKernelGGL(istft_spec_kernel, dim3((unsigned)((per + 255) / 256), B), dim3(256), 0, s, h, spec, n_fft, T, nb,
+                       nbp);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
+// Overlap-add + crop + envelope normalisation of vocos ISTFT("same").  frames: (B, n_fft, T), already multiplied by the
+// hann window (folded into the inverse-DFT basis).  Output sample s = tau*hop + r - pad collects
+// frames[g*hop + r][tau - g]; reads are coalesced along tau, the write is transposed through LDS so it is coalesced
+// along r.  win2 = window^2 (n_fft).
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ win2,
+                                                        float* __restrict__ y, int n_fft, int T, int hop, int pad,
+                                                        int r_tiles, int tau_tiles) {
+    __shared__ float tile[32][33];
+    int bid = blockIdx.x;
+    const int tt = bid % tau_tiles;
+    bid /= tau_tiles;
+    const int rt = bid % r_tiles;
+    const int b = bid / r_tiles;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float* fb = frames + (long long)b * n_fft * T;
+    const long long out_len = (long long)T * hop;
+    const int n_tau = T + (n_fft + hop - 1) / hop;  // hop-frames touched by any analysis frame
+    for (int rr = ty; rr < 32; rr += 8) {
+        const int r = rt * 32 + rr, tau = tt * 32 + tx;
+        float acc = 0.f, env = 0.f;
+        if (r < hop && tau < n_tau) {
+            for (int g = 0; g * hop + r < n_fft; ++g) {
+                const int t = tau - g;
+                if (t >= 0 && t < T) {
+                    acc += fb[(long long)(g * hop + r) * T + t];
+                    env += win2[g * hop + r];
+                }
+            }
+        }
+        tile[rr][tx] = env > 0.f ? acc / env : 0.f;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 32; cc += 8) {
+        const int tau = tt * 32 + cc, r = rt * 32 + tx;
+        if (r < hop && tau < n_tau) {
+            const long long sidx = (long long)tau * hop + r - pad;
+            if (sidx >= 0 && sidx < out_len) y[(long long)b * out_len + sidx] = tile[tx][cc];
+        }
+    }
+}
+
+fv_status launch_istft_ola(const float* frames, const float* win2, float* y, int B, int n_fft, int T, int hop, int pad,
+                           hipStream_t s) {
+    const int r_tiles = (hop + 31) / 32;
+    const int n_tau = T + (n_fft + hop - 1) / hop;
+    const int tau_tiles = (n_tau + 31) / 32;
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((long long)B * r_tiles * tau_tiles)), dim3(256), 0, s, frames,
+                       win2, y, n_fft, T, hop, pad, r_tiles, tau_tiles);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
+}  // namespace fv

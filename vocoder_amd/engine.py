@@ -1,0 +1,211 @@
+"""Python handle on an ``fv_engine`` / ``fv_conv`` (torch is used only for device memory and streams)."""
+from __future__ import annotations
+
+import ctypes
+from typing import Mapping
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FishVocError, check  # noqa: F401
+
+
+def _require_cuda(x: torch.Tensor, what: str) -> None:
+    if not x.is_cuda:
+        raise RuntimeError(
+            f"{what}: expected a CUDA/HIP tensor on an MI355X, got device '{x.device}'. "
+            "vocoder_amd runs only through its HIP kernels (no CPU fallback).")
+    if x.dtype != torch.float32:
+        raise TypeError(f"{what}: expected float32, got {x.dtype}")
+
+
+def _stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def upsampler_config(*, hop_length, upsample_rates, upsample_kernel_sizes, resblock_kernel_sizes,
+                     resblock_dilation_sizes, num_mels, upsample_initial_channel, use_template=False,
+                     pre_conv_kernel_size=7, post_conv_kernel_size=7) -> _lib.UpsamplerConfig:
+    c = _lib.UpsamplerConfig()
+    if len(upsample_rates) != len(upsample_kernel_sizes):
+        raise ValueError("upsample_rates and upsample_kernel_sizes differ in length")
+    if len(resblock_kernel_sizes) != len(resblock_dilation_sizes):
+        raise AssertionError("len(kernel_sizes) != len(dilation_sizes)")  # hifigan.py:126
+    if len(upsample_rates) > _lib.FV_MAX_STAGES or len(resblock_kernel_sizes) > _lib.FV_MAX_KERNELS:
+        raise ValueError("too many stages / resblock kernels")
+    c.hop_length = int(hop_length)
+    c.num_upsamples = len(upsample_rates)
+    for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+        c.upsample_rates[i], c.upsample_kernel_sizes[i] = int(u), int(k)
+    c.num_kernels = len(resblock_kernel_sizes)
+    for j, (k, ds) in enumerate(zip(resblock_kernel_sizes, resblock_dilation_sizes)):
+        c.resblock_kernel_sizes[j] = int(k)
+        if len(ds) != _lib.FV_MAX_DILATIONS:
+            # ResBlock1 indexes dilation[0..2] (hifigan.py:38,47,56): anything else is an IndexError upstream
+            raise IndexError("resblock_dilation_sizes entries must have exactly 3 dilations")
+        for n, d in enumerate(ds):
+            c.resblock_dilation_sizes[j][n] = int(d)
+    c.num_mels = int(num_mels)
+    c.upsample_initial_channel = int(upsample_initial_channel)
+    c.use_template = int(bool(use_template))
+    c.pre_conv_kernel_size = int(pre_conv_kernel_size)
+    c.post_conv_kernel_size = int(post_conv_kernel_size)
+    return c
+
+
+def convnext_config(*, input_channels, depths, dims, kernel_size=7, **_ignored) -> _lib.ConvNeXtConfig:
+    c = _lib.ConvNeXtConfig()
+    assert len(depths) == len(dims)  # convnext.py:158
+    c.input_channels = int(input_channels)
+    c.num_stages = len(depths)
+    for i, (d, m) in enumerate(zip(depths, dims)):
+        c.depths[i], c.dims[i] = int(d), int(m)
+    c.kernel_size = int(kernel_size)
+    return c
+
+
+def istft_head_config(*, dim, n_fft, hop_length, win_length, padding="same") -> _lib.IstftHeadConfig:
+    if padding != "same":
+        raise NotImplementedError("ISTFTHead: only padding='same' is in scope (every shipped vocos YAML uses it)")
+    c = _lib.IstftHeadConfig()
+    c.dim, c.n_fft, c.hop_length, c.win_length = int(dim), int(n_fft), int(hop_length), int(win_length)
+    return c
+
+
+class Engine:
+    """Owns one ``fv_engine`` on the current device.  ``state_dict`` uses the reference's key names."""
+
+    def __init__(self, model_kind: int, *, ups=None, backbone=None, head=None,
+                 state_dict: Mapping[str, "np.ndarray | torch.Tensor"], device=None):
+        self._h = ctypes.c_void_p()
+        self._lib = _lib.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("vocoder_amd.Engine needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        cfg = _lib.Config()
+        cfg.abi_version = _lib.FV_ABI_VERSION
+        cfg.model = model_kind
+        if ups is not None:
+            cfg.ups = ups
+        if backbone is not None:
+            cfg.backbone = backbone
+        if head is not None:
+            cfg.head = head
+        with torch.cuda.device(self.device):
+            check(self._lib.fv_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+            try:
+                for name, t in state_dict.items():
+                    a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+                    a = np.ascontiguousarray(a, dtype=np.float32)
+                    shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+                    check(self._lib.fv_load_weight(self._h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                                   shape, a.ndim))
+                check(self._lib.fv_finalize(self._h))
+            except Exception:
+                self.close()
+                raise
+        self.in_channels = self._lib.fv_input_channels(self._h)
+        self.out_channels = self._lib.fv_output_channels(self._h)
+        self._ws: torch.Tensor | None = None
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.fv_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def output_length(self, t_in: int) -> int:
+        return int(self._lib.fv_output_length(self._h, int(t_in)))
+
+    def workspace_bytes(self, batch: int, t_in: int) -> int:
+        return int(self._lib.fv_workspace_bytes(self._h, int(batch), int(t_in)))
+
+    def forward(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        _require_cuda(x, "Engine.forward")
+        if x.dim() != 3 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected input of shape (B, {self.in_channels}, T), got {tuple(x.shape)}")
+        x = x.contiguous()
+        B, _, T = x.shape
+        if B == 0 or T == 0:
+            raise ValueError(f"empty input {tuple(x.shape)}")
+        L = self.output_length(T)
+        if out is None:
+            out = torch.empty((B, self.out_channels, L), dtype=torch.float32, device=x.device)
+        need = self.workspace_bytes(B, T)
+        if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != x.device:
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(self._lib.fv_forward(self._h, x.data_ptr(), out.data_ptr(), B, T, self._ws.data_ptr(),
+                                       self._ws.numel() * 4, _stream_ptr(x.device)))
+        return out
+
+    __call__ = forward
+
+
+class FusedConv:
+    """One fused conv layer (``fv_conv``): pre-act -> Conv1d/ConvTranspose1d -> bias [+res] -> post-act."""
+
+    def __init__(self, weight, bias=None, *, transposed=False, dilation=1, padding=0, stride=1,
+                 pre_act=_lib.FV_ACT_NONE, post_act=_lib.FV_ACT_NONE, act_slope=0.0):
+        self._lib = _lib.lib()
+        self._h = ctypes.c_void_p()
+        if not torch.cuda.is_available():
+            raise RuntimeError("vocoder_amd.FusedConv needs a HIP device; there is no CPU fallback")
+        w = np.ascontiguousarray(weight.detach().cpu().numpy() if isinstance(weight, torch.Tensor) else weight,
+                                 dtype=np.float32)
+        d = _lib.ConvDesc()
+        d.transposed = int(transposed)
+        if transposed:
+            d.c_in, d.c_out, d.kernel_size = w.shape
+        else:
+            d.c_out, d.c_in, d.kernel_size = w.shape
+        d.dilation, d.padding, d.stride = int(dilation), int(padding), int(stride)
+        d.pre_act, d.post_act, d.act_slope = int(pre_act), int(post_act), float(act_slope)
+        fp = ctypes.POINTER(ctypes.c_float)
+        b = None
+        if bias is not None:
+            b = np.ascontiguousarray(bias.detach().cpu().numpy() if isinstance(bias, torch.Tensor) else bias,
+                                     dtype=np.float32)
+        check(self._lib.fv_conv_create(ctypes.byref(d), w.ctypes.data_as(fp),
+                                       b.ctypes.data_as(fp) if b is not None else None, ctypes.byref(self._h)))
+        self.c_in, self.c_out = d.c_in, d.c_out
+
+    def output_length(self, t_in: int) -> int:
+        return int(self._lib.fv_conv_output_length(self._h, int(t_in)))
+
+    def __call__(self, x: torch.Tensor, residual: torch.Tensor | None = None, out: torch.Tensor | None = None):
+        _require_cuda(x, "FusedConv")
+        x = x.contiguous()
+        B, C, T = x.shape
+        if C != self.c_in:
+            raise ValueError(f"expected {self.c_in} input channels, got {C}")
+        L = self.output_length(T)
+        if out is None:
+            out = torch.empty((B, self.c_out, L), dtype=torch.float32, device=x.device)
+        if residual is not None:
+            _require_cuda(residual, "FusedConv residual")
+            residual = residual.contiguous()
+            assert residual.shape == out.shape
+        with torch.cuda.device(x.device):
+            check(self._lib.fv_conv_forward(self._h, x.data_ptr(), out.data_ptr(),
+                                            residual.data_ptr() if residual is not None else None, B, T,
+                                            _stream_ptr(x.device)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.fv_conv_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
