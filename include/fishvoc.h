@@ -175,6 +175,15 @@ FV_API fv_status fv_conv_forward(fv_conv* c, const float* d_x, float* d_y, const
                           int32_t t_in, void* stream);
 FV_API void fv_conv_destroy(fv_conv* c);
 
+/* -------- per-launch timing (measurement aid; bench.py's roofline leg) --------
+ * Between fv_profile_begin and fv_profile_end every kernel that fv_forward enqueues is bracketed by hipEvents recorded
+ * on the launch stream.  fv_profile_end synchronises them and writes a JSON array
+ *   [{"kernel": label, "launches": n, "total_ms": .., "avg_ms": .., "flops_per_launch": .., "bytes_per_launch": ..}]
+ * (algorithmic flops / per-layer compulsory bytes) into json_buf (truncated to cap); *needed
+ * receives the full size.  The reference has no counterpart (its only timer is test.py:88-90). */
+FV_API fv_status fv_profile_begin(fv_engine* e);
+FV_API fv_status fv_profile_end(fv_engine* e, char* json_buf, size_t cap, size_t* needed);
+
 /* -------- misc -------- */
 FV_API const char* fv_last_error(void);
 FV_API int32_t fv_abi_version(void);

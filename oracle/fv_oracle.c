@@ -88,15 +88,24 @@ FVO_API void fvo_conv1d(const float* x, const float* w, const float* bias, float
             const float bv = bias ? bias[co] : 0.0f;
             for (int t = 0; t < Tout; ++t) yr[t] = bv;
             const int g = co / cout_g;
-            for (int ci = 0; ci < cin_g; ++ci) {
-                const float* xr = x + ((int64_t)b * Cin + g * cin_g + ci) * T;
-                const float* wr = w + ((int64_t)co * cin_g + ci) * k;
-                for (int j = 0; j < k; ++j) {
-                    const float wv = wr[j];
-                    const int off = j * dil - pad; /* x index = t + off */
-                    int t0 = off < 0 ? -off : 0;
-                    int t1 = T - off < Tout ? T - off : Tout;
-                    for (int t = t0; t < t1; ++t) yr[t] += wv * xr[t + off];
+            /* time-blocked so the output block stays in L1 while all (ci, tap) pairs stream over it */
+            for (int tb = 0; tb < Tout; tb += 2048) {
+                const int te = tb + 2048 < Tout ? tb + 2048 : Tout;
+                for (int ci = 0; ci < cin_g; ++ci) {
+                    const float* xr = x + ((int64_t)b * Cin + g * cin_g + ci) * T;
+                    const float* wr = w + ((int64_t)co * cin_g + ci) * k;
+                    for (int j = 0; j < k; ++j) {
+                        const float wv = wr[j];
+                        const int off = j * dil - pad; /* x index = t + off */
+                        int t0 = off < 0 ? -off : 0;
+                        int t1 = T - off < Tout ? T - off : Tout;
+                        if (t0 < tb) t0 = tb;
+                        if (t1 > te) t1 = te;
+                        float* restrict yo = yr;
+                        const float* restrict xo = xr + off;
+#pragma omp simd
+                        for (int t = t0; t < t1; ++t) yo[t] += wv * xo[t];
+                    }
                 }
             }
         }

@@ -1,0 +1,85 @@
+"""GPU: the drop-in nn.Module classes (what a fish_vocoder user touches) end to end: Hydra-style config ->
+instantiate -> load_state_dict(strict) -> .eval().to('cuda') -> forward(mel) -> waveform, against the reference goldens."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from vocoder_amd import config, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+TOL = 1e-4
+
+
+def _t(sd):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def test_hifigan_module_from_config_matches_reference_golden():
+    g = load_golden("hifigan_v1_t12.npz")
+    gen, cfg = config.build_generator("hifigan", overrides={"num_mels": 80})
+    gen.load_state_dict(_t(syn.hifigan_state_dict(g["cfg"], g["seed"])), strict=True)
+    gen = gen.eval().to("cuda:0")
+    y = gen(torch.from_numpy(g["mel"]).cuda())
+    assert y.shape == (1, 1, 12 * 512) and y.device.type == "cuda"
+    assert np.abs(y.cpu().numpy() - g["out"]).max() <= TOL
+    # GANModel.forward contract (gan.py:282-288)
+    from vocoder_amd.inference import InferenceModel
+    out, zero = InferenceModel(gen)(None, None, input_spec=torch.from_numpy(g["mel"]).cuda())
+    assert zero == 0 and torch.equal(out, y)
+    # reloading other weights rebuilds the engine
+    gen.load_state_dict(_t(syn.hifigan_state_dict(g["cfg"], g["seed"] + 1)), strict=True)
+    y2 = gen(torch.from_numpy(g["mel"]).cuda())
+    assert not torch.allclose(y, y2)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        gen.train()(torch.from_numpy(g["mel"]).cuda())
+
+
+def test_bigvgan_and_vocos_and_firefly_modules():
+    from vocoder_amd.modules.encoders import ConvNeXtEncoder
+    from vocoder_amd.modules.generators import BigVGANGenerator, HiFiGANGenerator, ISTFTHead, UnifyGenerator
+    g = load_golden("bigvgan_tiny.npz")
+    m = BigVGANGenerator(**g["cfg"])
+    inc = m.load_state_dict(_t(syn.bigvgan_state_dict(g["cfg"], g["seed"])), strict=False)
+    assert not inc.unexpected_keys and all(k.endswith("filter") for k in inc.missing_keys)
+    y = m.eval().cuda()(torch.from_numpy(g["mel"]).cuda())
+    assert np.abs(y.cpu().numpy() - g["out"]).max() <= TOL
+
+    g = load_golden("vocos_tiny.npz")
+    u = UnifyGenerator(ConvNeXtEncoder(**g["cfg"]["backbone"]), ISTFTHead(**g["cfg"]["head"]))
+    u.load_state_dict(_t(syn.vocos_state_dict(g["cfg"], g["seed"])), strict=True)
+    y = u.eval().cuda()(torch.from_numpy(g["mel"]).cuda())
+    assert y.shape == g["out"].shape
+    assert np.abs(y.cpu().numpy() - g["out"]).max() <= TOL
+
+    # Firefly-GAN composition (f3): ConvNeXt backbone -> HiFiGAN head with k=13 pre/post convs, vs the oracle
+    from oracle import oracle as orc
+    cfg = dict(backbone=dict(input_channels=20, depths=[1, 1], dims=[32, 64], kernel_size=7),
+               head=dict(hop_length=16, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4],
+                         resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=64,
+                         upsample_initial_channel=64, use_template=False, pre_conv_kernel_size=13,
+                         post_conv_kernel_size=13))
+    sd = syn.firefly_state_dict(cfg, 4)
+    f = UnifyGenerator(ConvNeXtEncoder(**cfg["backbone"]), HiFiGANGenerator(**cfg["head"]))
+    f.load_state_dict(_t(sd), strict=True)
+    mel = syn.synthetic_mel(2, 20, 9, 3)
+    y = f.eval().cuda()(torch.from_numpy(mel).cuda()).cpu().numpy()
+    assert np.abs(y - orc.firefly_forward(sd, cfg, mel)).max() <= TOL
+
+
+def test_fused_firefly_and_vocos_engine_kinds_match_module_chain():
+    """FV_MODEL_VOCOS / FV_MODEL_FIREFLY run backbone+head inside one fv_forward; must equal the two-engine chain."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config, upsampler_config
+    cfg = dict(backbone=dict(input_channels=20, depths=[1, 1], dims=[32, 64], kernel_size=7),
+               head=dict(hop_length=16, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4],
+                         resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=64,
+                         upsample_initial_channel=64, use_template=False, pre_conv_kernel_size=13,
+                         post_conv_kernel_size=13))
+    sd = syn.firefly_state_dict(cfg, 4)
+    from oracle import oracle as orc
+    mel = syn.synthetic_mel(2, 20, 9, 3)
+    eng = Engine(_lib.FV_MODEL_FIREFLY, backbone=convnext_config(**cfg["backbone"]), ups=upsampler_config(**cfg["head"]),
+                 state_dict=sd)
+    y = eng(torch.from_numpy(mel).cuda()).cpu().numpy()
+    assert np.abs(y - orc.firefly_forward(sd, cfg, mel)).max() <= TOL

@@ -1,0 +1,161 @@
+"""CPU: host-side logic — C-ABI exports, config resolver, drop-in module key parity, sharding (gloo, world_size 2)."""
+import ctypes
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from vocoder_amd import _lib, config, synthetic as syn
+from vocoder_amd.sharding import shard_sizes, shard_slice
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "fishvoc.h")).read()
+    declared = set(re.findall(r"FV_API\s+[\w\s\*]+?\b(fv_\w+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    L = _lib.lib()      # loads without a GPU (no compute calls here)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.fv_abi_version() == _lib.FV_ABI_VERSION
+
+
+def test_config_struct_layout_matches_header():
+    # int32 fields only, so sizeof is a good canary for drift between fishvoc.h and the ctypes mirror
+    assert ctypes.sizeof(_lib.UpsamplerConfig) == 4 * (2 + 8 + 8 + 1 + 8 + 24 + 5)
+    assert ctypes.sizeof(_lib.ConvNeXtConfig) == 4 * (2 + 8 + 8 + 1)
+    assert ctypes.sizeof(_lib.IstftHeadConfig) == 16
+    assert ctypes.sizeof(_lib.ConvDesc) == 40
+
+
+def test_fv_create_validation_without_gpu():
+    """Config validation (the reference's ctor asserts) happens before any device work."""
+    from vocoder_amd.engine import upsampler_config
+    L = _lib.lib()
+    cfg = _lib.Config()
+    cfg.abi_version = _lib.FV_ABI_VERSION
+    cfg.model = _lib.FV_MODEL_HIFIGAN
+    cfg.ups = upsampler_config(**dict(syn.HIFIGAN_V1_44K, hop_length=511))
+    h = ctypes.c_void_p()
+    assert L.fv_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"hop_length must be 512" in L.fv_last_error()
+    cfg.ups = upsampler_config(**dict(syn.HIFIGAN_V1_44K, use_template=True))
+    assert L.fv_create(ctypes.byref(cfg), ctypes.byref(h)) == -2
+    cfg.abi_version = 99
+    assert L.fv_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+
+
+def test_config_compose_and_instantiate():
+    gen, cfg = config.build_generator("hifigan", overrides={"num_mels": 80})
+    g = cfg["model"]["generator"]
+    assert g["hop_length"] == 512 and g["num_mels"] == 80 and g["use_template"] is False
+    assert type(gen).__name__ == "HiFiGANGenerator"
+    assert config._resolve_str("${eval: '${model.hop_length} * 32'}", {"model": {"hop_length": 512}}) == 16384
+    v, _ = config.build_generator("vocos", "24000_256_1024")
+    assert type(v.backbone).__name__ == "ConvNeXtEncoder" and v.head.n_fft == 1024
+    with pytest.raises(AssertionError, match="hop_length must be 512"):
+        config.build_generator("hifigan", overrides={"hop_length": 256})
+
+
+def test_reference_target_strings_resolve_to_dropins():
+    cls = config.locate("fish_vocoder.modules.generators.hifigan.HiFiGANGenerator")
+    assert cls.__module__ == "vocoder_amd.modules.generators.hifigan"
+    assert config.locate("fish_vocoder.modules.encoders.convnext.ConvNeXtEncoder").__module__.startswith("vocoder_amd")
+
+
+def test_dropin_state_dict_keys_and_strict_load():
+    from vocoder_amd.modules.generators import BigVGANGenerator, HiFiGANGenerator
+    cfg = dict(hop_length=16, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4],
+               resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=20,
+               upsample_initial_channel=64, use_template=False)
+    gen = HiFiGANGenerator(**cfg)
+    sd = syn.hifigan_state_dict(cfg, 3)
+    assert list(gen.state_dict().keys()) == list(sd.keys())      # reference order, reference names
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    with pytest.raises(RuntimeError):
+        gen.load_state_dict({k: torch.from_numpy(v) for k, v in list(sd.items())[1:]}, strict=True)
+    with pytest.raises(NotImplementedError):
+        HiFiGANGenerator(**dict(cfg, use_template=True))
+    with pytest.raises(AssertionError):
+        HiFiGANGenerator(**dict(cfg, hop_length=15))
+    # no CPU fallback: a CPU tensor must fail loudly, never compute
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gen.eval()(torch.zeros(1, 20, 4))
+    assert gen.remove_parametrizations() is None
+    big = BigVGANGenerator(**cfg)
+    keys = set(big.state_dict().keys())
+    bsd = syn.bigvgan_state_dict(cfg, 1)
+    assert set(bsd) <= keys and all(k.endswith("filter") for k in keys - set(bsd))
+
+
+def test_lightning_checkpoint_prefix_and_mel_preparation(tmp_path):
+    from vocoder_amd.inference import InferenceModel, load_generator_state_dict, prepare_mel, write_wav
+    sd = {"generator.conv_pre.bias": torch.zeros(4), "discriminators.x": torch.zeros(1)}
+    assert list(load_generator_state_dict({"state_dict": sd})) == ["conv_pre.bias"]
+    assert prepare_mel(torch.zeros(50, 80), 80).shape == (1, 80, 50)
+    assert prepare_mel(torch.zeros(2, 80, 50), 80).shape == (2, 80, 50)
+    write_wav(tmp_path / "a.wav", np.zeros((100, 1), np.float32), 44100)
+    assert (tmp_path / "a.wav").stat().st_size == 44 + 200
+    with pytest.raises(NotImplementedError):
+        InferenceModel(torch.nn.Identity())(torch.zeros(1, 1, 8))
+
+
+def test_shard_slices_cover_batch_exactly():
+    for batch, world in [(256, 8), (5, 8), (0, 2), (33, 4), (1, 1)]:
+        sizes = shard_sizes(batch, world)
+        assert sum(sizes) == batch and max(sizes) - min(sizes) <= 1
+        covered = [i for r in range(world) for i in range(batch)[shard_slice(batch, world, r)]]
+        assert covered == list(range(batch))
+    with pytest.raises(ValueError):
+        shard_slice(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from vocoder_amd.sharding import broadcast_state_dict, gather_batch, scatter_batch
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = dict(hop_length=4, upsample_rates=[2, 2], upsample_kernel_sizes=[4, 4], resblock_kernel_sizes=[3],
+                   resblock_dilation_sizes=[[1, 3, 5]], num_mels=6, upsample_initial_channel=8, use_template=False)
+        sd = syn.hifigan_state_dict(cfg, 5) if rank == 0 else None
+        got = broadcast_state_dict(sd, src=0)
+        ref = syn.hifigan_state_dict(cfg, 5)
+        same = list(got) == list(ref) and all(np.array_equal(got[k].numpy(), ref[k]) for k in ref)
+        batch = 5   # ragged: ranks get 3 and 2 clips
+        full = torch.arange(batch * 6 * 7, dtype=torch.float32).reshape(batch, 6, 7) if rank == 0 else None
+        mine = scatter_batch(full, batch, (6, 7), src=0)
+        out = gather_batch(mine * 2.0, batch, dst=0)   # stand-in for the per-rank forward
+        ok = same and mine.shape[0] == (3 if rank == 0 else 2)
+        if rank == 0:
+            ok = ok and torch.equal(out, full * 2.0)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weight_broadcast_scatter_gather_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

@@ -182,6 +182,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
             default: return launch_conv_misc(p, c, r.batch, stream);
         }
     };
+    const int prof_idx = prof_begin(stream);
     ok = try_launch(cfg);
     if (!ok) {
         specialised = false;
@@ -202,6 +203,17 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     std::snprintf(name, sizeof(name), "conv_mfma<%s k=%d d=%d tile=%s>", specialised ? "spec" : "generic", L.ks, L.dil,
                   kTileNames[cfg]);
     set_last_kernel(name);
+    if (prof_idx >= 0) {
+        // algorithmic work of this launch: dense MACs of the layer; per-layer compulsory bytes (input once, output once,
+        // residual / accumulate operand once, packed weights once)
+        const double macs = (double)L.c_in * L.c_out * L.k * (L.transposed ? (double)r.t_in : (double)tout) * r.batch;
+        double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
+        if (r.res) elems += (double)L.c_out * tout;
+        if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
+        char lbl[160];
+        std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d%s", name, L.c_in, L.c_out, L.transposed ? " convT" : "");
+        prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
+    }
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
 }

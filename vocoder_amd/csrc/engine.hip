@@ -33,6 +33,33 @@ void set_error(const char* fmt, ...) {
 }
 void set_last_kernel(const char* name) { g_kernel = name; }
 
+static thread_local Profiler* g_prof = nullptr;
+Profiler* current_profiler() { return g_prof; }
+int prof_begin(hipStream_t s) {
+    if (!g_prof) return -1;
+    ProfRec r;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+    (void)hipEventRecord(r.e0, s);
+    g_prof->recs.push_back(r);
+    return (int)g_prof->recs.size() - 1;
+}
+void prof_end(hipStream_t s, int idx, const char* label, double flops, double bytes) {
+    if (!g_prof || idx < 0) return;
+    ProfRec& r = g_prof->recs[idx];
+    (void)hipEventRecord(r.e1, s);
+    r.label = label;
+    r.flops = flops;
+    r.bytes = bytes;
+}
+// wraps a small-kernel launch expression with the profiler
+#define FV_PROF(stream, label, flops, bytes, call)                      \
+    do {                                                                \
+        const int _pi = prof_begin(stream);                             \
+        fv_status _st = (call);                                         \
+        if (_pi >= 0) prof_end(stream, _pi, label, flops, bytes);       \
+        if (_st) return _st;                                            \
+    } while (0)
+
 struct HostTensor {
     std::vector<float> data;
     std::vector<int64_t> shape;
@@ -222,6 +249,8 @@ struct fv_engine {
     ConvNeXtModel cnx;
     IstftHeadModel head;
     bool has_ups = false, has_cnx = false, has_head = false;
+    Profiler prof;
+    bool profiling = false;
 
     // ---- weight lookup helpers (reference state-dict names) ----
     const HostTensor* find(const std::string& name) {
@@ -543,9 +572,9 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 const bool last = n == FV_MAX_DILATIONS - 1;
                 const float* c1_in = src;
                 if (ups.bigvgan) {
-                    if ((st = launch_aa_snake(src, XA, br.act[2 * n].d_alpha, br.act[2 * n].d_inv_beta, br.act[2 * n].d_up,
-                                              br.act[2 * n].d_down, B, ch, t, s)))
-                        return st;
+                    FV_PROF(s, "aa_snake", 60.0 * B * ch * t, 8.0 * B * ch * t,
+                            launch_aa_snake(src, XA, br.act[2 * n].d_alpha, br.act[2 * n].d_inv_beta, br.act[2 * n].d_up,
+                                            br.act[2 * n].d_down, B, ch, t, s));
                     c1_in = XA;
                 }
                 // xt = c1(act(x)); the second activation is fused into c1's epilogue for SiLU
@@ -559,9 +588,9 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 if ((st = conv_layer_run(br.c1[n], r, s))) return st;
                 const float* c2_in = XT;
                 if (ups.bigvgan) {
-                    if ((st = launch_aa_snake(XT, XA, br.act[2 * n + 1].d_alpha, br.act[2 * n + 1].d_inv_beta,
-                                              br.act[2 * n + 1].d_up, br.act[2 * n + 1].d_down, B, ch, t, s)))
-                        return st;
+                    FV_PROF(s, "aa_snake", 60.0 * B * ch * t, 8.0 * B * ch * t,
+                            launch_aa_snake(XT, XA, br.act[2 * n + 1].d_alpha, br.act[2 * n + 1].d_inv_beta,
+                                            br.act[2 * n + 1].d_up, br.act[2 * n + 1].d_down, B, ch, t, s));
                     c2_in = XA;
                 }
                 // x = c2(act(xt)) + x ; the last pair of each branch accumulates the branch mean into Y
@@ -587,15 +616,17 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
     const float* post_in = cur;
     int pre = FV_ACT_SILU;
     if (ups.bigvgan) {
-        if ((st = launch_aa_snake(cur, XA, ups.act_post.d_alpha, ups.act_post.d_inv_beta, ups.act_post.d_up,
-                                  ups.act_post.d_down, B, ups.post_cin, t, s)))
-            return st;
+        FV_PROF(s, "aa_snake", 60.0 * B * ups.post_cin * t, 8.0 * B * ups.post_cin * t,
+                launch_aa_snake(cur, XA, ups.act_post.d_alpha, ups.act_post.d_inv_beta, ups.act_post.d_up,
+                                ups.act_post.d_down, B, ups.post_cin, t, s));
         post_in = XA;
         pre = FV_ACT_NONE;
     }
     const int qk = ups.cfg.post_conv_kernel_size;
-    return launch_conv_narrow(post_in, ups.d_wpost, ups.d_bpost, d_out, B, ups.post_cin, t, 1, qk, get_padding(qk), pre,
-                              FV_ACT_TANH, 0.f, s);
+    FV_PROF(s, "conv_post_narrow", 2.0 * B * ups.post_cin * qk * t, 4.0 * B * (ups.post_cin + 1) * t,
+            launch_conv_narrow(post_in, ups.d_wpost, ups.d_bpost, d_out, B, ups.post_cin, t, 1, qk, get_padding(qk), pre,
+                               FV_ACT_TANH, 0.f, s));
+    return FV_OK;
 }
 
 fv_status fv_engine::run_convnext(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s) {
@@ -616,10 +647,11 @@ fv_status fv_engine::run_convnext(const float* d_in, float* d_out, int B, int T,
             r.x = d_in;
             r.y = H;
             if ((st = conv_layer_run(stg.conv, r, s))) return st;
-            if ((st = launch_dwconv_ln(H, nullptr, nullptr, stg.d_ln_w, stg.d_ln_b, X, B, dim, T, 1, 1e-6f, s))) return st;
+            FV_PROF(s, "layernorm_cf", 8.0 * B * dim * T, 8.0 * B * dim * T,
+                    launch_dwconv_ln(H, nullptr, nullptr, stg.d_ln_w, stg.d_ln_b, X, B, dim, T, 1, 1e-6f, s));
         } else {
-            if ((st = launch_dwconv_ln(X, nullptr, nullptr, stg.d_ln_w, stg.d_ln_b, H, B, stg.ln_dim, T, 1, 1e-6f, s)))
-                return st;
+            FV_PROF(s, "layernorm_cf", 8.0 * B * stg.ln_dim * T, 8.0 * B * stg.ln_dim * T,
+                    launch_dwconv_ln(X, nullptr, nullptr, stg.d_ln_w, stg.d_ln_b, H, B, stg.ln_dim, T, 1, 1e-6f, s));
             r = ConvRun();
             r.batch = B;
             r.t_in = T;
@@ -630,8 +662,8 @@ fv_status fv_engine::run_convnext(const float* d_in, float* d_out, int B, int T,
         for (auto& bp : stg.blocks) {
             CnxBlock& blk = *bp;
             // dwconv -> LN (convnext.py:126-129)
-            if ((st = launch_dwconv_ln(X, blk.d_dw_w, blk.d_dw_b, blk.d_ln_w, blk.d_ln_b, H, B, dim, T, ks, 1e-6f, s)))
-                return st;
+            FV_PROF(s, "dwconv_ln", (2.0 * ks + 8.0) * B * dim * T, 8.0 * B * dim * T,
+                    launch_dwconv_ln(X, blk.d_dw_w, blk.d_dw_b, blk.d_ln_w, blk.d_ln_b, H, B, dim, T, ks, 1e-6f, s));
             // pwconv1 + GELU (convnext.py:130-131)
             r = ConvRun();
             r.batch = B;
@@ -651,7 +683,9 @@ fv_status fv_engine::run_convnext(const float* d_in, float* d_out, int B, int T,
             if ((st = conv_layer_run(blk.pw2, r, s))) return st;
         }
     }
-    return launch_dwconv_ln(X, nullptr, nullptr, cnx.d_norm_w, cnx.d_norm_b, d_out, B, cnx.out_dim(), T, 1, 1e-6f, s);
+    FV_PROF(s, "layernorm_cf", 8.0 * B * cnx.out_dim() * T, 8.0 * B * cnx.out_dim() * T,
+            launch_dwconv_ln(X, nullptr, nullptr, cnx.d_norm_w, cnx.d_norm_b, d_out, B, cnx.out_dim(), T, 1, 1e-6f, s));
+    return FV_OK;
 }
 
 fv_status fv_engine::run_head(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s) {
@@ -669,7 +703,7 @@ fv_status fv_engine::run_head(const float* d_in, float* d_out, int B, int T, flo
     r.y = Hh;
     if ((st = conv_layer_run(head.out, r, s))) return st;
     // Hh is already compacted to 2*nb rows: reuse the spec kernel with n_fft' = nb (rows [0,nb) mag, [nb,2nb) phase)
-    if ((st = launch_istft_spec(Hh, Sp, B, nb, T, nb, nb, s))) return st;
+    FV_PROF(s, "istft_spec", 30.0 * B * nb * T, 16.0 * B * nb * T, launch_istft_spec(Hh, Sp, B, nb, T, nb, nb, s));
     r = ConvRun();
     r.batch = B;
     r.t_in = T;
@@ -677,7 +711,9 @@ fv_status fv_engine::run_head(const float* d_in, float* d_out, int B, int T, flo
     r.y = Fr;
     if ((st = conv_layer_run(head.idft, r, s))) return st;
     const int pad = (head.cfg.win_length - head.cfg.hop_length) / 2;
-    return launch_istft_ola(Fr, head.d_win2, d_out, B, N, T, head.cfg.hop_length, pad, s);
+    FV_PROF(s, "istft_ola", 2.0 * B * N * T, 4.0 * B * (N * (double)T + (double)T * head.cfg.hop_length),
+            launch_istft_ola(Fr, head.d_win2, d_out, B, N, T, head.cfg.hop_length, pad, s));
+    return FV_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -916,6 +952,10 @@ FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32
     }
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)d_workspace;
+    struct ProfGuard {
+        ProfGuard(fv_engine* e) { g_prof = e->profiling ? &e->prof : nullptr; }
+        ~ProfGuard() { g_prof = nullptr; }
+    } guard(e);
     switch (e->cfg.model) {
         case FV_MODEL_HIFIGAN:
         case FV_MODEL_BIGVGAN: return e->run_upsampler(d_in, d_out, batch, t_in, ws, s);
@@ -936,6 +976,70 @@ FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32
     }
     set_error("fv_forward: unknown model");
     return FV_ERR_INVALID;
+}
+
+// ---- per-launch profile ----
+FV_API fv_status fv_profile_begin(fv_engine* e) {
+    if (!e) {
+        set_error("fv_profile_begin: null engine");
+        return FV_ERR_INVALID;
+    }
+    for (auto& r : e->prof.recs) {
+        if (r.e0) (void)hipEventDestroy(r.e0);
+        if (r.e1) (void)hipEventDestroy(r.e1);
+    }
+    e->prof.recs.clear();
+    e->profiling = true;
+    return FV_OK;
+}
+
+FV_API fv_status fv_profile_end(fv_engine* e, char* json_buf, size_t cap, size_t* needed) {
+    if (!e) {
+        set_error("fv_profile_end: null engine");
+        return FV_ERR_INVALID;
+    }
+    e->profiling = false;
+    struct Agg {
+        int count = 0;
+        double ms = 0, flops = 0, bytes = 0;
+    };
+    std::map<std::string, Agg> agg;
+    std::vector<std::string> order;
+    for (auto& r : e->prof.recs) {
+        if (!r.e0 || !r.e1) continue;
+        FV_HIP_CHECK(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        FV_HIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        if (!agg.count(r.label)) order.push_back(r.label);
+        Agg& a = agg[r.label];
+        a.count++;
+        a.ms += ms;
+        a.flops += r.flops;
+        a.bytes += r.bytes;
+    }
+    std::string js = "[";
+    for (size_t i = 0; i < order.size(); ++i) {
+        const Agg& a = agg[order[i]];
+        char buf[512];
+        std::snprintf(buf, sizeof(buf),
+                      "%s{\"kernel\": \"%s\", \"launches\": %d, \"total_ms\": %.6f, \"avg_ms\": %.6f, "
+                      "\"flops_per_launch\": %.1f, \"bytes_per_launch\": %.1f}",
+                      i ? ", " : "", order[i].c_str(), a.count, a.ms, a.ms / a.count, a.flops / a.count, a.bytes / a.count);
+        js += buf;
+    }
+    js += "]";
+    for (auto& r : e->prof.recs) {
+        if (r.e0) (void)hipEventDestroy(r.e0);
+        if (r.e1) (void)hipEventDestroy(r.e1);
+    }
+    e->prof.recs.clear();
+    if (needed) *needed = js.size() + 1;
+    if (json_buf && cap > 0) {
+        const size_t n = std::min(cap - 1, js.size());
+        std::memcpy(json_buf, js.data(), n);
+        json_buf[n] = 0;
+    }
+    return FV_OK;
 }
 
 // ---- single conv layer ----

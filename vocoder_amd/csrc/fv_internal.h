@@ -17,6 +17,20 @@ namespace fv {
 void set_error(const char* fmt, ...);
 void set_last_kernel(const char* name);
 
+// Optional per-launch timing (fv_profile_begin / fv_profile_end): hipEvents recorded on the launch stream around every
+// kernel of a forward, aggregated by label together with the launch's ALGORITHMIC flops and bytes.
+struct ProfRec {
+    std::string label;
+    double flops = 0, bytes = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+struct Profiler {
+    std::vector<ProfRec> recs;
+};
+Profiler* current_profiler();              // thread-local; nullptr when profiling is off
+int prof_begin(hipStream_t s);             // returns record index or -1
+void prof_end(hipStream_t s, int idx, const char* label, double flops, double bytes);
+
 #define FV_HIP_CHECK(expr)                                                                       \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \

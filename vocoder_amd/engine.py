@@ -148,6 +148,19 @@ class Engine:
 
     __call__ = forward
 
+    def profile(self, x: torch.Tensor, repeats: int = 3) -> list[dict]:
+        """Per-kernel hipEvent timings of `repeats` forwards (fv_profile_begin/end): a list of
+        {kernel, launches, total_ms, avg_ms, flops_per_launch, bytes_per_launch}."""
+        import json
+        check(self._lib.fv_profile_begin(self._h))
+        for _ in range(repeats):
+            self.forward(x)
+        torch.cuda.synchronize(x.device)
+        need = ctypes.c_size_t(0)
+        buf = ctypes.create_string_buffer(1 << 20)
+        check(self._lib.fv_profile_end(self._h, buf, len(buf), ctypes.byref(need)))
+        return json.loads(buf.value.decode())
+
 
 class FusedConv:
     """One fused conv layer (``fv_conv``): pre-act -> Conv1d/ConvTranspose1d -> bias [+res] -> post-act."""

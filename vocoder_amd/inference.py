@@ -1,0 +1,124 @@
+"""Inference wrapper with the contract of the reference's task model + test CLI.
+
+* ``InferenceModel.forward(audio, mask=None, input_spec=None) -> (fake_audio, 0)`` is what
+  ``GANModel.forward`` promises ``test.py:89`` (reference models/gan.py:282-288).  Only the ``input_spec`` branch is in
+  scope: the mel front-end (``mel_transforms``) is a "next" row.
+* ``load_generator_state_dict`` accepts a raw generator state dict or a Lightning checkpoint
+  (``{"state_dict": {"generator.<key>": ...}}``, test.py:32-37).
+* ``main`` mirrors the ``.pt``/``.pth`` mel branch of test.py:73-99: add a batch dim to 2-D mels, transpose when the last
+  dim is ``num_mels``, write ``(B, 1, T)`` -> wav.
+"""
+from __future__ import annotations
+
+import argparse
+import time
+import wave
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import config as fvconfig
+
+
+class InferenceModel(nn.Module):
+    def __init__(self, generator: nn.Module, sampling_rate: int = 44100, num_mels: int = 128, hop_length: int = 512):
+        super().__init__()
+        self.generator = generator
+        self.sampling_rate, self.num_mels, self.hop_length = sampling_rate, num_mels, hop_length
+
+    @property
+    def device(self):
+        return next(self.generator.parameters()).device
+
+    def forward(self, audio, mask=None, input_spec=None):
+        if input_spec is None:
+            raise NotImplementedError(
+                "wave -> mel (mel_transforms.input, gan.py:284) is outside the generator hot path; pass input_spec=")
+        return self.generator(input_spec), 0
+
+
+def load_generator_state_dict(ckpt) -> dict:
+    """Raw state dict, or Lightning checkpoint with the ``generator.`` prefix (other prefixes — discriminators,
+    mel_transforms — are dropped, they are not part of the generator)."""
+    if isinstance(ckpt, (str, Path)):
+        ckpt = torch.load(ckpt, map_location="cpu", weights_only=True)
+    if "state_dict" in ckpt:
+        ckpt = ckpt["state_dict"]
+    if any(k.startswith("generator.") for k in ckpt):
+        ckpt = {k[len("generator."):]: v for k, v in ckpt.items() if k.startswith("generator.")}
+    return dict(ckpt)
+
+
+def prepare_mel(mel: torch.Tensor, num_mels: int) -> torch.Tensor:
+    """test.py:78-82: (T, M) or (M, T) or batched; returns (B, num_mels, T) float32."""
+    mel = mel.to(torch.float32)
+    if mel.dim() == 2:
+        mel = mel[None]
+    if mel.shape[-1] == num_mels:
+        mel = mel.transpose(1, 2)
+    return mel.contiguous()
+
+
+def diffsinger_mel_to_ln(mel: torch.Tensor) -> torch.Tensor:
+    """DiffSinger log10 mels -> the natural-log convention of the generators (scripts/convert_diffsinger_mel.py:9-17)."""
+    return mel / 0.434294
+
+
+def write_wav(path, audio: np.ndarray, sampling_rate: int) -> None:
+    """audio: (T,) or (T, C) float in [-1, 1] -> 16-bit PCM (soundfile is not available here)."""
+    a = np.asarray(audio, dtype=np.float32)
+    if a.ndim == 1:
+        a = a[:, None]
+    pcm = (np.clip(a, -1.0, 1.0) * 32767.0).round().astype("<i2")
+    Path(path).parent.mkdir(parents=True, exist_ok=True)
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(pcm.shape[1])
+        w.setsampwidth(2)
+        w.setframerate(int(sampling_rate))
+        w.writeframes(pcm.tobytes())
+
+
+def build_model(generator="hifigan", resolution="44100_512_2048", overrides=None, config_root=None,
+                ckpt_path=None, device="cuda") -> InferenceModel:
+    gen, cfg = fvconfig.build_generator(generator, resolution, overrides, config_root)
+    if ckpt_path is not None:
+        gen.load_state_dict(load_generator_state_dict(ckpt_path), strict=True)
+    m = cfg["model"]
+    model = InferenceModel(gen, m["sampling_rate"], m["num_mels"], m["hop_length"])
+    return model.eval().to(device)
+
+
+@torch.no_grad()
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="mel (.pt) -> wav on the MI355X engine (mirrors fish_vocoder/test.py)")
+    ap.add_argument("--generator", default="hifigan")
+    ap.add_argument("--resolution", default="44100_512_2048")
+    ap.add_argument("--config-root", default=None, help="use another configs/ tree (e.g. the reference's)")
+    ap.add_argument("--ckpt-path", required=True)
+    ap.add_argument("--input-path", required=True)
+    ap.add_argument("--output-path", required=True)
+    ap.add_argument("--num-mels", type=int, default=None)
+    ap.add_argument("--diffsinger", action="store_true", help="inputs are log10 mels")
+    a = ap.parse_args(argv)
+    model = build_model(a.generator, a.resolution, {"num_mels": a.num_mels} if a.num_mels else None, a.config_root,
+                        a.ckpt_path)
+    inp = Path(a.input_path)
+    files = [inp] if inp.is_file() else sorted(p for p in inp.rglob("*") if p.suffix in (".pt", ".pth"))
+    base = inp.parent if inp.is_file() else inp
+    for f in files:
+        mel = torch.load(f, map_location="cpu", weights_only=True)
+        if a.diffsinger:
+            mel = diffsinger_mel_to_ln(mel)
+        mel = prepare_mel(mel, model.num_mels).to(model.device)
+        t0 = time.time()
+        fake = model(None, None, input_spec=mel)[0]
+        torch.cuda.synchronize()
+        print(f"{f}: {fake.shape[-1] / model.sampling_rate:.2f}s of audio in {time.time() - t0:.4f}s")
+        out = Path(a.output_path) / f.relative_to(base).with_suffix(".wav")
+        write_wav(out, fake.squeeze(1).cpu().numpy().T, model.sampling_rate)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+"""Shared plumbing of the drop-in generator modules.
+
+A drop-in module is an ``nn.Module`` whose *parameters* are ordinary torch parameters registered under the reference's
+names (so ``load_state_dict(strict=True)``, ``.to(device)``, ``.eval()``, ``state_dict()`` behave exactly like the
+reference's — test.py:32-38), but whose ``forward`` hands the tensors to the HIP engine.  The parameter-holding
+submodules are never called.  The engine is (re)built lazily from ``state_dict()`` whenever the weights may have
+changed (load_state_dict, ``_apply``: ``.to()/.cuda()/.float()``).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+
+class EngineModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        object.__setattr__(self, "_engine", None)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_engine())
+
+    # -- subclasses implement -------------------------------------------------------------
+    def _make_engine(self, state_dict):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    # -- engine cache ----------------------------------------------------------------------
+    def invalidate_engine(self) -> None:
+        eng = self.__dict__.get("_engine")
+        if eng is not None:
+            eng.close()
+        object.__setattr__(self, "_engine", None)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_engine()
+        return super()._apply(fn, *args, **kwargs)
+
+    def engine(self, device):
+        eng = self.__dict__.get("_engine")
+        if eng is None or eng.device != device:
+            self.invalidate_engine()
+            with torch.cuda.device(device):
+                eng = self._make_engine({k: v for k, v in self.state_dict().items()})
+            object.__setattr__(self, "_engine", eng)
+        return eng
+
+    def _run(self, x: torch.Tensor) -> torch.Tensor:
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise RuntimeError(
+                f"{type(self).__name__}.forward needs a CUDA/HIP tensor (got "
+                f"{getattr(x, 'device', type(x))}); vocoder_amd has no CPU path — move the model and input to the GPU")
+        if self.training:
+            raise RuntimeError(f"{type(self).__name__} is inference-only: call .eval() first")
+        with torch.no_grad():
+            return self.engine(x.device)(x.to(torch.float32))
+
+    def remove_parametrizations(self):
+        """Kept for API compatibility (hifigan.py:251).  Weight-norm is folded inside the engine at load time, so this
+        is a no-op; unlike the reference's version (which raises TypeError) it is harmless."""
+        return None
+
+    def extra_repr(self) -> str:
+        return "backend=libfishvoc_hip (gfx950)"
