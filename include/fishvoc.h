@@ -173,6 +173,11 @@ FV_API int64_t fv_conv_output_length(const fv_conv* c, int32_t t_in);
 /* y = post_act(conv(pre_act(x)) + bias [+ d_residual]); d_residual may be NULL or alias d_y. */
 FV_API fv_status fv_conv_forward(fv_conv* c, const float* d_x, float* d_y, const float* d_residual, int32_t batch,
                           int32_t t_in, void* stream);
+/* One ResBlock1 iteration in a single launch: y = x + c2(silu(c1(silu(x)))) (hifigan.py:102-107).  c1 is the dilated
+ * conv, c2 the dilation-1 conv; both C -> C with the same odd kernel size and 'same' padding, C in {16, 32},
+ * k in {3, 7, 11}, dilation in {1, 3, 5} (else FV_ERR_UNSUPPORTED).  d_y must not alias d_x. */
+FV_API fv_status fv_conv_pair_forward(fv_conv* c1, fv_conv* c2, const float* d_x, float* d_y, int32_t batch, int32_t t,
+                                      void* stream);
 FV_API void fv_conv_destroy(fv_conv* c);
 
 /* -------- per-launch timing (measurement aid; bench.py's roofline leg) --------

@@ -141,3 +141,37 @@ def test_errors_are_reported():
         conv(torch.zeros(1, 5, 8, device=_dev()))
     with pytest.raises(FishVocError):
         FusedConv(np.zeros((4, 4, 3), np.float32), None, padding=-1)
+
+
+PAIR_CASES = [
+    # (C, k, d, B, T) — T chosen to hit: several tiles, a ragged last tile, T smaller than one tile, T == 1
+    (16, 3, 1, 2, 2100), (16, 7, 3, 1, 1030), (16, 11, 5, 2, 700), (16, 11, 1, 1, 502), (16, 3, 5, 1, 1),
+    (32, 3, 3, 2, 1000), (32, 7, 5, 1, 517), (32, 11, 1, 2, 300), (32, 11, 5, 1, 247), (32, 7, 1, 1, 5),
+]
+
+
+@pytest.mark.parametrize("C,k,d,B,T", PAIR_CASES)
+def test_fused_resblock_pair_matches_oracle(C, k, d, B, T):
+    """y = x + c2(silu(c1(silu(x)))) — one ResBlock1 iteration (reference hifigan.py:102-107) in one launch."""
+    from vocoder_amd.engine import FusedConv
+    rng = np.random.default_rng(C * 100 + k * 10 + d)
+    x = rng.normal(size=(B, C, T)).astype(np.float32)
+    w1 = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    w2 = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    b1 = rng.normal(size=C).astype(np.float32)
+    b2 = rng.normal(size=C).astype(np.float32)
+    xt = orc.conv1d(orc.silu(x), w1, b1, dilation=d, padding=(k * d - d) // 2)
+    ref = x + orc.conv1d(orc.silu(xt), w2, b2, padding=(k - 1) // 2)
+    c1 = FusedConv(w1, b1, dilation=d, padding=(k * d - d) // 2)
+    c2 = FusedConv(w2, b2, padding=(k - 1) // 2)
+    y = c1.pair(c2, torch.from_numpy(x).to(_dev()))
+    torch.cuda.synchronize()
+    _check(y.cpu().numpy(), ref)
+
+
+def test_fused_pair_rejects_unsupported_shapes():
+    from vocoder_amd.engine import FusedConv, FishVocError
+    w = np.zeros((64, 64, 5), np.float32)
+    c = FusedConv(w, None, padding=2)
+    with pytest.raises(FishVocError, match="unsupported pair"):
+        c.pair(c, torch.zeros(1, 64, 32, device=_dev()))

@@ -25,7 +25,7 @@ EXPORTS = (
     "fv_create", "fv_load_weight", "fv_finalize", "fv_destroy", "fv_output_length", "fv_output_channels",
     "fv_input_channels", "fv_workspace_bytes", "fv_forward", "fv_conv_create", "fv_conv_output_length",
     "fv_conv_forward", "fv_conv_destroy", "fv_last_error", "fv_abi_version", "fv_last_kernel",
-    "fv_profile_begin", "fv_profile_end",
+    "fv_profile_begin", "fv_profile_end", "fv_conv_pair_forward",
 )
 
 _i32 = ctypes.c_int32
@@ -111,6 +111,8 @@ def lib() -> ctypes.CDLL:
     L.fv_conv_forward.restype = _i32
     L.fv_conv_destroy.argtypes = [vp]
     L.fv_conv_destroy.restype = None
+    L.fv_conv_pair_forward.argtypes = [vp, vp, vp, vp, _i32, _i32, vp]
+    L.fv_conv_pair_forward.restype = _i32
     L.fv_profile_begin.argtypes = [vp]
     L.fv_profile_begin.restype = _i32
     L.fv_profile_end.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]

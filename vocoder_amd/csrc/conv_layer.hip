@@ -87,12 +87,24 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
     FV_HIP_CHECK(hipMalloc((void**)&L.d_bias, bias.size() * sizeof(float)));
     FV_HIP_CHECK(hipMemcpy(L.d_wp, packed.data(), L.wp_bytes, hipMemcpyHostToDevice));
     FV_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!transposed && c_in == 16 && c_out == 16) {
+        // v_mfma_f32_16x16x4_f32 A fragments: [tap][lane] float4, .q = W[lane & 15][4q + (lane >> 4)][tap]
+        std::vector<float> p16((size_t)k * 64 * 4);
+        for (int j = 0; j < k; ++j)
+            for (int l = 0; l < 64; ++l)
+                for (int q = 0; q < 4; ++q)
+                    p16[((size_t)j * 64 + l) * 4 + q] = host_w[((size_t)(l & 15) * 16 + 4 * q + (l >> 4)) * k + j];
+        FV_HIP_CHECK(hipMalloc((void**)&L.d_wp16, p16.size() * sizeof(float)));
+        FV_HIP_CHECK(hipMemcpy(L.d_wp16, p16.data(), p16.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return FV_OK;
 }
 
 void conv_layer_destroy(ConvLayer& L) {
     if (L.d_wp) (void)hipFree(L.d_wp);
     if (L.d_bias) (void)hipFree(L.d_bias);
+    if (L.d_wp16) (void)hipFree(L.d_wp16);
+    L.d_wp16 = nullptr;
     L.d_wp = nullptr;
     L.d_bias = nullptr;
 }
@@ -213,6 +225,48 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         char lbl[160];
         std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d%s", name, L.c_in, L.c_out, L.transposed ? " convT" : "");
         prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
+    }
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
+fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x, float* y, int batch, int t, int out_mode,
+                        float out_scale, hipStream_t stream) {
+    const int C = c1.c_in;
+    const bool shape_ok = !c1.transposed && !c2.transposed && c1.c_out == C && c2.c_in == C && c2.c_out == C &&
+                          c1.k == c2.k && c2.dil == 1 && c1.padding == (c1.k - 1) / 2 * c1.dil && c2.padding == (c2.k - 1) / 2;
+    if (!shape_ok || !pair_supported(C, c1.k, c1.dil)) {
+        set_error("conv_pair_run: unsupported pair (C=%d k=%d d=%d)", C, c1.k, c1.dil);
+        return FV_ERR_UNSUPPORTED;
+    }
+    if (x == y) {
+        set_error("conv_pair_run: output must not alias the input (halo reads)");
+        return FV_ERR_INVALID;
+    }
+    PairParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = x;
+    p.y = y;
+    p.w1 = C == 16 ? c1.d_wp16 : c1.d_wp;
+    p.w2 = C == 16 ? c2.d_wp16 : c2.d_wp;
+    p.b1 = c1.d_bias;
+    p.b2 = c2.d_bias;
+    p.T = t;
+    p.out_mode = out_mode;
+    p.out_scale = out_scale;
+    const int prof_idx = prof_begin(stream);
+    if (!launch_resblock_pair(p, C, c1.k, c1.dil, batch, stream)) {
+        set_error("conv_pair_run: no kernel for (C=%d k=%d d=%d)", C, c1.k, c1.dil);
+        return FV_ERR_UNSUPPORTED;
+    }
+    static thread_local char name[96];
+    std::snprintf(name, sizeof(name), "resblock_pair<k=%d d=%d C=%d>", c1.k, c1.dil, C);
+    set_last_kernel(name);
+    if (prof_idx >= 0) {
+        // algorithmic work: the two convs' MACs; bytes: x once + output once (+ accumulate operand)
+        const double macs = 2.0 * C * C * c1.k * (double)t * batch;
+        const double elems = (out_mode == OUT_ACCUM ? 3.0 : 2.0) * C * (double)t * batch;
+        prof_end(stream, prof_idx, name, 2.0 * macs, elems * 4.0 + 2.0 * C * C * c1.k * 4.0);
     }
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;

@@ -11,9 +11,14 @@
 //     (activation applied on the way in), and every tap j reads it at a shifted address -> KS-fold reuse out of LDS,
 //     reads are lane-consecutive (bank-conflict free ds_read_b32 with immediate offsets).
 //   A operand (weights): pre-packed on the host in MFMA-fragment order so that each lane fetches its four
-//     k-steps of a tap with one coalesced global_load_dwordx4 straight from L2 (weights are L2-resident; no LDS).
+//     k-steps of a tap with one coalesced global_load_dwordx4 straight from L2 (weights are L2-resident; no LDS),
+//     software-prefetched one tap ahead.
 //   K ordering inside a chunk: tap-major, then channel pair p; MFMA k-half h (lane>>5) = channel 2p+h.
 //   Accumulators: MT x NT tiles of 32x32 fp32 (16 VGPRs each) per wave.
+//
+// Memory-op discipline (measured, profiles/README.md): every global load is UNCONDITIONAL on a clamped address and
+// the bounds test is applied to the loaded value — a `cond ? load : 0` makes hipcc branch around each load and wait
+// vmcnt(0) per element, which serialised the staging loads and the epilogue's residual loads.
 #pragma once
 
 #include "fv_internal.h"
@@ -32,15 +37,17 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     }
 }
 
+// min 3 waves per SIMD for the 64-accumulator tiles, 4 for the smaller ones: caps VGPR+AGPR so that several workgroups
+// stay resident per CU (their MFMA phases cover each other's staging / barrier phases)
 template <int KS, int DIL, int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void conv_mfma_kernel(const ConvParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int M_BLK = WM * MT * 32;  (void)M_BLK;
     constexpr int N_BLK = WN * NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
     constexpr int W = N_BLK + SPAN;                    // staged columns per channel row
-    constexpr int NE = (kChunk * W + 255) / 256;       // staged elements per thread
-    __shared__ float xs[2][kChunk * W];
+    constexpr int TOT = kChunk * W;
+    constexpr int NE = (TOT + 255) / 256;              // staged elements per thread
+    __shared__ float xs[2][TOT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,18 +70,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float stage[NE];
+    // ---- staging plan: thread handles elements e = tid + i*256 of the [8][W] chunk window (same for every chunk) ----
+    int st_off[NE];     // clamped offset (row * Tin + t) relative to the chunk's first channel row; < 0: always zero
     const int tbase = n0 - p.pad_l;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        int e = tid + i * 256;
+        const bool in_tile = e < TOT;
+        e = in_tile ? e : TOT - 1;
+        const int r = e / W;
+        const int col = e - r * W;
+        const int t = tbase + col;
+        const bool ok = in_tile && t >= 0 && t < p.Tin;
+        const int tc = t < 0 ? 0 : (t > p.Tin - 1 ? p.Tin - 1 : t);
+        st_off[i] = ok ? r * p.Tin + tc : -1;
+    }
+    float stage[NE];
     auto load_chunk = [&](int c) {
+        const int cbase = c * kChunk;
+        const float* __restrict__ xc = xb + (long long)cbase * p.Tin;
+        const int lim = (p.Cin - cbase) * p.Tin;   // offsets >= lim belong to zero-padded channels (>= Cin)
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * 256;
-            const int r = e / W;
-            const int col = e - r * W;
-            const int ci = c * kChunk + r;
-            const int t = tbase + col;
-            const bool ok = (e < kChunk * W) && (ci < p.Cin) && (t >= 0) && (t < p.Tin);
-            stage[i] = ok ? xb[(long long)ci * p.Tin + t] : 0.f;
+            const bool ok = st_off[i] >= 0 && st_off[i] < lim;
+            const float v = xc[ok ? st_off[i] : 0];   // unconditional load on an always-valid address
+            stage[i] = ok ? v : 0.f;
         }
     };
     auto store_chunk = [&](float* dst) {
@@ -83,94 +103,158 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             for (int i = 0; i < NE; ++i) {
                 const int e = tid + i * 256;
                 const float v = stage[i];
-                if (e < kChunk * W) dst[e] = v * __frcp_rn(1.0f + __expf(-v));
+                if (e < TOT) dst[e] = v * __frcp_rn(1.0f + __expf(-v));
             }
         } else if (p.pre_act == FV_ACT_NONE) {
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 const int e = tid + i * 256;
-                if (e < kChunk * W) dst[e] = stage[i];
+                if (e < TOT) dst[e] = stage[i];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 const int e = tid + i * 256;
                 // act(0) == 0 for every supported activation, so zero padding commutes with it
-                if (e < kChunk * W) dst[e] = act_apply(stage[i], p.pre_act, p.slope);
+                if (e < TOT) dst[e] = act_apply(stage[i], p.pre_act, p.slope);
             }
         }
     };
 
-    // A-operand base: packed as [m_tile][chunk][tap][lane] float4 (4 channel pairs)
+    // A-operand: packed as [m_tile][chunk][tap][lane] float4 (4 channel pairs); wave-uniform base + lane
     const int mt0 = (m_blk * WM + wm) * MT;
-    const float4* __restrict__ wbase = p.wp + lane;
+    const float4* __restrict__ wlane = p.wp + lane;
+    auto load_a = [&](float4 (&dst)[MT], int c, int j) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) dst[i] = wlane[((long long)((mt0 + i) * p.nchunk + c) * KS + j) * 64];
+    };
     const int b_lane = (lane >> 5) * W + wn * (NT * 32) + (lane & 31);
 
+    auto load_b = [&](float (&dst)[4][NT], const float* xsb, int j) {
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) dst[pp][jn] = xsb[b_lane + (2 * pp) * W + jn * 32 + j * DIL];
+    };
+
+    // Software pipeline, one tap deep for both operands: while the 4*MT*NT MFMAs of tap j run, the weight fragment
+    // (global, L2) and the activation fragments (LDS) of tap j+1 are already in flight.  The sched_barriers pin that
+    // order; without them hipcc sinks the loads next to their first use and exposes the L2 / LDS latency.
+    float4 a_cur[MT], a_nxt[MT];
+    float b_cur[4][NT], b_nxt[4][NT];
     load_chunk(0);
+    load_a(a_cur, 0, 0);
     for (int c = 0; c < p.nchunk; ++c) {
         float* xsb = xs[c & 1];
         store_chunk(xsb);
         __syncthreads();
-        if (c + 1 < p.nchunk) load_chunk(c + 1);
+        const bool more = c + 1 < p.nchunk;
+        if (more) load_chunk(c + 1);
+        load_b(b_cur, xsb, 0);
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
-            float4 a[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                a[i] = wbase[((long long)((mt0 + i) * p.nchunk + c) * KS + j) * 64];
+            if (j + 1 < KS) {
+                load_a(a_nxt, c, j + 1);
+                load_b(b_nxt, xsb, j + 1);
+            } else {
+                load_a(a_nxt, more ? c + 1 : c, 0);   // first tap of the next chunk
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
-                float bv[NT];
-#pragma unroll
-                for (int jn = 0; jn < NT; ++jn) bv[jn] = xsb[b_lane + (2 * pp) * W + jn * 32 + j * DIL];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const float av = pp == 0 ? a[i].x : pp == 1 ? a[i].y : pp == 2 ? a[i].z : a[i].w;
+                    const float av = pp == 0 ? a_cur[i].x : pp == 1 ? a_cur[i].y : pp == 2 ? a_cur[i].z : a_cur[i].w;
 #pragma unroll
                     for (int jn = 0; jn < NT; ++jn)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[jn], acc[i][jn], 0, 0, 0);
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[pp][jn], acc[i][jn], 0, 0, 0);
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
+            if (j + 1 < KS) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn) b_cur[pp][jn] = b_nxt[pp][jn];
             }
         }
     }
 
-    // Epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5). ----
     const int ncol0 = n0 + wn * (NT * 32) + (lane & 31);
     float* __restrict__ yb = p.y + (long long)b * p.y_bstride;
     const float* __restrict__ rb = p.res ? p.res + (long long)b * p.y_bstride : nullptr;
+    const bool accum = p.out_mode == OUT_ACCUM;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+        // column part of the output offset (independent of the row) and its validity
+        int coff[NT];
+        bool cok[NT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (mt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m >= p.M) continue;
-            const float bias = p.bias[m];
-            const float gm = p.gamma ? p.gamma[m] : 1.0f;
-            long long row_off;
-            int cstride, cbase;
+        for (int jn = 0; jn < NT; ++jn) {
+            const int n = ncol0 + jn * 32;
             if (p.convt) {
-                const int co = m / p.u, ph = m - co * p.u;
-                row_off = (long long)co * p.Tout;
-                cstride = p.u;
-                cbase = ph - p.pad_t;
+                coff[jn] = n * p.u - p.pad_t;   // + phase added per row
+                cok[jn] = n < p.N;
             } else {
-                row_off = (long long)m * p.N;
-                cstride = 1;
-                cbase = 0;
+                coff[jn] = n;
+                cok[jn] = n < p.N;
+            }
+        }
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            // 4 rows (r & 3) x NT columns at a time: issue all residual / accumulate loads, then compute, then store
+            int off[4][NT];
+            bool ok[4][NT];
+            float rv[4][NT], yo[4][NT], bias[4], gm[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = (mt0 + i) * 32 + rr + 8 * rq + 4 * (lane >> 5);
+                const bool mok = m < p.M;
+                const int mc = mok ? m : 0;
+                bias[rr] = p.bias[mc];
+                gm[rr] = p.gamma ? p.gamma[mc] : 1.0f;
+                int row_off, ph = 0;   // per-item offsets fit 32 bits (C * T < 2^31)
+                if (p.convt) {
+                    const int co = mc / p.u;
+                    ph = mc - co * p.u;
+                    row_off = co * p.Tout;
+                } else {
+                    row_off = mc * p.N;
+                }
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    const int t = coff[jn] + ph;
+                    bool v = mok && cok[jn];
+                    if (p.convt) v = v && t >= 0 && t < p.Tout;
+                    ok[rr][jn] = v;
+                    off[rr][jn] = v ? row_off + t : 0;   // offset 0 is always a valid element
+                }
+            }
+            if (rb) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn) rv[rr][jn] = rb[off[rr][jn]];
+            }
+            if (accum) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn) yo[rr][jn] = yb[off[rr][jn]];
             }
 #pragma unroll
-            for (int jn = 0; jn < NT; ++jn) {
-                const int n = ncol0 + jn * 32;
-                if (n >= p.N) continue;
-                const int t = n * cstride + cbase;
-                if (p.convt && (t < 0 || t >= p.Tout)) continue;
-                const long long o = row_off + t;
-                float v = (acc[i][jn][r] + bias) * gm;
-                if (rb) v += rb[o];
-                v = act_apply(v, p.post_act, p.slope);
-                if (p.out_mode == OUT_ACCUM) v = (yb[o] + v) * p.out_scale;
-                yb[o] = v;
-            }
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    float v = (acc[i][jn][rq * 4 + rr] + bias[rr]) * gm[rr];
+                    if (rb) v += rv[rr][jn];
+                    v = act_apply(v, p.post_act, p.slope);
+                    if (accum) v = (yo[rr][jn] + v) * p.out_scale;
+                    if (ok[rr][jn]) yb[off[rr][jn]] = v;
+                }
         }
     }
 }

@@ -10,6 +10,7 @@
 //                                       + generators/vocos.py:43-69 (Vocos)
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -251,6 +252,7 @@ struct fv_engine {
     bool has_ups = false, has_cnx = false, has_head = false;
     Profiler prof;
     bool profiling = false;
+    bool fuse_pairs = true;   // FV_NO_PAIR_FUSION=1 in the environment disables the fused (c1, c2) kernels (A/B runs)
 
     // ---- weight lookup helpers (reference state-dict names) ----
     const HostTensor* find(const std::string& name) {
@@ -567,6 +569,26 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
         // ParralelBlock / stack-mean of the three ResBlock1 / AMPBlock branches (hifigan.py:132-133, bigvgan.py:358-365)
         for (int j = 0; j < nk; ++j) {
             ResBranch& br = *stg->branches[j];
+            // HiFiGAN narrow stages: the whole (c1, c2) pair in one kernel, intermediate kept in LDS.  Not in place
+            // (workgroups read their neighbours' halo), so the branch ping-pongs S -> XB -> XT -> Y.
+            const bool fuse = !ups.bigvgan && pair_supported(ch, br.k, br.dil[0]) && pair_supported(ch, br.k, br.dil[1]) &&
+                              pair_supported(ch, br.k, br.dil[2]) && fuse_pairs;
+            if (fuse) {
+                const float* src = S;
+                for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
+                    const bool last = n == FV_MAX_DILATIONS - 1;
+                    float* dst = last ? Y : (n == 0 ? XB : XT);
+                    int mode = OUT_SET;
+                    float scale = 1.0f;
+                    if (last && nk > 1) {
+                        mode = j == 0 ? OUT_SET : OUT_ACCUM;
+                        scale = (j == nk - 1) ? 1.0f / (float)nk : 1.0f;
+                    }
+                    if ((st = conv_pair_run(br.c1[n], br.c2[n], src, dst, B, t, mode, scale, s))) return st;
+                    src = dst;
+                }
+                continue;
+            }
             for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
                 const float* src = n == 0 ? S : XB;
                 const bool last = n == FV_MAX_DILATIONS - 1;
@@ -815,6 +837,7 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
         return FV_ERR_INVALID;
     }
     e->cfg = *cfg;
+    if (const char* v = std::getenv("FV_NO_PAIR_FUSION")) e->fuse_pairs = !(v[0] == '1');
     *out = e;
     return FV_OK;
 }
@@ -1089,6 +1112,20 @@ FV_API fv_status fv_conv_forward(fv_conv* c, const float* d_x, float* d_y, const
     r.post_act = c->desc.post_act;
     r.slope = c->desc.act_slope;
     return conv_layer_run(c->L, r, (hipStream_t)stream);
+}
+
+/* y = x + c2(silu(c1(silu(x)))) in one launch (narrow channels only); c1/c2 are fv_conv handles of equal C and k. */
+FV_API fv_status fv_conv_pair_forward(fv_conv* c1, fv_conv* c2, const float* d_x, float* d_y, int32_t batch, int32_t t,
+                                      void* stream) {
+    if (!c1 || !c2 || !d_x || !d_y) {
+        set_error("fv_conv_pair_forward: null argument");
+        return FV_ERR_INVALID;
+    }
+    if (batch < 1 || t < 1) {
+        set_error("fv_conv_pair_forward: empty input");
+        return FV_ERR_INVALID;
+    }
+    return conv_pair_run(c1->L, c2->L, d_x, d_y, batch, t, OUT_SET, 1.0f, (hipStream_t)stream);
 }
 
 FV_API void fv_conv_destroy(fv_conv* c) {

@@ -82,6 +82,7 @@ struct ConvLayer {
     // GEMM view
     int M = 0, ks = 0, pad_l = 0, nchunk = 0, m_pad = 0;
     float4* d_wp = nullptr;
+    float4* d_wp16 = nullptr;  // 16x16x4-fragment layout, only for 16 -> 16 channel Conv1d (fused pair kernel)
     float* d_bias = nullptr;
     size_t wp_bytes = 0;
 
@@ -122,6 +123,23 @@ bool launch_conv_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_misc(const ConvParams& p, int cfg, int batch, hipStream_t s);   // k=2, 4, 5, 13 ...
 bool launch_conv_generic(const ConvParams& p, int cfg, int batch, hipStream_t s, size_t* lds_bytes);
+
+// Fused ResBlock (c1, c2) pair for narrow stages: y = x + c2(silu(c1(silu(x))))  (resblock_pair.hip)
+struct PairParams {
+    const float* x;       // (B, C, T)
+    const float4* w1;     // c1 packed weights (32x32x2 layout for C >= 32, 16x16x4 layout for C == 16)
+    const float* b1;
+    const float4* w2;
+    const float* b2;
+    float* y;             // (B, C, T); must NOT alias x (neighbouring workgroups read x's halo)
+    int T, n_tiles;
+    int out_mode;
+    float out_scale;
+};
+bool pair_supported(int C, int ks, int dil);
+bool launch_resblock_pair(const PairParams& p, int C, int ks, int dil, int batch, hipStream_t s);
+fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x, float* y, int batch, int t, int out_mode,
+                        float out_scale, hipStream_t stream);
 
 // Tile configurations (block = 4 waves): rows = WM*MT*32, cols = WN*NT*32.
 enum TileCfg : int { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2, TILE_128x64 = 3, TILE_32x128 = 4, TILE_64x128 = 5, TILE_COUNT };

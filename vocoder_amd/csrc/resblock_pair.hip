@@ -1,0 +1,361 @@
+// Fused ResBlock (c1, c2) pair for the narrow, bandwidth-bound stages (C = 16 / 32 / 64):
+//
+//     y = x + c2( silu( c1( silu(x) ) ) )          (one iteration of ResBlock1.forward,
+//                                                    fish_vocoder/modules/generators/hifigan.py:102-107)
+//
+// in ONE launch.  Per layer the reference (and the unfused path here) moves 5 tensor passes through HBM for this
+// (read x, write xt, read xt, read x, write x'); fused it is ~2-3: the x window is read once (+ halo), the
+// intermediate silu(c1(.)) never leaves LDS, and the residual re-read hits L2/MALL.
+//
+// Workgroup = 4 wavefronts, one batch item, TT final columns:
+//   phase 1  stage A = silu(x[:, t0-HP : t0+W1+HP']) for ALL C channels into LDS (zero outside [0, T))
+//   phase 2  c1 as implicit GEMM on fp32 MFMA over W1 = TT + KS-1 columns, epilogue bias + silu (+ zero outside [0, T):
+//            c2's zero padding) written to LDS buffer Bf
+//   phase 3  c2 as implicit GEMM reading Bf, epilogue bias + residual x (+ MRF accumulate) to HBM
+// All K = C*KS is resident, so there are only two barriers per workgroup and every LDS address is an immediate.
+// C = 32 / 64 use v_mfma_f32_32x32x2_f32; C = 16 uses v_mfma_f32_16x16x4_f32 (no padded rows).
+#include "conv_mfma_impl.h"
+
+namespace fv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KS, int DIL, int C>
+struct PairGeom {
+    static constexpr int W1 = 8192 / C;                 // c1 output columns per workgroup (512 / 256 / 128)
+    static constexpr int TT = W1 - (KS - 1);            // final output columns per workgroup
+    static constexpr int H1 = (KS - 1) / 2 * DIL, H2 = (KS - 1) / 2, HP = H1 + H2;
+    static constexpr int WA_RAW = W1 + (KS - 1) * DIL;  // staged x columns
+    static constexpr int WB_RAW = W1 + (KS - 1);        // c1 output columns incl. the read-overhang of the last c2 tile
+    // row strides == 16 (mod 32): the 16x16x4 B-fragment read puts lanes 0-15 / 16-31 on adjacent channel rows
+    static constexpr int WA = (WA_RAW - 16 + 31) / 32 * 32 + 16;
+    static constexpr int WB = (WB_RAW - 16 + 31) / 32 * 32 + 16;
+    static constexpr int LDS_FLOATS = C * (WA + WB);
+};
+
+__device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+
+// As[r][col] = silu(x[r][t0 - HP + col]) for r < C, col < WA_RAW (0 outside [0, T)); LDS row stride WA.
+template <int C, int WA_RAW, int WA, int HP>
+__device__ __forceinline__ void stage_window(const float* __restrict__ xb, float* __restrict__ As, int tid, int t0, int T) {
+    constexpr int TOT = C * WA_RAW;
+    constexpr int BATCH = 8;
+    constexpr int NB = (TOT + 256 * BATCH - 1) / (256 * BATCH);
+#pragma unroll 1
+    for (int bb = 0; bb < NB; ++bb) {
+        float v[BATCH];
+        int dst[BATCH];
+        bool ok[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            int e = tid + (bb * BATCH + i) * 256;
+            const bool in = e < TOT;
+            e = in ? e : TOT - 1;
+            const int r = e / WA_RAW, col = e - r * WA_RAW;
+            const int t = t0 - HP + col;
+            ok[i] = in && t >= 0 && t < T;
+            dst[i] = in ? r * WA + col : -1;
+            const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+            v[i] = xb[(long long)r * T + tc];
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i)
+            if (dst[i] >= 0) As[dst[i]] = ok[i] ? silu_f(v[i]) : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C = 32 (MT = 1) and C = 64 (MT = 2): 32x32x2 MFMA.  Each wave owns NT n-tiles of 32 columns and all m-tiles.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KS, int DIL, int C>
+__global__ __launch_bounds__(256) void resblock_pair32_kernel(const PairParams p) {
+    using G = PairGeom<KS, DIL, C>;
+    constexpr int MT = C / 32;
+    constexpr int NT = G::W1 / 32 / 4;   // n-tiles per wave
+    constexpr int NCH = C / 8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;
+    float* Bs = lds + C * G::WA;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x % p.n_tiles, b = blockIdx.x / p.n_tiles;
+    const int t0 = tile * G::TT;
+    const float* __restrict__ xb = p.x + (long long)b * C * p.T;
+
+    // phase 1: A = silu(x) window.  Loads are unconditional on clamped addresses and issued in batches of 8 so that
+    // their latencies overlap (a guarded load per element compiles to a branch + vmcnt(0) each).
+    stage_window<C, G::WA_RAW, G::WA, G::HP>(xb, As, tid, t0, p.T);
+    __syncthreads();
+
+    const int ncol = wave * (NT * 32) + (lane & 31);
+    const int krow = lane >> 5;
+
+    // phase 2: c1
+    {
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const float4* __restrict__ w = p.w1 + lane;
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                float4 a[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = w[((i * NCH + cc) * KS + j) * 64];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    float bv[NT];
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn)
+                        bv[jn] = As[(cc * 8 + 2 * pp + krow) * G::WA + ncol + jn * 32 + j * DIL];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const float av = pp == 0 ? a[i].x : pp == 1 ? a[i].y : pp == 2 ? a[i].z : a[i].w;
+#pragma unroll
+                        for (int jn = 0; jn < NT; ++jn)
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[jn], acc[i][jn], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
+                const float bias = p.b1[m];
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    const int n = ncol + jn * 32;
+                    const int pos = t0 - G::H2 + n;
+                    const float v = (pos >= 0 && pos < p.T) ? silu_f(acc[i][jn][r] + bias) : 0.f;
+                    Bs[m * G::WB + n] = v;
+                }
+            }
+    }
+    __syncthreads();
+
+    // phase 3: c2 + residual
+    {
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const float4* __restrict__ w = p.w2 + lane;
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                float4 a[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = w[((i * NCH + cc) * KS + j) * 64];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    float bv[NT];
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn) bv[jn] = Bs[(cc * 8 + 2 * pp + krow) * G::WB + ncol + jn * 32 + j];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const float av = pp == 0 ? a[i].x : pp == 1 ? a[i].y : pp == 2 ? a[i].z : a[i].w;
+#pragma unroll
+                        for (int jn = 0; jn < NT; ++jn)
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[jn], acc[i][jn], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        float* __restrict__ yb = p.y + (long long)b * C * p.T;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
+                const float bias = p.b2[m];
+                long long o[NT];
+                bool ok[NT];
+                float xr[NT], yo[NT];
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    const int n = ncol + jn * 32;
+                    const int t = t0 + n;
+                    ok[jn] = n < G::TT && t < p.T;
+                    o[jn] = ok[jn] ? (long long)m * p.T + t : 0;
+                    xr[jn] = xb[o[jn]];
+                }
+                if (p.out_mode == OUT_ACCUM) {
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn) yo[jn] = yb[o[jn]];
+                }
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    float v = acc[i][jn][r] + bias + xr[jn];
+                    if (p.out_mode == OUT_ACCUM) v = (yo[jn] + v) * p.out_scale;
+                    if (ok[jn]) yb[o[jn]] = v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C = 16: 16x16x4 MFMA (A: row = lane & 15, k = lane >> 4; C/D: col = lane & 15, row = 4 * (lane >> 4) + reg).
+// Weights packed as [tap][lane] float4 = the four channel quads of that tap.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KS, int DIL>
+__global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairParams p) {
+    constexpr int C = 16;
+    using G = PairGeom<KS, DIL, C>;
+    constexpr int NT = G::W1 / 16 / 4;   // 8 n-tiles of 16 columns per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;
+    float* Bs = lds + C * G::WA;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x % p.n_tiles, b = blockIdx.x / p.n_tiles;
+    const int t0 = tile * G::TT;
+    const float* __restrict__ xb = p.x + (long long)b * C * p.T;
+
+    stage_window<C, G::WA_RAW, G::WA, G::HP>(xb, As, tid, t0, p.T);
+    __syncthreads();
+
+    const int ncol = wave * (NT * 16) + (lane & 15);
+    const int krow = lane >> 4;
+
+    {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float4* __restrict__ w = p.w1 + lane;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const float4 a = w[j * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float av = q == 0 ? a.x : q == 1 ? a.y : q == 2 ? a.z : a.w;
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    const float bv = As[(4 * q + krow) * G::WA + ncol + jn * 16 + j * DIL];
+                    acc[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[jn], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 4 * krow + r;
+            const float bias = p.b1[m];
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) {
+                const int n = ncol + jn * 16;
+                const int pos = t0 - G::H2 + n;
+                Bs[m * G::WB + n] = (pos >= 0 && pos < p.T) ? silu_f(acc[jn][r] + bias) : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float4* __restrict__ w = p.w2 + lane;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const float4 a = w[j * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float av = q == 0 ? a.x : q == 1 ? a.y : q == 2 ? a.z : a.w;
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    const float bv = Bs[(4 * q + krow) * G::WB + ncol + jn * 16 + j];
+                    acc[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[jn], 0, 0, 0);
+                }
+            }
+        }
+        float* __restrict__ yb = p.y + (long long)b * C * p.T;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 4 * krow + r;
+            const float bias = p.b2[m];
+            long long o[NT];
+            bool ok[NT];
+            float xr[NT], yo[NT];
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) {
+                const int n = ncol + jn * 16;
+                const int t = t0 + n;
+                ok[jn] = n < G::TT && t < p.T;
+                o[jn] = ok[jn] ? (long long)m * p.T + t : 0;
+                xr[jn] = xb[o[jn]];
+            }
+            if (p.out_mode == OUT_ACCUM) {
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) yo[jn] = yb[o[jn]];
+            }
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) {
+                float v = acc[jn][r] + bias + xr[jn];
+                if (p.out_mode == OUT_ACCUM) v = (yo[jn] + v) * p.out_scale;
+                if (ok[jn]) yb[o[jn]] = v;
+            }
+        }
+    }
+}
+
+template <int KS, int DIL>
+static bool launch_pair_c(const PairParams& p, int C, int batch, hipStream_t s) {
+    if (C == 16) {
+        using G = PairGeom<KS, DIL, 16>;
+        PairParams q = p;
+        q.n_tiles = (p.T + G::TT - 1) / G::TT;
+        const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)resblock_pair16_kernel<KS, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL((resblock_pair16_kernel<KS, DIL>), dim3(batch * q.n_tiles), dim3(256), lds, s, q);
+        return true;
+    }
+    if (C == 32) {
+        using G = PairGeom<KS, DIL, 32>;
+        PairParams q = p;
+        q.n_tiles = (p.T + G::TT - 1) / G::TT;
+        const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)resblock_pair32_kernel<KS, DIL, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 32>), dim3(batch * q.n_tiles), dim3(256), lds, s, q);
+        return true;
+    }
+    return false;
+}
+
+bool pair_supported(int C, int ks, int dil) {
+    if (C != 16 && C != 32) return false;
+    if (ks != 3 && ks != 7 && ks != 11) return false;
+    return dil == 1 || dil == 3 || dil == 5;
+}
+
+bool launch_resblock_pair(const PairParams& p, int C, int ks, int dil, int batch, hipStream_t s) {
+    if (!pair_supported(C, ks, dil)) return false;
+#define FV_PAIR_CASE(K, D) \
+    if (ks == K && dil == D) return launch_pair_c<K, D>(p, C, batch, s);
+    FV_PAIR_CASE(3, 1) FV_PAIR_CASE(3, 3) FV_PAIR_CASE(3, 5)
+    FV_PAIR_CASE(7, 1) FV_PAIR_CASE(7, 3) FV_PAIR_CASE(7, 5)
+    FV_PAIR_CASE(11, 1) FV_PAIR_CASE(11, 3) FV_PAIR_CASE(11, 5)
+#undef FV_PAIR_CASE
+    return false;
+}
+
+}  // namespace fv

@@ -212,6 +212,17 @@ class FusedConv:
                                             _stream_ptr(x.device)))
         return out
 
+    def pair(self, c2: "FusedConv", x: torch.Tensor) -> torch.Tensor:
+        """One ResBlock1 iteration in a single launch: x + c2(silu(self(silu(x)))) (fv_conv_pair_forward)."""
+        _require_cuda(x, "FusedConv.pair")
+        x = x.contiguous()
+        B, C, T = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(self._lib.fv_conv_pair_forward(self._h, c2._h, x.data_ptr(), out.data_ptr(), B, T,
+                                                 _stream_ptr(x.device)))
+        return out
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.fv_conv_destroy(self._h)
