@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void conv_mfma_generic_kernel(const ConvParams
     const int b_lane = (lane >> 5) * W + wn * 32 + (lane & 31);
     const int total = kChunk * W;
 
-    for (int c = 0; c < p.nchunk; ++c) {
+    for (int c = 0; c < p.nchunk_real; ++c) {
         float* xsb = xs_dyn + (c & 1) * total;
         for (int e = tid; e < total; e += 256) {
             const int r = e / W, col = e - r * W;

@@ -77,7 +77,8 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
                     }
             }
     }
-    L.nchunk = (c_in + kChunk - 1) / kChunk;
+    L.nchunk_real = (c_in + kChunk - 1) / kChunk;
+    L.nchunk = (L.nchunk_real + 3) / 4 * 4;   // whole LDS chunks for every SUBS in {1, 2, 4} (zero weights)
     L.m_pad = (L.M + 127) / 128 * 128;
     std::vector<float> packed;
     pack_conv_weights(wc, L.M, c_in, L.ks, L.m_pad, L.nchunk, packed);
@@ -162,6 +163,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     p.M = L.M;
     p.N = (int)L.gemm_cols(r.t_in);
     p.nchunk = L.nchunk;
+    p.nchunk_real = L.nchunk_real;
     p.pad_l = L.pad_l;
     p.ks = L.ks;
     p.dil = L.dil;

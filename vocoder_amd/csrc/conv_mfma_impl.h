@@ -37,6 +37,13 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     }
 }
 
+// 8-channel sub-chunks staged per barrier (LDS budget 2 * 8*SUBS * W floats, <= 36 KiB)
+constexpr int subs_for(int ks, int w) {
+    int s = ks <= 4 ? 4 : 2;
+    while (s > 1 && s * kChunk * w > 4608) s /= 2;
+    return s;
+}
+
 // min 3 waves per SIMD for the 64-accumulator tiles, 4 for the smaller ones: caps VGPR+AGPR so that several workgroups
 // stay resident per CU (their MFMA phases cover each other's staging / barrier phases)
 template <int KS, int DIL, int WM, int WN, int MT, int NT>
@@ -45,7 +52,11 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     constexpr int N_BLK = WN * NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
     constexpr int W = N_BLK + SPAN;                    // staged columns per channel row
-    constexpr int TOT = kChunk * W;
+    // channels per LDS chunk = 8 * SUBS: short kernels (pointwise, polyphase convT, k=3) stage more channels per
+    // barrier so that the MFMA run between two barriers stays long
+    constexpr int SUBS = subs_for(KS, W);
+    constexpr int CH = kChunk * SUBS;
+    constexpr int TOT = CH * W;
     constexpr int NE = (TOT + 255) / 256;              // staged elements per thread
     __shared__ float xs[2][TOT];
 
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     }
     float stage[NE];
     auto load_chunk = [&](int c) {
-        const int cbase = c * kChunk;
+        const int cbase = c * CH;
         const float* __restrict__ xc = xb + (long long)cbase * p.Tin;
         const int lim = (p.Cin - cbase) * p.Tin;   // offsets >= lim belong to zero-padded channels (>= Cin)
 #pragma unroll
@@ -130,11 +141,11 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     };
     const int b_lane = (lane >> 5) * W + wn * (NT * 32) + (lane & 31);
 
-    auto load_b = [&](float (&dst)[4][NT], const float* xsb, int j) {
+    auto load_b = [&](float (&dst)[4][NT], const float* xsb, int sub, int j) {
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-            for (int jn = 0; jn < NT; ++jn) dst[pp][jn] = xsb[b_lane + (2 * pp) * W + jn * 32 + j * DIL];
+            for (int jn = 0; jn < NT; ++jn) dst[pp][jn] = xsb[b_lane + (sub * kChunk + 2 * pp) * W + jn * 32 + j * DIL];
     };
 
     // Software pipeline, one tap deep for both operands: while the 4*MT*NT MFMAs of tap j run, the weight fragment
@@ -142,23 +153,29 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     // order; without them hipcc sinks the loads next to their first use and exposes the L2 / LDS latency.
     float4 a_cur[MT], a_nxt[MT];
     float b_cur[4][NT], b_nxt[4][NT];
+    const int nch = (p.nchunk_real + SUBS - 1) / SUBS;   // LDS chunks; packed weights are padded to whole chunks
     load_chunk(0);
     load_a(a_cur, 0, 0);
-    for (int c = 0; c < p.nchunk; ++c) {
+    for (int c = 0; c < nch; ++c) {
         float* xsb = xs[c & 1];
         store_chunk(xsb);
         __syncthreads();
-        const bool more = c + 1 < p.nchunk;
+        const bool more = c + 1 < nch;
         if (more) load_chunk(c + 1);
-        load_b(b_cur, xsb, 0);
+        load_b(b_cur, xsb, 0, 0);
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            if (j + 1 < KS) {
-                load_a(a_nxt, c, j + 1);
-                load_b(b_nxt, xsb, j + 1);
+        for (int st = 0; st < SUBS * KS; ++st) {
+            constexpr int LAST = SUBS * KS - 1;
+            const int sub = st / KS, j = st % KS;
+            if (st < LAST) {
+                const int sub_n = (st + 1) / KS, j_n = (st + 1) % KS;
+                load_a(a_nxt, c * SUBS + sub_n, j_n);
+                load_b(b_nxt, xsb, sub_n, j_n);
             } else {
-                load_a(a_nxt, more ? c + 1 : c, 0);   // first tap of the next chunk
+                load_a(a_nxt, more ? (c + 1) * SUBS : c * SUBS, 0);   // first tap of the next chunk
             }
+            (void)sub;
+            (void)j;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
@@ -173,7 +190,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
-            if (j + 1 < KS) {
+            if (st < LAST) {
 #pragma unroll
                 for (int pp = 0; pp < 4; ++pp)
 #pragma unroll

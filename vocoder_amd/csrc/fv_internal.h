@@ -62,7 +62,8 @@ struct ConvParams {
     const float* gamma;  // per-row scale applied before the residual (ConvNeXt layer-scale), may be NULL
     int Cin, Tin;
     int M, N;            // valid GEMM rows / columns per batch item
-    int nchunk;          // ceil(Cin / kChunk)
+    int nchunk;          // 8-channel sub-chunks in the packed weights (ceil(Cin / 8) rounded up to a multiple of 4)
+    int nchunk_real;     // ceil(Cin / 8): sub-chunks that actually hold channels
     int n_tiles, m_blks; // grid = B * m_blks * n_tiles
     int pad_l;
     int ks, dil;         // runtime copies (used by the generic variant)
@@ -80,7 +81,7 @@ struct ConvLayer {
     bool transposed = false;
     int c_in = 0, c_out = 0, k = 0, dil = 1, padding = 0, stride = 1;
     // GEMM view
-    int M = 0, ks = 0, pad_l = 0, nchunk = 0, m_pad = 0;
+    int M = 0, ks = 0, pad_l = 0, nchunk = 0, nchunk_real = 0, m_pad = 0;
     float4* d_wp = nullptr;
     float4* d_wp16 = nullptr;  // 16x16x4-fragment layout, only for 16 -> 16 channel Conv1d (fused pair kernel)
     float* d_bias = nullptr;

@@ -64,6 +64,94 @@ __device__ __forceinline__ void stage_window(const float* __restrict__ xb, float
     }
 }
 
+
+// acc[i][jn] += sum over (cc, tap j, pair pp) of W-fragment x B-fragment, B element = bsrc[(cc*8 + 2pp)*STRIDE + jn*32 + j*DILX]
+// (bsrc already carries the lane's k-half row and column).  One step (= one tap of one 8-channel sub-chunk) deep software
+// pipeline on both operands, pinned with sched_barriers (see conv_mfma_impl.h).
+template <int KS, int STRIDE, int DILX, int MT, int NT, int NCH>
+__device__ __forceinline__ void gemm32_resident(const float4* __restrict__ w, const float* __restrict__ bsrc,
+                                                f32x16 (&acc)[MT][NT]) {
+    constexpr int STEPS = NCH * KS;
+    float4 a_cur[MT], a_nxt[MT];
+    float b_cur[4][NT], b_nxt[4][NT];
+    auto load_a = [&](float4 (&dst)[MT], int st) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) dst[i] = w[(i * STEPS + st) * 64];   // [(i*NCH + cc)*KS + j] == i*STEPS + st
+    };
+    auto load_b = [&](float (&dst)[4][NT], int st) {
+        const int cc = st / KS, j = st % KS;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) dst[pp][jn] = bsrc[(cc * 8 + 2 * pp) * STRIDE + jn * 32 + j * DILX];
+    };
+    load_a(a_cur, 0);
+    load_b(b_cur, 0);
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        if (st + 1 < STEPS) {
+            load_a(a_nxt, st + 1);
+            load_b(b_nxt, st + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float av = pp == 0 ? a_cur[i].x : pp == 1 ? a_cur[i].y : pp == 2 ? a_cur[i].z : a_cur[i].w;
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[pp][jn], acc[i][jn], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < STEPS) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) b_cur[pp][jn] = b_nxt[pp][jn];
+        }
+    }
+}
+
+// 16-channel variant on v_mfma_f32_16x16x4_f32: B element = bsrc[(4q)*STRIDE + jn*16 + j*DILX]
+template <int KS, int STRIDE, int DILX, int NT>
+__device__ __forceinline__ void gemm16_resident(const float4* __restrict__ w, const float* __restrict__ bsrc, f32x4 (&acc)[NT]) {
+    float4 a_cur, a_nxt;
+    float b_cur[4][NT], b_nxt[4][NT];
+    auto load_b = [&](float (&dst)[4][NT], int j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) dst[q][jn] = bsrc[(4 * q) * STRIDE + jn * 16 + j * DILX];
+    };
+    a_cur = w[0];
+    load_b(b_cur, 0);
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        if (j + 1 < KS) {
+            a_nxt = w[(j + 1) * 64];
+            load_b(b_nxt, j + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float av = q == 0 ? a_cur.x : q == 1 ? a_cur.y : q == 2 ? a_cur.z : a_cur.w;
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) acc[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_cur[q][jn], acc[jn], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < KS) {
+            a_cur = a_nxt;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) b_cur[q][jn] = b_nxt[q][jn];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // C = 32 (MT = 1) and C = 64 (MT = 2): 32x32x2 MFMA.  Each wave owns NT n-tiles of 32 columns and all m-tiles.
 // ---------------------------------------------------------------------------------------------------------------
@@ -100,30 +188,7 @@ __global__ __launch_bounds__(256) void resblock_pair32_kernel(const PairParams p
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const float4* __restrict__ w = p.w1 + lane;
-#pragma unroll
-        for (int cc = 0; cc < NCH; ++cc) {
-#pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                float4 a[MT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = w[((i * NCH + cc) * KS + j) * 64];
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    float bv[NT];
-#pragma unroll
-                    for (int jn = 0; jn < NT; ++jn)
-                        bv[jn] = As[(cc * 8 + 2 * pp + krow) * G::WA + ncol + jn * 32 + j * DIL];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        const float av = pp == 0 ? a[i].x : pp == 1 ? a[i].y : pp == 2 ? a[i].z : a[i].w;
-#pragma unroll
-                        for (int jn = 0; jn < NT; ++jn)
-                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[jn], acc[i][jn], 0, 0, 0);
-                    }
-                }
-            }
-        }
+        gemm32_resident<KS, G::WA, DIL, MT, NT, NCH>(p.w1 + lane, As + krow * G::WA + ncol, acc);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -150,29 +215,7 @@ __global__ __launch_bounds__(256) void resblock_pair32_kernel(const PairParams p
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const float4* __restrict__ w = p.w2 + lane;
-#pragma unroll
-        for (int cc = 0; cc < NCH; ++cc) {
-#pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                float4 a[MT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = w[((i * NCH + cc) * KS + j) * 64];
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    float bv[NT];
-#pragma unroll
-                    for (int jn = 0; jn < NT; ++jn) bv[jn] = Bs[(cc * 8 + 2 * pp + krow) * G::WB + ncol + jn * 32 + j];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        const float av = pp == 0 ? a[i].x : pp == 1 ? a[i].y : pp == 2 ? a[i].z : a[i].w;
-#pragma unroll
-                        for (int jn = 0; jn < NT; ++jn)
-                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[jn], acc[i][jn], 0, 0, 0);
-                    }
-                }
-            }
-        }
+        gemm32_resident<KS, G::WB, 1, MT, NT, NCH>(p.w2 + lane, Bs + krow * G::WB + ncol, acc);
         float* __restrict__ yb = p.y + (long long)b * C * p.T;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -234,20 +277,7 @@ __global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairParams p
         f32x4 acc[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float4* __restrict__ w = p.w1 + lane;
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            const float4 a = w[j * 64];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float av = q == 0 ? a.x : q == 1 ? a.y : q == 2 ? a.z : a.w;
-#pragma unroll
-                for (int jn = 0; jn < NT; ++jn) {
-                    const float bv = As[(4 * q + krow) * G::WA + ncol + jn * 16 + j * DIL];
-                    acc[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[jn], 0, 0, 0);
-                }
-            }
-        }
+        gemm16_resident<KS, G::WA, DIL, NT>(p.w1 + lane, As + krow * G::WA + ncol, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = 4 * krow + r;
@@ -266,20 +296,7 @@ __global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairParams p
         f32x4 acc[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float4* __restrict__ w = p.w2 + lane;
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            const float4 a = w[j * 64];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float av = q == 0 ? a.x : q == 1 ? a.y : q == 2 ? a.z : a.w;
-#pragma unroll
-                for (int jn = 0; jn < NT; ++jn) {
-                    const float bv = Bs[(4 * q + krow) * G::WB + ncol + jn * 16 + j];
-                    acc[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[jn], 0, 0, 0);
-                }
-            }
-        }
+        gemm16_resident<KS, G::WB, 1, NT>(p.w2 + lane, Bs + krow * G::WB + ncol, acc);
         float* __restrict__ yb = p.y + (long long)b * C * p.T;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
