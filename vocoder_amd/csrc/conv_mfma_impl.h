@@ -39,7 +39,7 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
 
 // 8-channel sub-chunks staged per barrier (LDS budget 2 * 8*SUBS * W floats, <= 36 KiB)
 constexpr int subs_for(int ks, int w) {
-    int s = ks <= 4 ? 4 : 2;
+    int s = ks <= 2 ? 4 : 1;
     while (s > 1 && s * kChunk * w > 4608) s /= 2;
     return s;
 }

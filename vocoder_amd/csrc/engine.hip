@@ -253,6 +253,10 @@ struct fv_engine {
     Profiler prof;
     bool profiling = false;
     bool fuse_pairs = true;   // FV_NO_PAIR_FUSION=1 in the environment disables the fused (c1, c2) kernels (A/B runs)
+    bool branch_streams = true;   // FV_SINGLE_STREAM=1 runs the ResBlock branches back to back on the caller's stream
+    std::vector<hipStream_t> bstreams;   // nk-1 auxiliary streams (branch 0 runs on the caller's stream)
+    std::vector<hipEvent_t> bev_fork, bev_last;
+    fv_status ensure_branch_streams(int nk);
 
     // ---- weight lookup helpers (reference state-dict names) ----
     const HostTensor* find(const std::string& name) {
@@ -378,6 +382,9 @@ struct fv_engine {
     fv_status run_head(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
 
     ~fv_engine() {
+        for (auto st : bstreams) (void)hipStreamDestroy(st);
+        for (auto e : bev_fork) (void)hipEventDestroy(e);
+        for (auto e : bev_last) (void)hipEventDestroy(e);
         ups.destroy();
         cnx.destroy();
         head.destroy();
@@ -540,12 +547,43 @@ fv_status fv_engine::build_head(const std::string& pfx) {
 // ------------------------------------------------------------------------------------------------
 // forward passes
 // ------------------------------------------------------------------------------------------------
+// Workspace of the upsampler: cur / S / Y plus (XB, XT, XA) per concurrent branch = 3 + 3 * num_kernels buffers
+
+fv_status fv_engine::ensure_branch_streams(int nk) {
+    if ((int)bstreams.size() >= nk - 1 && !bev_fork.empty()) return FV_OK;
+    while ((int)bstreams.size() < nk - 1) {
+        hipStream_t st;
+        FV_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        bstreams.push_back(st);
+    }
+    const size_t stages = std::max<size_t>(ups.stages.size(), 1);
+    while (bev_fork.size() < stages) {
+        hipEvent_t e;
+        FV_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        bev_fork.push_back(e);
+    }
+    while (bev_last.size() < stages * (size_t)nk) {
+        hipEvent_t e;
+        FV_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        bev_last.push_back(e);
+    }
+    return FV_OK;
+}
+
 fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s) {
     const int64_t me = (ups.max_elems(T) * B + 63) / 64 * 64;
-    float* buf[6];
-    for (int i = 0; i < 6; ++i) buf[i] = ws + (size_t)i * me;
-    float *cur = buf[0], *S = buf[1], *XB = buf[2], *XT = buf[3], *XA = buf[4], *Y = buf[5];
+    const int nk = ups.cfg.num_kernels;
+    float *cur = ws, *S = ws + me, *Y = ws + 2 * me;
+    auto XB = [&](int j) { return ws + (size_t)(3 + 3 * j) * me; };
+    auto XT = [&](int j) { return ws + (size_t)(4 + 3 * j) * me; };
+    auto XA = [&](int j) { return ws + (size_t)(5 + 3 * j) * me; };
     fv_status st;
+    // The nk ResBlock branches of a stage are independent until the stack-mean: run them on their own streams
+    // (fork after the upsampler conv, join after the last branch) so that one branch's tail / barrier phases are
+    // filled by the others' workgroups.  The MRF accumulate into Y stays ordered j = 0, 1, 2 through events.
+    // Profiling runs stay on one stream so that per-kernel hipEvent durations do not overlap.
+    const bool multi = branch_streams && nk > 1 && !profiling;
+    if (multi && (st = ensure_branch_streams(nk))) return st;
     ConvRun r;
     r.batch = B;
     // conv_pre (hifigan.py:227)
@@ -554,7 +592,7 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
     r.t_in = T;
     if ((st = conv_layer_run(ups.conv_pre, r, s))) return st;
     int t = (int)ups.conv_pre.out_len(T);
-    const int nk = ups.cfg.num_kernels;
+    int stage_idx = 0;
     for (auto& stg : ups.stages) {
         // x = ups[i](silu(x))  — HiFiGAN (hifigan.py:230-231); BigVGAN has no pre-activation (bigvgan.py:355-356)
         r = ConvRun();
@@ -566,9 +604,28 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
         if ((st = conv_layer_run(stg->up, r, s))) return st;
         t = (int)stg->up.out_len(t);
         const int ch = stg->ch;
+        if (multi) FV_HIP_CHECK(hipEventRecord(bev_fork[stage_idx], s));
         // ParralelBlock / stack-mean of the three ResBlock1 / AMPBlock branches (hifigan.py:132-133, bigvgan.py:358-365)
         for (int j = 0; j < nk; ++j) {
             ResBranch& br = *stg->branches[j];
+            hipStream_t bs = (multi && j > 0) ? bstreams[j - 1] : s;
+            if (multi && j > 0) FV_HIP_CHECK(hipStreamWaitEvent(bs, bev_fork[stage_idx], 0));
+            const int bj = multi ? j : 0;   // single-stream: branches run back to back and share one buffer set
+            // ordering of the accumulate into Y: branch j's last kernel runs after branch j-1's
+            auto before_last = [&]() -> fv_status {
+                if (multi && j > 0) FV_HIP_CHECK(hipStreamWaitEvent(bs, bev_last[stage_idx * nk + j - 1], 0));
+                return FV_OK;
+            };
+            auto after_last = [&]() -> fv_status {
+                if (multi) FV_HIP_CHECK(hipEventRecord(bev_last[stage_idx * nk + j], bs));
+                return FV_OK;
+            };
+            int mode_last = OUT_SET;
+            float scale_last = 1.0f;
+            if (nk > 1) {
+                mode_last = j == 0 ? OUT_SET : OUT_ACCUM;
+                scale_last = (j == nk - 1) ? 1.0f / (float)nk : 1.0f;
+            }
             // HiFiGAN narrow stages: the whole (c1, c2) pair in one kernel, intermediate kept in LDS.  Not in place
             // (workgroups read their neighbours' halo), so the branch ping-pongs S -> XB -> XT -> Y.
             const bool fuse = !ups.bigvgan && pair_supported(ch, br.k, br.dil[0]) && pair_supported(ch, br.k, br.dil[1]) &&
@@ -577,43 +634,41 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 const float* src = S;
                 for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
                     const bool last = n == FV_MAX_DILATIONS - 1;
-                    float* dst = last ? Y : (n == 0 ? XB : XT);
-                    int mode = OUT_SET;
-                    float scale = 1.0f;
-                    if (last && nk > 1) {
-                        mode = j == 0 ? OUT_SET : OUT_ACCUM;
-                        scale = (j == nk - 1) ? 1.0f / (float)nk : 1.0f;
-                    }
-                    if ((st = conv_pair_run(br.c1[n], br.c2[n], src, dst, B, t, mode, scale, s))) return st;
+                    float* dst = last ? Y : (n == 0 ? XB(bj) : XT(bj));
+                    if (last && (st = before_last())) return st;
+                    if ((st = conv_pair_run(br.c1[n], br.c2[n], src, dst, B, t, last ? mode_last : OUT_SET,
+                                            last ? scale_last : 1.0f, bs)))
+                        return st;
                     src = dst;
                 }
+                if ((st = after_last())) return st;
                 continue;
             }
             for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
-                const float* src = n == 0 ? S : XB;
+                const float* src = n == 0 ? S : XB(bj);
                 const bool last = n == FV_MAX_DILATIONS - 1;
                 const float* c1_in = src;
                 if (ups.bigvgan) {
-                    FV_PROF(s, "aa_snake", 60.0 * B * ch * t, 8.0 * B * ch * t,
-                            launch_aa_snake(src, XA, br.act[2 * n].d_alpha, br.act[2 * n].d_inv_beta, br.act[2 * n].d_up,
-                                            br.act[2 * n].d_down, B, ch, t, s));
-                    c1_in = XA;
+                    FV_PROF(bs, "aa_snake", 60.0 * B * ch * t, 8.0 * B * ch * t,
+                            launch_aa_snake(src, XA(bj), br.act[2 * n].d_alpha, br.act[2 * n].d_inv_beta,
+                                            br.act[2 * n].d_up, br.act[2 * n].d_down, B, ch, t, bs));
+                    c1_in = XA(bj);
                 }
                 // xt = c1(act(x)); the second activation is fused into c1's epilogue for SiLU
                 r = ConvRun();
                 r.batch = B;
                 r.t_in = t;
                 r.x = c1_in;
-                r.y = XT;
+                r.y = XT(bj);
                 r.pre_act = ups.bigvgan ? FV_ACT_NONE : FV_ACT_SILU;
                 r.post_act = ups.bigvgan ? FV_ACT_NONE : FV_ACT_SILU;
-                if ((st = conv_layer_run(br.c1[n], r, s))) return st;
-                const float* c2_in = XT;
+                if ((st = conv_layer_run(br.c1[n], r, bs))) return st;
+                const float* c2_in = XT(bj);
                 if (ups.bigvgan) {
-                    FV_PROF(s, "aa_snake", 60.0 * B * ch * t, 8.0 * B * ch * t,
-                            launch_aa_snake(XT, XA, br.act[2 * n + 1].d_alpha, br.act[2 * n + 1].d_inv_beta,
-                                            br.act[2 * n + 1].d_up, br.act[2 * n + 1].d_down, B, ch, t, s));
-                    c2_in = XA;
+                    FV_PROF(bs, "aa_snake", 60.0 * B * ch * t, 8.0 * B * ch * t,
+                            launch_aa_snake(XT(bj), XA(bj), br.act[2 * n + 1].d_alpha, br.act[2 * n + 1].d_inv_beta,
+                                            br.act[2 * n + 1].d_up, br.act[2 * n + 1].d_down, B, ch, t, bs));
+                    c2_in = XA(bj);
                 }
                 // x = c2(act(xt)) + x ; the last pair of each branch accumulates the branch mean into Y
                 r = ConvRun();
@@ -622,26 +677,30 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 r.x = c2_in;
                 r.res = src;
                 if (!last) {
-                    r.y = XB;
+                    r.y = XB(bj);
                 } else {
                     r.y = Y;
-                    r.out_mode = j == 0 ? OUT_SET : OUT_ACCUM;
-                    r.out_scale = (j == nk - 1) ? 1.0f / (float)nk : 1.0f;
-                    if (nk == 1) r.out_mode = OUT_SET;
+                    r.out_mode = mode_last;
+                    r.out_scale = scale_last;
+                    if ((st = before_last())) return st;
                 }
-                if ((st = conv_layer_run(br.c2[n], r, s))) return st;
+                if ((st = conv_layer_run(br.c2[n], r, bs))) return st;
             }
+            if ((st = after_last())) return st;
         }
+        // join: the last branch's final kernel is ordered after every other branch's
+        if (multi) FV_HIP_CHECK(hipStreamWaitEvent(s, bev_last[stage_idx * nk + nk - 1], 0));
         std::swap(cur, Y);
+        ++stage_idx;
     }
     // activation_post -> conv_post -> tanh (hifigan.py:245-247 / bigvgan.py:367-369)
     const float* post_in = cur;
     int pre = FV_ACT_SILU;
     if (ups.bigvgan) {
         FV_PROF(s, "aa_snake", 60.0 * B * ups.post_cin * t, 8.0 * B * ups.post_cin * t,
-                launch_aa_snake(cur, XA, ups.act_post.d_alpha, ups.act_post.d_inv_beta, ups.act_post.d_up,
+                launch_aa_snake(cur, XA(0), ups.act_post.d_alpha, ups.act_post.d_inv_beta, ups.act_post.d_up,
                                 ups.act_post.d_down, B, ups.post_cin, t, s));
-        post_in = XA;
+        post_in = XA(0);
         pre = FV_ACT_NONE;
     }
     const int qk = ups.cfg.post_conv_kernel_size;
@@ -838,6 +897,7 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
     }
     e->cfg = *cfg;
     if (const char* v = std::getenv("FV_NO_PAIR_FUSION")) e->fuse_pairs = !(v[0] == '1');
+    if (const char* v = std::getenv("FV_SINGLE_STREAM")) e->branch_streams = !(v[0] == '1');
     *out = e;
     return FV_OK;
 }
@@ -922,7 +982,9 @@ FV_API int64_t fv_output_length(const fv_engine* e, int32_t t_in) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static size_t ups_ws_elems(const fv_engine* e, int B, int T) { return (size_t)6 * ((e->ups.max_elems(T) * B + 63) / 64 * 64); }
+static size_t ups_ws_elems(const fv_engine* e, int B, int T) {
+    return (size_t)(3 + 3 * e->ups.cfg.num_kernels) * ((e->ups.max_elems(T) * B + 63) / 64 * 64);
+}
 static size_t cnx_ws_elems(const fv_engine* e, int B, int T) {
     const size_t me = ((size_t)e->cnx.max_dim() * T * B + 63) / 64 * 64;
     return 2 * me + 4 * me;  // X, H, and the 4x hidden
