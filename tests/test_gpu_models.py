@@ -149,3 +149,36 @@ def test_vocos_24k_vs_oracle():
     y = _fwd(eng, mel)
     err = np.abs(y - ref).max()
     assert err <= TOL, f"vocos-24k max|d| = {err:.3e}"
+
+
+def test_graph_replay_and_branch_streams_match_first_eager_call():
+    """Calls 1-2 with the same buffers run eagerly (branch streams), call 3+ replays the captured hipGraph; new data written
+    into the same input buffer must flow through the replay."""
+    cfg = dict(syn.HIFIGAN_V1_44K)
+    sd = syn.hifigan_state_dict(cfg, seed=2)
+    eng = _hifigan_engine(cfg, sd)
+    mel_a = torch.from_numpy(syn.synthetic_mel(3, 80, 10, seed=1)).to(_dev())
+    mel_b = torch.from_numpy(syn.synthetic_mel(3, 80, 10, seed=2)).to(_dev())
+    x = mel_a.clone()
+    out = torch.empty((3, 1, 10 * 512), device=_dev())
+    eng(x, out)
+    torch.cuda.synchronize()
+    first = out.clone()
+    for _ in range(4):
+        eng(x, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, first)
+    x.copy_(mel_b)
+    eng(x, out)
+    torch.cuda.synchronize()
+    ref_b = orc.hifigan_forward(sd, cfg, mel_b.cpu().numpy())
+    assert np.abs(out.cpu().numpy() - ref_b).max() <= TOL
+    ref_a = orc.hifigan_forward(sd, cfg, mel_a.cpu().numpy())
+    assert np.abs(first.cpu().numpy() - ref_a).max() <= TOL
+    # on a user-provided non-default stream as well
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            eng(x, out)
+    s.synchronize()
+    assert np.abs(out.cpu().numpy() - ref_b).max() <= TOL

@@ -253,6 +253,25 @@ struct fv_engine {
     Profiler prof;
     bool profiling = false;
     bool fuse_pairs = true;   // FV_NO_PAIR_FUSION=1 in the environment disables the fused (c1, c2) kernels (A/B runs)
+    struct GraphKey {
+        const void* in;
+        void* out;
+        void* ws;
+        int batch, t_in;
+        hipStream_t stream;
+        bool operator==(const GraphKey& o) const {
+            return in == o.in && out == o.out && ws == o.ws && batch == o.batch && t_in == o.t_in && stream == o.stream;
+        }
+    };
+    struct GraphEntry {
+        GraphKey key;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+    };
+    std::vector<GraphEntry> graphs;
+    GraphKey last_key{};
+    bool have_last = false;
+    bool use_graph = true;        // FV_NO_GRAPH=1 disables hipGraph replay
     bool branch_streams = true;   // FV_SINGLE_STREAM=1 runs the ResBlock branches back to back on the caller's stream
     std::vector<hipStream_t> bstreams;   // nk-1 auxiliary streams (branch 0 runs on the caller's stream)
     std::vector<hipEvent_t> bev_fork, bev_last;
@@ -377,11 +396,16 @@ struct fv_engine {
     fv_status build_convnext(const std::string& pfx);
     fv_status build_head(const std::string& pfx);
 
+    fv_status run_model(const float* d_in, float* d_out, int batch, int t_in, float* ws, hipStream_t s);
     fv_status run_upsampler(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
     fv_status run_convnext(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
     fv_status run_head(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
 
     ~fv_engine() {
+        for (auto& g : graphs) {
+            (void)hipGraphExecDestroy(g.exec);
+            (void)hipGraphDestroy(g.graph);
+        }
         for (auto st : bstreams) (void)hipStreamDestroy(st);
         for (auto e : bev_fork) (void)hipEventDestroy(e);
         for (auto e : bev_last) (void)hipEventDestroy(e);
@@ -898,6 +922,7 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
     e->cfg = *cfg;
     if (const char* v = std::getenv("FV_NO_PAIR_FUSION")) e->fuse_pairs = !(v[0] == '1');
     if (const char* v = std::getenv("FV_SINGLE_STREAM")) e->branch_streams = !(v[0] == '1');
+    if (const char* v = std::getenv("FV_NO_GRAPH")) e->use_graph = !(v[0] == '1');
     *out = e;
     return FV_OK;
 }
@@ -1041,6 +1066,58 @@ FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32
         ProfGuard(fv_engine* e) { g_prof = e->profiling ? &e->prof : nullptr; }
         ~ProfGuard() { g_prof = nullptr; }
     } guard(e);
+
+    // hipGraph replay: a forward is ~110 launches plus fork/join events; at small batch the host launch cost dominates
+    // (p50 clip latency).  The launch sequence is static for a given (pointers, batch, frames, stream), so the second
+    // consecutive call with the same key is stream-captured (including the branch streams) and later calls replay it.
+    fv_engine::GraphKey key{d_in, d_out, d_workspace, batch, t_in, s};
+    const bool graphable = e->use_graph && !e->profiling && s != nullptr;
+    if (graphable) {
+        for (auto& g : e->graphs)
+            if (g.key == key) {
+                FV_HIP_CHECK(hipGraphLaunch(g.exec, s));
+                return FV_OK;
+            }
+        if (e->have_last && e->last_key == key) {
+            hipError_t be = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            if (be == hipSuccess) {
+                fv_status st = e->run_model(d_in, d_out, batch, t_in, ws, s);
+                hipGraph_t graph = nullptr;
+                hipError_t ee = hipStreamEndCapture(s, &graph);
+                if (st == FV_OK && ee == hipSuccess && graph) {
+                    hipGraphExec_t exec = nullptr;
+                    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                        if (e->graphs.size() >= 8) {
+                            (void)hipGraphExecDestroy(e->graphs.front().exec);
+                            (void)hipGraphDestroy(e->graphs.front().graph);
+                            e->graphs.erase(e->graphs.begin());
+                        }
+                        e->graphs.push_back({key, graph, exec});
+                        FV_HIP_CHECK(hipGraphLaunch(exec, s));
+                        return FV_OK;
+                    }
+                    (void)hipGraphDestroy(graph);
+                } else if (graph) {
+                    (void)hipGraphDestroy(graph);
+                }
+                (void)hipGetLastError();
+                e->use_graph = false;   // capture is not available in this context: stay eager from now on
+                if (st) return st;
+            } else {
+                (void)hipGetLastError();
+                e->use_graph = false;
+            }
+        }
+        e->last_key = key;
+        e->have_last = true;
+    }
+    return e->run_model(d_in, d_out, batch, t_in, ws, s);
+}
+
+}  // extern "C"
+
+fv_status fv_engine::run_model(const float* d_in, float* d_out, int batch, int t_in, float* ws, hipStream_t s) {
+    fv_engine* e = this;
     switch (e->cfg.model) {
         case FV_MODEL_HIFIGAN:
         case FV_MODEL_BIGVGAN: return e->run_upsampler(d_in, d_out, batch, t_in, ws, s);
@@ -1062,6 +1139,8 @@ FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32
     set_error("fv_forward: unknown model");
     return FV_ERR_INVALID;
 }
+
+extern "C" {
 
 // ---- per-launch profile ----
 FV_API fv_status fv_profile_begin(fv_engine* e) {

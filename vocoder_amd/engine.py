@@ -109,6 +109,7 @@ class Engine:
         self.in_channels = self._lib.fv_input_channels(self._h)
         self.out_channels = self._lib.fv_output_channels(self._h)
         self._ws: torch.Tensor | None = None
+        self._side: torch.cuda.Stream | None = None
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -142,8 +143,20 @@ class Engine:
         if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != x.device:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            check(self._lib.fv_forward(self._h, x.data_ptr(), out.data_ptr(), B, T, self._ws.data_ptr(),
-                                       self._ws.numel() * 4, _stream_ptr(x.device)))
+            cur = torch.cuda.current_stream(x.device)
+            if cur.cuda_stream == 0:
+                # The legacy default stream cannot be stream-captured, which would rule out the engine's hipGraph
+                # replay.  Run on an engine-owned side stream, ordered after / before the caller's stream.
+                if self._side is None or self._side.device != x.device:
+                    self._side = torch.cuda.Stream(x.device)
+                side = self._side
+                side.wait_stream(cur)
+                check(self._lib.fv_forward(self._h, x.data_ptr(), out.data_ptr(), B, T, self._ws.data_ptr(),
+                                           self._ws.numel() * 4, int(side.cuda_stream)))
+                cur.wait_stream(side)
+            else:
+                check(self._lib.fv_forward(self._h, x.data_ptr(), out.data_ptr(), B, T, self._ws.data_ptr(),
+                                           self._ws.numel() * 4, int(cur.cuda_stream)))
         return out
 
     __call__ = forward
