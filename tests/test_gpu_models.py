@@ -64,7 +64,8 @@ def test_hifigan_full_size_properties():
     assert np.array_equal(y, y_again)
     for i in (0, 17, 31):
         yi = _fwd(eng, mel[i:i + 1])
-        assert np.abs(yi[0] - y[i]).max() <= 1e-6
+        # a single clip dispatches the latency (split-K) kernels: same arithmetic, different summation order
+        assert np.abs(yi[0] - y[i]).max() <= 2e-5
     # first clip against the oracle on a prefix: the receptive field is finite (one-sided reach of the whole stack is
     # ~9 mel frames, dominated by the k=11, d=5 ResBlocks of stage 0), so a T=28 prefix run agrees with the full run
     # on the first 8 frames.

@@ -7,7 +7,7 @@
 namespace fv {
 
 void tile_dims(int cfg, int* m_blk, int* n_blk) {
-    static const int dims[TILE_COUNT][2] = {{128, 128}, {64, 256}, {32, 512}, {128, 64}, {32, 128}, {64, 128}};
+    static const int dims[TILE_COUNT][2] = {{128, 128}, {64, 256}, {32, 512}, {128, 64}, {32, 128}, {64, 128}, {32, 64}};
     *m_blk = dims[cfg][0];
     *n_blk = dims[cfg][1];
 }
@@ -130,11 +130,16 @@ static int choose_tile(int M, long long N, int batch) {
     const double cols_big = (double)tiles_big * nb_big, cols_small = (double)tiles_small * nb_small * 1.04;
     const long long blocks_big = tiles_big * m_blks * batch;
     // not enough workgroups to fill 256 CUs twice over, or a lot of padded columns -> smaller tile
-    if (blocks_big < 512 || cols_small < cols_big) return small;
+    if (blocks_big < 512 || cols_small < cols_big) {
+        // still fewer workgroups than CUs: 32 x 64 tiles with K split across the four waves (latency variant)
+        const long long blocks_small = tiles_small * m_blks * batch;
+        if (blocks_small < 200) return TILE_SPLITK_32x64;
+        return small;
+    }
     return big;
 }
 
-static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128"};
+static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64"};
 
 fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t stream) {
     if (!L.d_wp) {

@@ -37,6 +37,85 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     }
 }
 
+// Fused epilogue shared by the conv kernels: bias, layer-scale, residual, post-activation, MRF accumulate, polyphase
+// scatter.  acc follows the 32x32 MFMA C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][NT], int b, int mt0, int ncol0, int lane) {
+    float* __restrict__ yb = p.y + (long long)b * p.y_bstride;
+    const float* __restrict__ rb = p.res ? p.res + (long long)b * p.y_bstride : nullptr;
+    const bool accum = p.out_mode == OUT_ACCUM;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        // column part of the output offset (independent of the row) and its validity
+        int coff[NT];
+        bool cok[NT];
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) {
+            const int n = ncol0 + jn * 32;
+            if (p.convt) {
+                coff[jn] = n * p.u - p.pad_t;   // + phase added per row
+                cok[jn] = n < p.N;
+            } else {
+                coff[jn] = n;
+                cok[jn] = n < p.N;
+            }
+        }
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            // 4 rows (r & 3) x NT columns at a time: issue all residual / accumulate loads, then compute, then store
+            int off[4][NT];
+            bool ok[4][NT];
+            float rv[4][NT], yo[4][NT], bias[4], gm[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = (mt0 + i) * 32 + rr + 8 * rq + 4 * (lane >> 5);
+                const bool mok = m < p.M;
+                const int mc = mok ? m : 0;
+                bias[rr] = p.bias[mc];
+                gm[rr] = p.gamma ? p.gamma[mc] : 1.0f;
+                int row_off, ph = 0;   // per-item offsets fit 32 bits (C * T < 2^31)
+                if (p.convt) {
+                    const int co = mc / p.u;
+                    ph = mc - co * p.u;
+                    row_off = co * p.Tout;
+                } else {
+                    row_off = mc * p.N;
+                }
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    const int t = coff[jn] + ph;
+                    bool v = mok && cok[jn];
+                    if (p.convt) v = v && t >= 0 && t < p.Tout;
+                    ok[rr][jn] = v;
+                    off[rr][jn] = v ? row_off + t : 0;   // offset 0 is always a valid element
+                }
+            }
+            if (rb) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn) rv[rr][jn] = rb[off[rr][jn]];
+            }
+            if (accum) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn) yo[rr][jn] = yb[off[rr][jn]];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    float v = (acc[i][jn][rq * 4 + rr] + bias[rr]) * gm[rr];
+                    if (rb) v += rv[rr][jn];
+                    v = act_apply(v, p.post_act, p.slope);
+                    if (accum) v = (yo[rr][jn] + v) * p.out_scale;
+                    if (ok[rr][jn]) yb[off[rr][jn]] = v;
+                }
+        }
+    }
+}
+
 // 8-channel sub-chunks staged per barrier (LDS budget 2 * 8*SUBS * W floats, <= 36 KiB)
 constexpr int subs_for(int ks, int w) {
     int s = ks <= 2 ? 4 : 1;
@@ -199,80 +278,136 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
         }
     }
 
-    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5). ----
-    const int ncol0 = n0 + wn * (NT * 32) + (lane & 31);
-    float* __restrict__ yb = p.y + (long long)b * p.y_bstride;
-    const float* __restrict__ rb = p.res ? p.res + (long long)b * p.y_bstride : nullptr;
-    const bool accum = p.out_mode == OUT_ACCUM;
+    conv_epilogue<MT, NT>(p, acc, b, mt0, n0 + wn * (NT * 32) + (lane & 31), lane);
+}
+
+// Latency variant for launches that cannot fill the chip with regular tiles (small batch x short T): the workgroup
+// owns a 32 x 64 output tile and its four waves split K between them — wave w takes channel pair w of every
+// 8-channel chunk (k-steps stay whole, the staged window and the B-fragment reads are shared, each wave fetches only
+// its own dword of the packed weights).  Partial accumulators are reduced through LDS and wave 0 runs the epilogue.
+// 16x more workgroups than the 128 x 128 tile for the same problem.
+template <int KS, int DIL>
+__global__ __launch_bounds__(256, 4) void conv_mfma_splitk_kernel(const ConvParams p) {
+    constexpr int NT = 2, N_BLK = 64;
+    constexpr int SPAN = (KS - 1) * DIL;
+    constexpr int W = N_BLK + SPAN;
+    constexpr int TOT = kChunk * W;
+    constexpr int NE = (TOT + 255) / 256;
+    __shared__ float xs[2][TOT];
+    __shared__ float red[3][32][64];   // [wave-1][acc register][lane]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int bid = blockIdx.x;
+    const int n_tile = bid % p.n_tiles;
+    bid /= p.n_tiles;
+    const int m_blk = bid % p.m_blks;
+    const int b = bid / p.m_blks;
+    const int n0 = n_tile * N_BLK;
+    const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
+
+    f32x16 acc[1][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        // column part of the output offset (independent of the row) and its validity
-        int coff[NT];
-        bool cok[NT];
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int jn = 0; jn < NT; ++jn) {
-            const int n = ncol0 + jn * 32;
-            if (p.convt) {
-                coff[jn] = n * p.u - p.pad_t;   // + phase added per row
-                cok[jn] = n < p.N;
-            } else {
-                coff[jn] = n;
-                cok[jn] = n < p.N;
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    int st_off[NE];
+    const int tbase = n0 - p.pad_l;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        int e = tid + i * 256;
+        const bool in_tile = e < TOT;
+        e = in_tile ? e : TOT - 1;
+        const int r = e / W;
+        const int col = e - r * W;
+        const int t = tbase + col;
+        const bool ok = in_tile && t >= 0 && t < p.Tin;
+        const int tc = t < 0 ? 0 : (t > p.Tin - 1 ? p.Tin - 1 : t);
+        st_off[i] = ok ? r * p.Tin + tc : -1;
+    }
+    float stage[NE];
+    auto load_chunk = [&](int c) {
+        const int cbase = c * kChunk;
+        const float* __restrict__ xc = xb + (long long)cbase * p.Tin;
+        const int lim = (p.Cin - cbase) * p.Tin;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const bool ok = st_off[i] >= 0 && st_off[i] < lim;
+            const float v = xc[ok ? st_off[i] : 0];
+            stage[i] = ok ? v : 0.f;
+        }
+    };
+    auto store_chunk = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * 256;
+            if (e < TOT) dst[e] = act_apply(stage[i], p.pre_act, p.slope);
+        }
+    };
+
+    // this wave's dword of the packed float4 (channel pair `wave`)
+    const float* __restrict__ wlane = reinterpret_cast<const float*>(p.wp + lane) + wave;
+    auto load_a = [&](int c, int j) { return wlane[((long long)(m_blk * p.nchunk + c) * KS + j) * 256]; };
+    const int b_lane = (2 * wave + (lane >> 5)) * W + (lane & 31);
+    auto load_b = [&](float (&dst)[NT], const float* xsb, int j) {
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) dst[jn] = xsb[b_lane + jn * 32 + j * DIL];
+    };
+
+    // weights: a whole chunk's taps (KS dwords) are fetched one chunk ahead — with only NT MFMAs per tap a one-tap
+    // prefetch distance would be far shorter than the L2 latency
+    float a_cur[KS], a_nxt[KS];
+    float b_cur[NT], b_nxt[NT];
+    load_chunk(0);
+#pragma unroll
+    for (int j = 0; j < KS; ++j) a_cur[j] = load_a(0, j);
+    for (int c = 0; c < p.nchunk_real; ++c) {
+        float* xsb = xs[c & 1];
+        store_chunk(xsb);
+        __syncthreads();
+        const bool more = c + 1 < p.nchunk_real;
+        if (more) load_chunk(c + 1);
+        const int cn = more ? c + 1 : c;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) a_nxt[j] = load_a(cn, j);
+        load_b(b_cur, xsb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            if (j + 1 < KS) load_b(b_nxt, xsb, j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn)
+                acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], b_cur[jn], acc[0][jn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < KS) {
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) b_cur[jn] = b_nxt[jn];
             }
         }
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            // 4 rows (r & 3) x NT columns at a time: issue all residual / accumulate loads, then compute, then store
-            int off[4][NT];
-            bool ok[4][NT];
-            float rv[4][NT], yo[4][NT], bias[4], gm[4];
+        for (int j = 0; j < KS; ++j) a_cur[j] = a_nxt[j];
+    }
+
+    // reduce the four partial tiles
+    if (wave > 0) {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int m = (mt0 + i) * 32 + rr + 8 * rq + 4 * (lane >> 5);
-                const bool mok = m < p.M;
-                const int mc = mok ? m : 0;
-                bias[rr] = p.bias[mc];
-                gm[rr] = p.gamma ? p.gamma[mc] : 1.0f;
-                int row_off, ph = 0;   // per-item offsets fit 32 bits (C * T < 2^31)
-                if (p.convt) {
-                    const int co = mc / p.u;
-                    ph = mc - co * p.u;
-                    row_off = co * p.Tout;
-                } else {
-                    row_off = mc * p.N;
-                }
+        for (int jn = 0; jn < NT; ++jn)
 #pragma unroll
-                for (int jn = 0; jn < NT; ++jn) {
-                    const int t = coff[jn] + ph;
-                    bool v = mok && cok[jn];
-                    if (p.convt) v = v && t >= 0 && t < p.Tout;
-                    ok[rr][jn] = v;
-                    off[rr][jn] = v ? row_off + t : 0;   // offset 0 is always a valid element
-                }
-            }
-            if (rb) {
+            for (int r = 0; r < 16; ++r) red[wave - 1][jn * 16 + r][lane] = acc[0][jn][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
+        for (int w = 0; w < 3; ++w)
 #pragma unroll
-                    for (int jn = 0; jn < NT; ++jn) rv[rr][jn] = rb[off[rr][jn]];
-            }
-            if (accum) {
+            for (int jn = 0; jn < NT; ++jn)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int jn = 0; jn < NT; ++jn) yo[rr][jn] = yb[off[rr][jn]];
-            }
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                for (int jn = 0; jn < NT; ++jn) {
-                    float v = (acc[i][jn][rq * 4 + rr] + bias[rr]) * gm[rr];
-                    if (rb) v += rv[rr][jn];
-                    v = act_apply(v, p.post_act, p.slope);
-                    if (accum) v = (yo[rr][jn] + v) * p.out_scale;
-                    if (ok[rr][jn]) yb[off[rr][jn]] = v;
-                }
-        }
+                for (int r = 0; r < 16; ++r) acc[0][jn][r] += red[w][jn * 16 + r][lane];
+        conv_epilogue<1, NT>(p, acc, b, m_blk, n0 + (lane & 31), lane);
     }
 }
 
@@ -291,6 +426,9 @@ inline bool launch_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
         case TILE_128x64: launch_one<KS, DIL, 4, 1, 1, 2>(p, batch, s); return true;
         case TILE_32x128: launch_one<KS, DIL, 1, 4, 1, 1>(p, batch, s); return true;
         case TILE_64x128: launch_one<KS, DIL, 1, 4, 2, 1>(p, batch, s); return true;
+        case TILE_SPLITK_32x64:
+            hipLaunchKernelGGL((conv_mfma_splitk_kernel<KS, DIL>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
+            return true;
         default: return false;
     }
 }
