@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU (default 32 = BASELINE config)")
     ap.add_argument("--frames", type=int, default=T_MEL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the bounded CPU-oracle sample")
+    ap.add_argument("--cpu-clips", type=int, default=32, help="clips in the bounded CPU-oracle sample")
     ap.add_argument("--profile-json", default=None, help="also dump the per-kernel hipEvent table to this file")
     return ap.parse_args()
 
@@ -92,11 +92,16 @@ def roofline_from_profile(table: list[dict], repeats: int) -> dict:
     gbs = top["bytes_per_launch"] / t_s / 1e9
     t_mfma = top["flops_per_launch"] / (PEAK_MFMA_F32_TFLOPS * 1e12)
     t_hbm = top["bytes_per_launch"] / (PEAK_HBM_GBS * 1e9)
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.py);
+    # PMC counters cannot be read from inside this process, so this is looked up, not measured live
     traffic = None
-    tpath = os.path.join(REPO, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, when collected
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(top["kernel"])
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            from pmc_traffic import bench_key
+            ent = json.load(open(tpath)).get(bench_key(top["kernel"]))
+            traffic = ent["hbm_bytes_per_launch"] if ent else None
         except Exception:
             traffic = None
     if t_mfma >= t_hbm:

@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Throughput of the other BASELINE configs (not bench lines, context for DESIGN.md):
+config[2] BigVGAN 24 kHz B=64, config[3] Vocos 24 kHz B=128; plus per-kernel hipEvent tables."""
+import json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from vocoder_amd import _lib, synthetic as syn
+from vocoder_amd.engine import Engine, convnext_config, istft_head_config, upsampler_config
+
+def run(name, eng, mel, sr, steps=10):
+    out = torch.empty((mel.shape[0], 1, eng.output_length(mel.shape[2])), device="cuda")
+    for _ in range(3):
+        eng(mel, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng(mel, out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n = out.numel()
+    tab = eng.profile(mel, repeats=2)
+    tot = sum(r["total_ms"] for r in tab) / 2
+    top = sorted(tab, key=lambda r: -r["total_ms"])[:6]
+    print(json.dumps({"model": name, "batch": mel.shape[0], "ms_per_step": dt * 1e3, "samples_per_s": n / dt,
+                      "x_realtime": n / dt / sr, "finite": bool(torch.isfinite(out).all()),
+                      "serialized_kernel_ms": tot,
+                      "top_kernels": [(r["kernel"], round(r["total_ms"] / 2, 3), round(r["flops_per_launch"] / r["avg_ms"] / 1e9, 1)) for r in top]}))
+
+cfg = dict(syn.BIGVGAN_24K)
+eng = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=syn.bigvgan_state_dict(cfg, 0))
+run("bigvgan-24k", eng, torch.from_numpy(syn.synthetic_mel(64, 80, 94, 1)).cuda(), 24000)
+del eng
+cfg = dict(syn.VOCOS_24K)
+eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), head=istft_head_config(**cfg["head"]),
+             state_dict=syn.vocos_state_dict(cfg, 0))
+run("vocos-24k", eng, torch.from_numpy(syn.synthetic_mel(128, 80, 94, 2)).cuda(), 24000)

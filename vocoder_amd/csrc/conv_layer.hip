@@ -230,7 +230,8 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         if (r.res) elems += (double)L.c_out * tout;
         if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
         char lbl[160];
-        std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d%s", name, L.c_in, L.c_out, L.transposed ? " convT" : "");
+        std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d%s grid=%d", name, L.c_in, L.c_out, L.transposed ? " convT" : "",
+                      r.batch * p.m_blks * p.n_tiles);
         prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
     }
     FV_HIP_CHECK(hipGetLastError());
@@ -270,10 +271,13 @@ fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x
     std::snprintf(name, sizeof(name), "resblock_pair<k=%d d=%d C=%d>", c1.k, c1.dil, C);
     set_last_kernel(name);
     if (prof_idx >= 0) {
+        const int tt = 8192 / C - (c1.k - 1);   // PairGeom::TT
+        char lbl[128];
+        std::snprintf(lbl, sizeof(lbl), "%s grid=%d", name, batch * ((t + tt - 1) / tt));
         // algorithmic work: the two convs' MACs; bytes: x once + output once (+ accumulate operand)
         const double macs = 2.0 * C * C * c1.k * (double)t * batch;
         const double elems = (out_mode == OUT_ACCUM ? 3.0 : 2.0) * C * (double)t * batch;
-        prof_end(stream, prof_idx, name, 2.0 * macs, elems * 4.0 + 2.0 * C * C * c1.k * 4.0);
+        prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * 4.0 + 2.0 * C * C * c1.k * 4.0);
     }
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
