@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libfishvoc_hip.so")
+# FV_LIB_PATH points the loader at an experimental build (A/B kernel variants); default = the in-tree library
+LIB_PATH = os.environ.get("FV_LIB_PATH") or os.path.join(CSRC, "libfishvoc_hip.so")
 
 FV_ABI_VERSION = 1
 FV_MAX_STAGES = 8

@@ -19,7 +19,8 @@ void tile_dims(int cfg, int* m_blk, int* n_blk) {
 static void pack_conv_weights(const std::vector<float>& wc, int M, int Cin, int ks, int m_pad, int nchunk,
                               std::vector<float>& out) {
     const int mtiles = m_pad / 32;
-    out.assign((size_t)mtiles * nchunk * ks * 64 * 4, 0.f);
+    // + 8 zero k-steps after the last m-tile: the kernels' weight prefetch runs a few steps past the end
+    out.assign(((size_t)mtiles * nchunk * ks + 8) * 64 * 4, 0.f);
     for (int mt = 0; mt < mtiles; ++mt)
         for (int c = 0; c < nchunk; ++c)
             for (int j = 0; j < ks; ++j)

@@ -116,6 +116,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
 }
 
+#ifndef FV_X_DA
+#define FV_X_DA 3
+#endif
+constexpr int kWeightPrefetch = FV_X_DA;   // weight-fragment prefetch distance in k-steps (taps)
+
 // 8-channel sub-chunks staged per barrier (LDS budget 2 * 8*SUBS * W floats, <= 36 KiB)
 constexpr int subs_for(int ks, int w) {
     int s = ks <= 2 ? 4 : 1;
@@ -126,7 +131,11 @@ constexpr int subs_for(int ks, int w) {
 // min 3 waves per SIMD for the 64-accumulator tiles, 4 for the smaller ones: caps VGPR+AGPR so that several workgroups
 // stay resident per CU (their MFMA phases cover each other's staging / barrier phases)
 template <int KS, int DIL, int WM, int WN, int MT, int NT>
+#ifdef FV_X_WAVES4
+__global__ __launch_bounds__(256, (NT >= 4 ? 2 : 4)) void conv_mfma_kernel(const ConvParams p) {
+#else
 __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void conv_mfma_kernel(const ConvParams p) {
+#endif
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int N_BLK = WN * NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
@@ -135,9 +144,17 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     // barrier so that the MFMA run between two barriers stays long
     constexpr int SUBS = subs_for(KS, W);
     constexpr int CH = kChunk * SUBS;
-    constexpr int TOT = CH * W;
-    constexpr int NE = (TOT + 255) / 256;              // staged elements per thread
-    __shared__ float xs[2][TOT];
+#ifdef FV_X_PRIVATE
+    // experiment: every wave stages its own (NT*32 + SPAN)-column window -> no workgroup barrier in the main loop
+    constexpr bool PRIV = (KS >= 3);
+#else
+    constexpr bool PRIV = false;
+#endif
+    constexpr int WL = PRIV ? NT * 32 + SPAN : W;      // window width staged by one staging group
+    constexpr int TOT = CH * WL;
+    constexpr int NTHR = PRIV ? 64 : 256;              // threads per staging group
+    constexpr int NE = (TOT + NTHR - 1) / NTHR;        // staged elements per thread
+    __shared__ float xs[PRIV ? 4 : 1][2][TOT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -162,19 +179,22 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 
     // ---- staging plan: thread handles elements e = tid + i*256 of the [8][W] chunk window (same for every chunk) ----
     int st_off[NE];     // clamped offset (row * Tin + t) relative to the chunk's first channel row; < 0: always zero
-    const int tbase = n0 - p.pad_l;
+    const int sid = PRIV ? lane : tid;
+    const int tbase = n0 - p.pad_l + (PRIV ? wn * (NT * 32) : 0);
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        int e = tid + i * 256;
+        int e = sid + i * NTHR;
         const bool in_tile = e < TOT;
         e = in_tile ? e : TOT - 1;
-        const int r = e / W;
-        const int col = e - r * W;
+        const int r = e / WL;
+        const int col = e - r * WL;
         const int t = tbase + col;
         const bool ok = in_tile && t >= 0 && t < p.Tin;
         const int tc = t < 0 ? 0 : (t > p.Tin - 1 ? p.Tin - 1 : t);
         st_off[i] = ok ? r * p.Tin + tc : -1;
     }
+    // Staging is split in two halves one chunk apart: load_chunk only ISSUES the global loads (no dependent ALU, so no
+    // wait), store_chunk — one chunk of MFMAs later — applies the bounds mask and the activation and writes LDS.
     float stage[NE];
     auto load_chunk = [&](int c) {
         const int cbase = c * CH;
@@ -183,93 +203,89 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const bool ok = st_off[i] >= 0 && st_off[i] < lim;
-            const float v = xc[ok ? st_off[i] : 0];   // unconditional load on an always-valid address
-            stage[i] = ok ? v : 0.f;
+            stage[i] = xc[ok ? st_off[i] : 0];   // unconditional load on an always-valid address
         }
     };
-    auto store_chunk = [&](float* dst) {
-        if (p.pre_act == FV_ACT_SILU) {
+    auto store_chunk = [&](float* dst, int c) {
+        const int lim = (p.Cin - c * CH) * p.Tin;
 #pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int e = tid + i * 256;
-                const float v = stage[i];
-                if (e < TOT) dst[e] = v * __frcp_rn(1.0f + __expf(-v));
+        for (int i = 0; i < NE; ++i) {
+            const int e = sid + i * NTHR;
+            const bool ok = st_off[i] >= 0 && st_off[i] < lim;
+            float v = stage[i];
+            if (p.pre_act == FV_ACT_SILU) {
+                v = v * __frcp_rn(1.0f + __expf(-v));
+            } else if (p.pre_act != FV_ACT_NONE) {
+                v = act_apply(v, p.pre_act, p.slope);
             }
-        } else if (p.pre_act == FV_ACT_NONE) {
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int e = tid + i * 256;
-                if (e < TOT) dst[e] = stage[i];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int e = tid + i * 256;
-                // act(0) == 0 for every supported activation, so zero padding commutes with it
-                if (e < TOT) dst[e] = act_apply(stage[i], p.pre_act, p.slope);
-            }
+            if (e < TOT) dst[e] = ok ? v : 0.f;
         }
     };
 
     // A-operand: packed as [m_tile][chunk][tap][lane] float4 (4 channel pairs); wave-uniform base + lane
     const int mt0 = (m_blk * WM + wm) * MT;
     const float4* __restrict__ wlane = p.wp + lane;
-    auto load_a = [&](float4 (&dst)[MT], int c, int j) {
+    // weights of m-tile mt are one contiguous stream over the global k-step index g = sub_chunk * KS + tap
+    const long long wstride = (long long)p.nchunk * KS * 64;
+    auto load_a = [&](float4 (&dst)[MT], int g) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) dst[i] = wlane[((long long)((mt0 + i) * p.nchunk + c) * KS + j) * 64];
+        for (int i = 0; i < MT; ++i) dst[i] = wlane[(mt0 + i) * wstride + (long long)g * 64];
     };
-    const int b_lane = (lane >> 5) * W + wn * (NT * 32) + (lane & 31);
+    const int b_lane = (lane >> 5) * WL + (PRIV ? 0 : wn * (NT * 32)) + (lane & 31);
 
     auto load_b = [&](float (&dst)[4][NT], const float* xsb, int sub, int j) {
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-            for (int jn = 0; jn < NT; ++jn) dst[pp][jn] = xsb[b_lane + (sub * kChunk + 2 * pp) * W + jn * 32 + j * DIL];
+            for (int jn = 0; jn < NT; ++jn) dst[pp][jn] = xsb[b_lane + (sub * kChunk + 2 * pp) * WL + jn * 32 + j * DIL];
     };
 
-    // Software pipeline, one tap deep for both operands: while the 4*MT*NT MFMAs of tap j run, the weight fragment
-    // (global, L2) and the activation fragments (LDS) of tap j+1 are already in flight.  The sched_barriers pin that
-    // order; without them hipcc sinks the loads next to their first use and exposes the L2 / LDS latency.
-    float4 a_cur[MT], a_nxt[MT];
+    // Software pipeline.  Activation fragments (LDS) run one k-step ahead.  Weight fragments (global, L2) run DA k-steps
+    // ahead: vmcnt retires loads in issue order, so the first weight wait after the next chunk's staging loads were issued
+    // also waits for those (HBM latency); keeping DA weight loads older than the staging loads gives them DA taps
+    // (DA * 4*MT*NT MFMAs) to land.  The sched_barriers pin the issue order; without them hipcc sinks every load next to
+    // its first use.  Weight prefetch may run past the last k-step: the packed buffer carries DA+1 steps of padding.
+    constexpr int STEPS = SUBS * KS;
+    constexpr int DA = kWeightPrefetch;
+    float4 aq[DA + 1][MT];
     float b_cur[4][NT], b_nxt[4][NT];
     const int nch = (p.nchunk_real + SUBS - 1) / SUBS;   // LDS chunks; packed weights are padded to whole chunks
     load_chunk(0);
-    load_a(a_cur, 0, 0);
+#pragma unroll
+    for (int d = 0; d < DA; ++d) load_a(aq[d], d);
     for (int c = 0; c < nch; ++c) {
-        float* xsb = xs[c & 1];
-        store_chunk(xsb);
-        __syncthreads();
-        const bool more = c + 1 < nch;
-        if (more) load_chunk(c + 1);
+        float* xsb = xs[PRIV ? wave : 0][c & 1];
+        store_chunk(xsb, c);
+        if (!PRIV) __syncthreads();   // PRIV: a wave's LDS ops execute in order and nothing is shared across waves
+        if (c + 1 < nch) load_chunk(c + 1);
         load_b(b_cur, xsb, 0, 0);
 #pragma unroll
-        for (int st = 0; st < SUBS * KS; ++st) {
-            constexpr int LAST = SUBS * KS - 1;
-            const int sub = st / KS, j = st % KS;
-            if (st < LAST) {
-                const int sub_n = (st + 1) / KS, j_n = (st + 1) % KS;
-                load_a(a_nxt, c * SUBS + sub_n, j_n);
-                load_b(b_nxt, xsb, sub_n, j_n);
-            } else {
-                load_a(a_nxt, more ? (c + 1) * SUBS : c * SUBS, 0);   // first tap of the next chunk
-            }
-            (void)sub;
-            (void)j;
+        for (int st = 0; st < STEPS; ++st) {
+            load_a(aq[DA], c * STEPS + st + DA);
+            if (st + 1 < STEPS) load_b(b_nxt, xsb, (st + 1) / KS, (st + 1) % KS);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef FV_X_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const float av = pp == 0 ? a_cur[i].x : pp == 1 ? a_cur[i].y : pp == 2 ? a_cur[i].z : a_cur[i].w;
+                    const float av = pp == 0 ? aq[0][i].x : pp == 1 ? aq[0][i].y : pp == 2 ? aq[0][i].z : aq[0][i].w;
 #pragma unroll
                     for (int jn = 0; jn < NT; ++jn)
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[pp][jn], acc[i][jn], 0, 0, 0);
                 }
             }
+#ifdef FV_X_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
-            if (st < LAST) {
+            for (int d = 0; d < DA; ++d)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) aq[d][i] = aq[d + 1][i];
+            if (st + 1 < STEPS) {
 #pragma unroll
                 for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
