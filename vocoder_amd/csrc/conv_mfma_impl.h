@@ -55,6 +55,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             if (p.convt) {
                 coff[jn] = n * p.u - p.pad_t;   // + phase added per row
                 cok[jn] = n < p.N;
+            } else if (p.flat) {
+                const int bb = n / p.N;         // column = (batch item, t)
+                coff[jn] = bb * (int)p.y_bstride + (n - bb * p.N);
+                cok[jn] = n < p.n_total;
             } else {
                 coff[jn] = n;
                 cok[jn] = n < p.N;
@@ -165,9 +169,10 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     const int n_tile = bid % p.n_tiles;
     bid /= p.n_tiles;
     const int m_blk = bid % p.m_blks;
-    const int b = bid / p.m_blks;
+    const int b = bid / p.m_blks;      // 0 in flat mode (the grid then has no batch factor)
     const int n0 = n_tile * N_BLK;
     const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
+    const bool flat = KS == 1 && p.flat;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -179,6 +184,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 
     // ---- staging plan: thread handles elements e = tid + i*256 of the [8][W] chunk window (same for every chunk) ----
     int st_off[NE];     // clamped offset (row * Tin + t) relative to the chunk's first channel row; < 0: always zero
+    int st_row[KS == 1 ? NE : 1];   // ks == 1 only: channel row inside the chunk (the offset may carry a batch term)
     const int sid = PRIV ? lane : tid;
     const int tbase = n0 - p.pad_l + (PRIV ? wn * (NT * 32) : 0);
 #pragma unroll
@@ -188,10 +194,19 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
         e = in_tile ? e : TOT - 1;
         const int r = e / WL;
         const int col = e - r * WL;
-        const int t = tbase + col;
-        const bool ok = in_tile && t >= 0 && t < p.Tin;
+        int t = tbase + col;
+        int boff = 0;
+        bool ok = in_tile;
+        if (flat) {   // column = (batch item, t)
+            ok = ok && t < p.n_total;
+            const int bb = t / p.N;
+            t -= bb * p.N;
+            boff = bb * (int)p.x_bstride;
+        }
+        ok = ok && t >= 0 && t < p.Tin;
         const int tc = t < 0 ? 0 : (t > p.Tin - 1 ? p.Tin - 1 : t);
-        st_off[i] = ok ? r * p.Tin + tc : -1;
+        st_off[i] = ok ? boff + r * p.Tin + tc : -1;
+        if (KS == 1) st_row[i < NE ? i : 0] = r;
     }
     // Staging is split in two halves one chunk apart: load_chunk only ISSUES the global loads (no dependent ALU, so no
     // wait), store_chunk — one chunk of MFMAs later — applies the bounds mask and the activation and writes LDS.
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
         const int lim = (p.Cin - cbase) * p.Tin;   // offsets >= lim belong to zero-padded channels (>= Cin)
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const bool ok = st_off[i] >= 0 && st_off[i] < lim;
+            const bool ok = st_off[i] >= 0 && (KS == 1 ? st_row[KS == 1 ? i : 0] < p.Cin - cbase : st_off[i] < lim);
             stage[i] = xc[ok ? st_off[i] : 0];   // unconditional load on an always-valid address
         }
     };
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int e = sid + i * NTHR;
-            const bool ok = st_off[i] >= 0 && st_off[i] < lim;
+            const bool ok = st_off[i] >= 0 && (KS == 1 ? st_row[KS == 1 ? i : 0] < p.Cin - c * CH : st_off[i] < lim);
             float v = stage[i];
             if (p.pre_act == FV_ACT_SILU) {
                 v = v * __frcp_rn(1.0f + __expf(-v));

@@ -74,6 +74,8 @@ struct ConvParams {
     int convt;           // scatter store for the transposed conv
     int u, pad_t, Tout, Cout;
     long long x_bstride, y_bstride;
+    int flat;            // pointwise convs (ks == 1): GEMM columns run over the flattened (batch, time) axis
+    int n_total;         // flat: batch * N
 };
 
 struct ConvLayer {

@@ -225,8 +225,88 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
     }
 }
 
+// Register-resident variant (C <= 1024): 16 time columns x 16 channel groups per workgroup; each thread evaluates the
+// depthwise FIR once for its C/16 channels and keeps the values in registers across the mean / variance / normalise
+// passes (the kernel above re-evaluates the FIR three times and has 6x fewer threads per column).
+constexpr int DWLN_MAXPER = 64;
+__global__ __launch_bounds__(256) void dwconv_ln_reg_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
+                                                            const float* __restrict__ dw_b,
+                                                            const float* __restrict__ ln_w,
+                                                            const float* __restrict__ ln_b, float* __restrict__ y, int C,
+                                                            int T, int k, float eps, int n_tiles) {
+    __shared__ float red[16][17];
+    const int col = threadIdx.x & 15, cg = threadIdx.x >> 4;
+    const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
+    const int t = tile * 16 + col;
+    const bool live = t < T;
+    const int tc = live ? t : T - 1;
+    const int pad = (k - 1) / 2;
+    const float* xb = x + (long long)b * C * T;
+    const int per = (C + 15) / 16;
+    float h[DWLN_MAXPER];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < DWLN_MAXPER; ++q) {
+        h[q] = 0.f;
+        const int c = cg + 16 * q;
+        if (q < per && c < C) {
+            const float* xr = xb + (long long)c * T;
+            float v;
+            if (dw_w) {
+                v = dw_b ? dw_b[c] : 0.f;
+                const float* w = dw_w + (long long)c * k;
+                for (int j = 0; j < k; ++j) {
+                    const int tt = tc + j - pad;
+                    const float xv = xr[tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt)];
+                    v = fmaf(w[j], (tt >= 0 && tt < T) ? xv : 0.f, v);
+                }
+            } else {
+                v = xr[tc];
+            }
+            h[q] = v;
+            s += v;
+        }
+    }
+    red[cg][col] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) mean += red[g][col];
+    mean /= (float)C;
+    __syncthreads();
+    float qv = 0.f;
+#pragma unroll
+    for (int q = 0; q < DWLN_MAXPER; ++q) {
+        const int c = cg + 16 * q;
+        if (q < per && c < C) {
+            const float d = h[q] - mean;
+            qv = fmaf(d, d, qv);
+        }
+    }
+    red[cg][col] = qv;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) var += red[g][col];
+    var /= (float)C;
+    const float inv = 1.0f / sqrtf(var + eps);
+    float* yb = y + (long long)b * C * T;
+#pragma unroll
+    for (int q = 0; q < DWLN_MAXPER; ++q) {
+        const int c = cg + 16 * q;
+        if (q < per && c < C && live) yb[(long long)c * T + t] = (h[q] - mean) * inv * ln_w[c] + ln_b[c];
+    }
+}
+
 fv_status launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                            float* y, int B, int C, int T, int k, float eps, hipStream_t s) {
+    if (C <= 16 * DWLN_MAXPER) {
+        const int n16 = (T + 15) / 16;
+        hipLaunchKernelGGL(dwconv_ln_reg_kernel, dim3(B * n16), dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, k, eps,
+                           n16);
+        FV_HIP_CHECK(hipGetLastError());
+        return FV_OK;
+    }
     const int n_tiles = (T + 31) / 32;
     hipLaunchKernelGGL(dwconv_ln_kernel, dim3(B * n_tiles), dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, k, eps,
                        n_tiles);
