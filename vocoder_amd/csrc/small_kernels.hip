@@ -100,13 +100,33 @@ fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, 
 // ---------------------------------------------------------------------------------------------
 constexpr int AA_TT = 1024;
 
+// sin(z)^2 with a three-constant Cody-Waite reduction to [-pi/2, pi/2] and an odd degree-11 polynomial: |error| < 2e-7 for
+// |z| < 1e3 (the snake argument alpha*u stays far below that).  libm's sinf costs ~4x more VALU work and made this
+// kernel compute- instead of bandwidth-bound.  The sign lost by the reduction does not matter for the square.
+__device__ __forceinline__ float sin_squared(float z) {
+    const float k = rintf(z * 0.318309886183790672f);
+    float r = fmaf(k, -3.140625f, z);                         // pi split in three short constants: k * c exact
+    r = fmaf(k, -9.67502593994140625e-4f, r);
+    r = fmaf(k, -1.509957990978376432e-7f, r);
+    const float r2 = r * r;
+    float p = fmaf(r2, -2.50521083854417188e-8f, 2.75573192239858925e-6f);
+    p = fmaf(r2, p, -1.98412698412698413e-4f);
+    p = fmaf(r2, p, 8.33333333333333322e-3f);
+    p = fmaf(r2, p, -1.66666666666666657e-1f);
+    const float sn = fmaf(r * r2, p, r);
+    return sn * sn;
+}
+
 __global__ __launch_bounds__(256) void aa_snake_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ alpha_eff,
                                                        const float* __restrict__ inv_beta,
                                                        const float* __restrict__ up_taps,
                                                        const float* __restrict__ down_taps, int C, int T, int n_tiles) {
+    // xs[m] = x[clamp(t0 - 6 + m)];  AE[m] / AO[m] = activated even / odd up-sampled sample of input position
+    // h = t0 - 3 + m (de-interleaved so that phase 3 reads consecutive addresses: no bank conflicts, no lane divergence)
     __shared__ float xs[AA_TT + 16];
-    __shared__ float as[2 * AA_TT + 16];
+    __shared__ float AE[AA_TT + 8];
+    __shared__ float AO[AA_TT + 8];
     __shared__ float tp[24];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x % n_tiles;
@@ -116,41 +136,47 @@ __global__ __launch_bounds__(256) void aa_snake_kernel(const float* __restrict__
     const float* xr = x + row * T;
     if (tid < 12) tp[tid] = up_taps[tid];
     else if (tid < 24) tp[tid] = down_taps[tid - 12];
-    // x window: indices t0-6 .. t0+AA_TT+6 (clamped = replicate padding)
     for (int e = tid; e < AA_TT + 13; e += 256) {
         int t = t0 - 6 + e;
-        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);   // replicate padding of the up-sampler input
         xs[e] = xr[t];
     }
     __syncthreads();
     const float al = alpha_eff[c], ib = inv_beta[c];
-    // activated up-sampled signal for n in [2*t0 - 5, 2*(t0+AA_TT) + 6): as[e] <-> n = 2*t0 - 5 + e
-    const int T2 = 2 * T;
-    for (int e = tid; e < 2 * AA_TT + 11; e += 256) {
-        int n = 2 * t0 - 5 + e;
-        n = n < 0 ? 0 : (n > T2 - 1 ? T2 - 1 : n);   // replicate padding of the down-sampler input
-        const int h = n >> 1;
-        // polyphase taps: even n uses odd taps j=1,3,..,11 at x[h + (5-j)/2 ...]; odd n uses even taps
-        float u = 0.f;
-        const int xi = h - t0 + 6;  // position of x[h] in xs
-        if ((n & 1) == 0) {
+    // up-sample (polyphase: even output n = 2h uses odd taps at x[h+2 .. h-3], odd output uses even taps at x[h+3 .. h-2]),
+    // activate, for h = t0 - 3 .. t0 + AA_TT + 2
+    for (int m = tid; m < AA_TT + 6; m += 256) {
+        const int h = t0 - 3 + m;
+        const int hc = h < 0 ? 0 : (h > T - 1 ? T - 1 : h);
+        const int xi = hc - t0 + 6;   // position of x[hc] in xs
+        float ue = 0.f, uo = 0.f;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) u = fmaf(tp[2 * q + 1], xs[xi + 2 - q], u);   // j=2q+1 -> src h + 2 - q
-        } else {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) u = fmaf(tp[2 * q], xs[xi + 3 - q], u);       // j=2q   -> src h + 3 - q
+        for (int q = 0; q < 6; ++q) {
+            ue = fmaf(tp[2 * q + 1], xs[xi + 2 - q], ue);
+            uo = fmaf(tp[2 * q], xs[xi + 3 - q], uo);
         }
-        u *= 2.0f;
-        const float sn = sinf(u * al);
-        as[e] = fmaf(ib, sn * sn, u);
+        ue *= 2.0f;
+        uo *= 2.0f;
+        float ae = fmaf(ib, sin_squared(ue * al), ue);
+        float ao = fmaf(ib, sin_squared(uo * al), uo);
+        // replicate padding of the down-sampler input: n < 0 -> a[0] (even sample of h = 0), n > 2T-1 -> a[2T-1]
+        if (h < 0) ao = ae;
+        if (h > T - 1) ae = ao;
+        AE[m] = ae;
+        AO[m] = ao;
     }
     __syncthreads();
+    // y[t0 + i] = sum_j down[j] * a[2(t0+i) + j - 5]:  j odd -> even sample of h = t0 + i + (j-5)/2,  j even -> odd sample
+    // of h = t0 + i + (j-6)/2
     for (int i = tid; i < AA_TT; i += 256) {
         const int t = t0 + i;
         if (t >= T) break;
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) acc = fmaf(tp[12 + j], as[2 * i + j], acc);   // n = 2t + j - 5 -> e = 2i + j
+        for (int q = 0; q < 6; ++q) {
+            acc = fmaf(tp[12 + 2 * q + 1], AE[i + q + 1], acc);   // h - (t0-3) = i + q - 2 + 3
+            acc = fmaf(tp[12 + 2 * q], AO[i + q], acc);           // h - (t0-3) = i + q - 3 + 3
+        }
         y[row * T + t] = acc;
     }
 }
