@@ -128,14 +128,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run: one process per GPU
         import torch.distributed as dist  # noqa: PLC0415
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
     cfg = dict(syn.HIFIGAN_V1_44K)
     sd = syn.hifigan_state_dict(cfg, seed=0) if rank == 0 else None
-    if world > 1:
+    if dist is not None:
         from vocoder_amd.sharding import broadcast_state_dict
         sd_t = broadcast_state_dict(sd, src=0, device=dev)    # one-time weight fan-out (56 MB) over RCCL
         sd_eng = sd_t

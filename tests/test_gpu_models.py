@@ -183,3 +183,31 @@ def test_graph_replay_and_branch_streams_match_first_eager_call():
             eng(x, out)
     s.synchronize()
     assert np.abs(out.cpu().numpy() - ref_b).max() <= TOL
+
+
+def test_long_clip_and_odd_lengths_vs_oracle():
+    """A 35 s clip at hop 16 (T_mel = 1501, prime-ish) and a 2-frame clip through the tiny config: exercises many tiles,
+    ragged last tiles in every stage and the fused-pair kernels' halo logic at both ends."""
+    g = load_golden("hifigan_tiny.npz")
+    cfg = g["cfg"]
+    sd = syn.hifigan_state_dict(cfg, 12)
+    eng = _hifigan_engine(cfg, sd)
+    for B, T in ((1, 1501), (3, 2), (2, 257)):
+        mel = syn.synthetic_mel(B, cfg["num_mels"], T, seed=T)
+        ref = orc.hifigan_forward(sd, cfg, mel)
+        y = _fwd(eng, mel)
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() <= TOL, (B, T, float(np.abs(y - ref).max()))
+
+
+def test_narrow_stage_configs_use_fused_pairs_and_match():
+    """C0 = 256 -> stages of 128, 64, 32, 16 channels with k in (3, 7, 11): the 32/16-channel stages run the fused
+    (c1, c2) pair kernels (16x16x4 and 32x32x2 MFMA variants)."""
+    cfg = dict(hop_length=32, upsample_rates=[2, 2, 2, 4], upsample_kernel_sizes=[4, 4, 4, 8],
+               resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=24,
+               upsample_initial_channel=256, use_template=False, pre_conv_kernel_size=7, post_conv_kernel_size=7)
+    sd = syn.hifigan_state_dict(cfg, 21)
+    mel = syn.synthetic_mel(2, 24, 70, seed=3)
+    ref = orc.hifigan_forward(sd, cfg, mel)
+    y = _fwd(_hifigan_engine(cfg, sd), mel)
+    assert np.abs(y - ref).max() <= TOL

@@ -127,6 +127,11 @@ bool launch_conv_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_misc(const ConvParams& p, int cfg, int batch, hipStream_t s);   // k=2, 4, 5, 13 ...
 bool launch_conv_generic(const ConvParams& p, int cfg, int batch, hipStream_t s, size_t* lds_bytes);
 
+#ifndef FV_X_PAIRCOLS
+#define FV_X_PAIRCOLS 4096
+#endif
+constexpr int kPairCols = FV_X_PAIRCOLS;   // c1 columns per workgroup x channels (LDS budget of the fused pair kernel)
+
 // Fused ResBlock (c1, c2) pair for narrow stages: y = x + c2(silu(c1(silu(x))))  (resblock_pair.hip)
 struct PairParams {
     const float* x;       // (B, C, T)

@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int KS, int DIL, int C>
 struct PairGeom {
-    static constexpr int W1 = 8192 / C;                 // c1 output columns per workgroup (512 / 256 / 128)
+    static constexpr int W1 = kPairCols / C;            // c1 output columns per workgroup (256 at C=16, 128 at C=32: ~40 KB of LDS, 4 workgroups per CU)
     static constexpr int TT = W1 - (KS - 1);            // final output columns per workgroup
     static constexpr int H1 = (KS - 1) / 2 * DIL, H2 = (KS - 1) / 2, HP = H1 + H2;
     static constexpr int WA_RAW = W1 + (KS - 1) * DIL;  // staged x columns
