@@ -26,6 +26,7 @@
 namespace fv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
@@ -122,6 +123,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 
 #ifndef FV_X_DA
 #define FV_X_DA 3
+#endif
+#ifndef FV_X_ABLATE
+#define FV_X_ABLATE 0   // experiments only: bit 0 no weight loads, 1 no LDS fragment reads, 2 no staging, 3 no barrier
 #endif
 constexpr int kWeightPrefetch = FV_X_DA;   // weight-fragment prefetch distance in k-steps (taps)
 
@@ -239,12 +243,22 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 
     // A-operand: packed as [m_tile][chunk][tap][lane] float4 (4 channel pairs); wave-uniform base + lane
     const int mt0 = (m_blk * WM + wm) * MT;
-    const float4* __restrict__ wlane = p.wp + lane;
-    // weights of m-tile mt are one contiguous stream over the global k-step index g = sub_chunk * KS + tap
-    const long long wstride = (long long)p.nchunk * KS * 64;
-    auto load_a = [&](float4 (&dst)[MT], int g) {
+    // Weights of m-tile mt are one contiguous stream over the global k-step index g = sub_chunk * KS + tap.  They are
+    // fetched with raw buffer loads: descriptor + wave-uniform byte offset in SGPRs, the per-lane part (lane * 16 B) in
+    // one constant VGPR — no 64-bit VALU address arithmetic in the MFMA loop (it cost ~10 % of the kernel as flat loads).
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+    const int wvoff = lane * 16;
+    const int wstride_b = p.nchunk * KS * 1024;   // bytes per m-tile (64 lanes x 16 B per k-step)
+    // byte offset of k-step g of this wave's m-tile i = wbase[i] + g * 1024, with wbase[i] held in an SGPR
+    int wbase[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) dst[i] = wlane[(mt0 + i) * wstride + (long long)g * 64];
+    for (int i = 0; i < MT; ++i) wbase[i] = __builtin_amdgcn_readfirstlane((mt0 + i) * wstride_b);
+    auto load_a = [&](float4 (&dst)[MT], int goff_b) {   // goff_b = g * 1024, wave-uniform
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wbase[i] + goff_b, 0);
+            dst[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
     };
     const int b_lane = (lane >> 5) * WL + (PRIV ? 0 : wn * (NT * 32)) + (lane & 31);
 
@@ -267,17 +281,40 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     const int nch = (p.nchunk_real + SUBS - 1) / SUBS;   // LDS chunks; packed weights are padded to whole chunks
     load_chunk(0);
 #pragma unroll
-    for (int d = 0; d < DA; ++d) load_a(aq[d], d);
+    for (int d = 0; d < DA; ++d) load_a(aq[d], d * 1024);
     for (int c = 0; c < nch; ++c) {
         float* xsb = xs[PRIV ? wave : 0][c & 1];
+#if !(FV_X_ABLATE & 4)
         store_chunk(xsb, c);
+#endif
+#if !(FV_X_ABLATE & 8)
         if (!PRIV) __syncthreads();   // PRIV: a wave's LDS ops execute in order and nothing is shared across waves
+#endif
+#if !(FV_X_ABLATE & 4)
         if (c + 1 < nch) load_chunk(c + 1);
+#endif
+        // readfirstlane: c is wave-uniform, this makes the weight offsets provably so (else hipcc wraps every buffer
+        // load in a waterfall loop)
+        const int gchunk_b = __builtin_amdgcn_readfirstlane((c * STEPS + DA) * 1024);
         load_b(b_cur, xsb, 0, 0);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
-            load_a(aq[DA], c * STEPS + st + DA);
+#if (FV_X_ABLATE & 1)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) aq[DA][i] = make_float4(0.5f, 0.25f, -0.5f, 0.125f);   // ablation: no weight loads
+#else
+            load_a(aq[DA], gchunk_b + st * 1024);
+#endif
+#if (FV_X_ABLATE & 2)
+            if (st + 1 < STEPS) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn) b_nxt[pp][jn] = (float)(lane + pp);   // ablation: no LDS fragment reads
+            }
+#else
             if (st + 1 < STEPS) load_b(b_nxt, xsb, (st + 1) / KS, (st + 1) % KS);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #ifdef FV_X_SETPRIO
             __builtin_amdgcn_s_setprio(1);
@@ -379,9 +416,14 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_splitk_kernel(const ConvPara
         }
     };
 
-    // this wave's dword of the packed float4 (channel pair `wave`)
-    const float* __restrict__ wlane = reinterpret_cast<const float*>(p.wp + lane) + wave;
-    auto load_a = [&](int c, int j) { return wlane[((long long)(m_blk * p.nchunk + c) * KS + j) * 256]; };
+    // this wave's dword of the packed float4 (channel pair `wave`), by raw buffer loads (SGPR base + constant VGPR part)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+    const int wvoff = lane * 16 + wave * 4;
+    const int wtile_b = __builtin_amdgcn_readfirstlane(m_blk * p.nchunk * KS * 1024);
+    auto load_a = [&](int c, int j) {
+        const int soff = __builtin_amdgcn_readfirstlane(wtile_b + (c * KS + j) * 1024);
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, wvoff, soff, 0));
+    };
     const int b_lane = (2 * wave + (lane >> 5)) * W + (lane & 31);
     auto load_b = [&](float (&dst)[NT], const float* xsb, int j) {
 #pragma unroll

@@ -69,14 +69,20 @@ __device__ __forceinline__ void stage_window(const float* __restrict__ xb, float
 // (bsrc already carries the lane's k-half row and column).  One step (= one tap of one 8-channel sub-chunk) deep software
 // pipeline on both operands, pinned with sched_barriers (see conv_mfma_impl.h).
 template <int KS, int STRIDE, int DILX, int MT, int NT, int NCH>
-__device__ __forceinline__ void gemm32_resident(const float4* __restrict__ w, const float* __restrict__ bsrc,
+__device__ __forceinline__ void gemm32_resident(const float4* __restrict__ w, int lane, const float* __restrict__ bsrc,
                                                 f32x16 (&acc)[MT][NT]) {
     constexpr int STEPS = NCH * KS;
     float4 a_cur[MT], a_nxt[MT];
     float b_cur[4][NT], b_nxt[4][NT];
+    // weights by raw buffer loads: descriptor + constant byte offset in SGPRs, lane * 16 B in one VGPR (no VALU addressing)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7fffffff, 0x00020000);
+    const int voff = lane * 16;
     auto load_a = [&](float4 (&dst)[MT], int st) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) dst[i] = w[(i * STEPS + st) * 64];   // [(i*NCH + cc)*KS + j] == i*STEPS + st
+        for (int i = 0; i < MT; ++i) {   // [(i*NCH + cc)*KS + j] == i*STEPS + st
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (i * STEPS + st) * 1024, 0);
+            dst[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
     };
     auto load_b = [&](float (&dst)[4][NT], int st) {
         const int cc = st / KS, j = st % KS;
@@ -117,7 +123,14 @@ __device__ __forceinline__ void gemm32_resident(const float4* __restrict__ w, co
 
 // 16-channel variant on v_mfma_f32_16x16x4_f32: B element = bsrc[(4q)*STRIDE + jn*16 + j*DILX]
 template <int KS, int STRIDE, int DILX, int NT>
-__device__ __forceinline__ void gemm16_resident(const float4* __restrict__ w, const float* __restrict__ bsrc, f32x4 (&acc)[NT]) {
+__device__ __forceinline__ void gemm16_resident(const float4* __restrict__ w, int lane, const float* __restrict__ bsrc,
+                                                f32x4 (&acc)[NT]) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7fffffff, 0x00020000);
+    const int voff = lane * 16;
+    auto load_w = [&](int j) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * 1024, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
     float4 a_cur, a_nxt;
     float b_cur[4][NT], b_nxt[4][NT];
     auto load_b = [&](float (&dst)[4][NT], int j) {
@@ -126,12 +139,12 @@ __device__ __forceinline__ void gemm16_resident(const float4* __restrict__ w, co
 #pragma unroll
             for (int jn = 0; jn < NT; ++jn) dst[q][jn] = bsrc[(4 * q) * STRIDE + jn * 16 + j * DILX];
     };
-    a_cur = w[0];
+    a_cur = load_w(0);
     load_b(b_cur, 0);
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
         if (j + 1 < KS) {
-            a_nxt = w[(j + 1) * 64];
+            a_nxt = load_w(j + 1);
             load_b(b_nxt, j + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -188,7 +201,7 @@ __global__ __launch_bounds__(256) void resblock_pair32_kernel(const PairParams p
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        gemm32_resident<KS, G::WA, DIL, MT, NT, NCH>(p.w1 + lane, As + krow * G::WA + ncol, acc);
+        gemm32_resident<KS, G::WA, DIL, MT, NT, NCH>(p.w1, lane, As + krow * G::WA + ncol, acc);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(256) void resblock_pair32_kernel(const PairParams p
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        gemm32_resident<KS, G::WB, 1, MT, NT, NCH>(p.w2 + lane, Bs + krow * G::WB + ncol, acc);
+        gemm32_resident<KS, G::WB, 1, MT, NT, NCH>(p.w2, lane, Bs + krow * G::WB + ncol, acc);
         float* __restrict__ yb = p.y + (long long)b * C * p.T;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -277,7 +290,7 @@ __global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairParams p
         f32x4 acc[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm16_resident<KS, G::WA, DIL, NT>(p.w1 + lane, As + krow * G::WA + ncol, acc);
+        gemm16_resident<KS, G::WA, DIL, NT>(p.w1, lane, As + krow * G::WA + ncol, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = 4 * krow + r;
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairParams p
         f32x4 acc[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm16_resident<KS, G::WB, 1, NT>(p.w2 + lane, Bs + krow * G::WB + ncol, acc);
+        gemm16_resident<KS, G::WB, 1, NT>(p.w2, lane, Bs + krow * G::WB + ncol, acc);
         float* __restrict__ yb = p.y + (long long)b * C * p.T;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
