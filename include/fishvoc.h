@@ -56,7 +56,9 @@ typedef enum fv_model_kind {
     FV_MODEL_VOCOS = 3,    /* UnifyGenerator(ConvNeXtEncoder, ISTFTHead) (unify.py:5, convnext.py:146, vocos.py:6) */
     FV_MODEL_FIREFLY = 4,  /* UnifyGenerator(ConvNeXtEncoder, HiFiGANGenerator) (firefly-gan-base.yaml) */
     FV_MODEL_CONVNEXT = 5, /* ConvNeXtEncoder alone: (B, C_in, T) -> (B, dims[-1], T) */
-    FV_MODEL_ISTFT_HEAD = 6 /* ISTFTHead alone: (B, dim, T) -> (B, 1, T*hop) (vocos.py:43-69) */
+    FV_MODEL_ISTFT_HEAD = 6, /* ISTFTHead alone: (B, dim, T) -> (B, 1, T*hop) (vocos.py:43-69) */
+    FV_MODEL_LOGMEL = 7      /* LogMelSpectrogram: (B, 1, L) wave -> (B, n_mels, frames) (data/transforms/spectrogram.py:59-104);
+                                the step right before the generator in test.py:71 */
 } fv_model_kind;
 
 #define FV_MAX_STAGES 8
@@ -69,7 +71,8 @@ typedef enum fv_act {
     FV_ACT_SILU = 1,       /* F.silu (hifigan.py:103,105,230) */
     FV_ACT_LEAKY_RELU = 2, /* slope in fv_conv_desc.act_slope (refinegan.py:89; kept for completeness) */
     FV_ACT_GELU = 3,       /* nn.GELU() exact erf (convnext.py:114) */
-    FV_ACT_TANH = 4        /* torch.tanh (hifigan.py:247) */
+    FV_ACT_TANH = 4,       /* torch.tanh (hifigan.py:247) */
+    FV_ACT_LOG_CLAMP = 5   /* log(clamp(x, min=1e-5)) (spectrogram.py:93-94) */
 } fv_act;
 
 /* HiFiGANGenerator / BigVGANGenerator ctor kwargs (hifigan.py:137-151, bigvgan.py:256-270). */
@@ -105,12 +108,25 @@ typedef struct fv_istft_head_config {
     int32_t win_length;
 } fv_istft_head_config;
 
+/* LogMelSpectrogram ctor kwargs (spectrogram.py:60-70); center must be 0 (the reference default), win_length == n_fft,
+ * n_fft a multiple of hop_length. */
+typedef struct fv_logmel_config {
+    int32_t sample_rate;
+    int32_t n_fft;
+    int32_t win_length;
+    int32_t hop_length;
+    int32_t n_mels;
+    float f_min;
+    float f_max; /* <= 0: sample_rate // 2 */
+} fv_logmel_config;
+
 typedef struct fv_config {
     int32_t abi_version; /* = FV_ABI_VERSION */
     int32_t model;       /* fv_model_kind */
     fv_upsampler_config ups;   /* HIFIGAN, BIGVGAN, FIREFLY(head) */
     fv_convnext_config backbone; /* VOCOS, FIREFLY, CONVNEXT */
     fv_istft_head_config head;   /* VOCOS */
+    fv_logmel_config mel;        /* LOGMEL */
 } fv_config;
 
 typedef struct fv_engine fv_engine;

@@ -405,3 +405,71 @@ def firefly_forward(sd, cfg, mel) -> np.ndarray:
     """UnifyGenerator(ConvNeXtEncoder, HiFiGANGenerator) (configs/model/generator/firefly-gan-base.yaml)."""
     h = convnext_forward(strip_prefix(sd, "backbone."), cfg["backbone"], mel)
     return hifigan_forward(strip_prefix(sd, "head."), cfg["head"], h)
+
+
+# ------------------------------------------------------------------------------------------------
+# Log-mel front-end (next row f1): fish_vocoder/data/transforms/spectrogram.py
+# ------------------------------------------------------------------------------------------------
+def _hz_to_mel_slaney(f):
+    """torchaudio.functional._hz_to_mel(mel_scale="slaney") — third-party (torchaudio, absent here), restated from the
+    published Slaney / librosa formula: linear below 1 kHz (200/3 Hz per mel), log above."""
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, mels)
+
+
+def _mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def melscale_fbanks_slaney(n_freqs, f_min, f_max, n_mels, sample_rate) -> np.ndarray:
+    """torchaudio.functional.melscale_fbanks(norm="slaney", mel_scale="slaney") -> (n_freqs, n_mels) fp32.
+    PARITY UNPINNED (torchaudio is not installed and not vendored in /root/reference; call site spectrogram.py:83-91)."""
+    all_freqs = np.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = np.linspace(_hz_to_mel_slaney(f_min), _hz_to_mel_slaney(f_max), n_mels + 2)
+    f_pts = _mel_to_hz_slaney(m_pts)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    fb = np.maximum(0.0, np.minimum(down, up))
+    enorm = 2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])
+    return (fb * enorm[None, :]).astype(np.float32)
+
+
+def linear_spectrogram(wave, n_fft, win_length, hop_length) -> np.ndarray:
+    """LinearSpectrogram.forward, mode pow2_sqrt, center=False (spectrogram.py:25-56): reflect-pad
+    ((win-hop)//2, (win-hop+1)//2) -> STFT(hann periodic) -> sqrt(re^2 + im^2 + 1e-6).  (B, L) -> (B, n_fft/2+1, frames)."""
+    y = np.asarray(wave, dtype=np.float32)
+    if y.ndim == 3:
+        y = y[:, 0]
+    pl, pr = (win_length - hop_length) // 2, (win_length - hop_length + 1) // 2
+    yp = np.pad(y.astype(np.float64), ((0, 0), (pl, pr)), mode="reflect")
+    n = np.arange(win_length, dtype=np.float64)
+    window = (0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)).astype(np.float32).astype(np.float64)
+    if win_length < n_fft:  # torch.stft centres a short window inside n_fft
+        lpad = (n_fft - win_length) // 2
+        window = np.pad(window, (lpad, n_fft - win_length - lpad))
+    frames = 1 + (yp.shape[1] - n_fft) // hop_length
+    idx = np.arange(n_fft)[None, :] + hop_length * np.arange(frames)[:, None]
+    seg = yp[:, idx] * window[None, None, :]                 # (B, frames, n_fft)
+    spec = np.fft.rfft(seg, axis=-1)                          # (B, frames, n_fft/2+1)
+    mag = np.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-6)
+    return np.ascontiguousarray(mag.transpose(0, 2, 1)).astype(np.float32)
+
+
+def logmel_forward(wave, cfg) -> np.ndarray:
+    """LogMelSpectrogram.forward (spectrogram.py:99-104): mel_scale(spectrogram(x)) -> log(clamp(., 1e-5))."""
+    sr = cfg["sample_rate"]
+    f_max = cfg.get("f_max") or sr // 2
+    mag = linear_spectrogram(wave, cfg["n_fft"], cfg["win_length"], cfg["hop_length"])
+    fb = melscale_fbanks_slaney(cfg["n_fft"] // 2 + 1, cfg.get("f_min", 0.0), f_max, cfg["n_mels"], sr)
+    mel = np.einsum("bft,fm->bmt", mag.astype(np.float64), fb.astype(np.float64))
+    return np.log(np.maximum(mel, 1e-5)).astype(np.float32)

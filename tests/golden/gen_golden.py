@@ -144,7 +144,39 @@ class _ISTFT(nn.Module):
         return y / env
 
 
+class _MelScale(nn.Module):
+    """Stand-in for torchaudio.transforms.MelScale(norm="slaney", mel_scale="slaney") (torchaudio is absent): the
+    published melscale_fbanks algorithm in torch; fixtures built on it are "unpinned" for the filterbank values."""
+
+    def __init__(self, n_mels, sample_rate, f_min, f_max, n_stft, norm="slaney", mel_scale="slaney"):
+        super().__init__()
+        assert norm == "slaney" and mel_scale == "slaney"
+        f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, math.log(6.4) / 27.0
+        min_log_mel = min_log_hz / f_sp
+
+        def h2m(f):
+            return min_log_mel + math.log(f / min_log_hz) / logstep if f >= min_log_hz else f / f_sp
+
+        all_freqs = torch.linspace(0, sample_rate // 2, n_stft, dtype=torch.float64)
+        m_pts = torch.linspace(h2m(f_min), h2m(f_max), n_mels + 2, dtype=torch.float64)
+        f_pts = torch.where(m_pts >= min_log_mel, min_log_hz * torch.exp(logstep * (m_pts - min_log_mel)), f_sp * m_pts)
+        f_diff = f_pts[1:] - f_pts[:-1]
+        slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+        fb = torch.clamp(torch.min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0)
+        fb = fb * (2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])).unsqueeze(0)
+        self.register_buffer("fb", fb.to(torch.float32))
+
+    def forward(self, spec):
+        return torch.matmul(spec.transpose(-1, -2), self.fb).transpose(-1, -2)
+
+
 def _inject_stubs():
+    ta = types.ModuleType("torchaudio")
+    tat = types.ModuleType("torchaudio.transforms")
+    tat.MelScale = _MelScale
+    ta.transforms = tat
+    sys.modules["torchaudio"] = ta
+    sys.modules["torchaudio.transforms"] = tat
     aft = types.ModuleType("alias_free_torch")
     aft.Activation1d = _Activation1d
     sys.modules["alias_free_torch"] = aft
@@ -162,6 +194,7 @@ from fish_vocoder.modules.encoders.convnext import ConvNeXtEncoder  # noqa: E402
 from fish_vocoder.modules.generators.bigvgan import BigVGANGenerator, Snake, SnakeBeta  # noqa: E402
 from fish_vocoder.modules.generators.hifigan import HiFiGANGenerator  # noqa: E402
 from fish_vocoder.modules.generators.vocos import ISTFTHead  # noqa: E402
+from fish_vocoder.data.transforms.spectrogram import LinearSpectrogram, LogMelSpectrogram  # noqa: E402
 
 
 def _t(sd):
@@ -322,6 +355,25 @@ def gen_vocos(name, cfg, seed, B, T, mel_seed):
     _save(name, cfg=_cfg_arr(cfg), seed=seed, mel=mel, hidden=h.numpy(), out=out, pinned=False)
 
 
+@torch.no_grad()
+def gen_logmel():
+    """LinearSpectrogram is reference + torch.stft only (pinned); LogMelSpectrogram goes through the stand-in MelScale
+    (filterbank values unpinned, wiring pinned)."""
+    rng = np.random.default_rng(31)
+    arrs = {}
+    for tag, cfg, L in (("a", dict(sample_rate=16000, n_fft=64, win_length=64, hop_length=16, n_mels=12, f_min=0.0, f_max=8000), 16 * 23),
+                        ("b", dict(sample_rate=44100, n_fft=2048, win_length=2048, hop_length=512, n_mels=128, f_min=0.0, f_max=22050), 512 * 9)):
+        wave = (0.3 * rng.normal(size=(2, L))).astype(np.float32)
+        lin = LinearSpectrogram(cfg["n_fft"], cfg["win_length"], cfg["hop_length"])
+        mel = LogMelSpectrogram(**cfg)
+        arrs[f"{tag}_cfg"] = _cfg_arr(cfg)
+        arrs[f"{tag}_wave"] = wave
+        arrs[f"{tag}_linear"] = lin(torch.from_numpy(wave)).numpy()
+        arrs[f"{tag}_logmel"] = mel(torch.from_numpy(wave)[:, None, :]).numpy()
+        arrs[f"{tag}_fb"] = mel.mel_scale.fb.numpy()
+    _save("logmel.npz", pinned_linear=True, pinned_logmel=False, **arrs)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -356,6 +408,7 @@ def main():
                             kernel_size=7),
               head=dict(dim=64, n_fft=64, hop_length=16, win_length=64, padding="same"))
     gen_vocos("vocos_tiny.npz", vc, seed=9, B=2, T=15, mel_seed=26)
+    gen_logmel()
 
 
 if __name__ == "__main__":

@@ -83,3 +83,33 @@ def test_fused_firefly_and_vocos_engine_kinds_match_module_chain():
                  state_dict=sd)
     y = eng(torch.from_numpy(mel).cuda()).cpu().numpy()
     assert np.abs(y - orc.firefly_forward(sd, cfg, mel)).max() <= TOL
+
+
+def test_logmel_frontend_module_and_wav_to_wav():
+    """f1: wave -> log-mel on the GPU (reference LogMelSpectrogram golden), then mel -> HiFiGAN without leaving the device."""
+    import json
+    from vocoder_amd.data.transforms import LogMelSpectrogram
+    from oracle import oracle as orc
+    z = load_golden("logmel.npz")
+    for tag in "ab":
+        cfg = json.loads(bytes(z[f"{tag}_cfg"]).decode())
+        m = LogMelSpectrogram(**cfg).eval().cuda()
+        assert set(m.state_dict()) == {"spectrogram.window", "mel_scale.fb"}
+        y = m(torch.from_numpy(z[f"{tag}_wave"]).cuda())
+        assert y.shape == z[f"{tag}_logmel"].shape
+        # |d| on log-mel: the floor log(1e-5) region amplifies relative error of tiny mel energies; values here are O(1)
+        assert np.abs(y.cpu().numpy() - z[f"{tag}_logmel"]).max() <= 2e-4
+    # 44.1 kHz config, longer signal, vs the oracle
+    cfg = dict(sample_rate=44100, n_fft=2048, win_length=2048, hop_length=512, n_mels=80, f_min=0.0, f_max=22050)
+    rng = np.random.default_rng(0)
+    wave = (0.2 * rng.normal(size=(3, 512 * 40))).astype(np.float32)
+    m = LogMelSpectrogram(**cfg).eval().cuda()
+    mel = m(torch.from_numpy(wave).cuda()[:, None, :])
+    ref = orc.logmel_forward(wave, cfg)
+    assert mel.shape == ref.shape == (3, 80, 40)
+    assert np.abs(mel.cpu().numpy() - ref).max() <= 2e-4
+    gen, _ = config.build_generator("hifigan", overrides={"num_mels": 80})
+    out = gen.eval().cuda()(mel)
+    assert out.shape == (3, 1, 40 * 512) and torch.isfinite(out).all()
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 1, 100, device="cuda"))     # shorter than the reflect padding

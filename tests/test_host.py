@@ -31,6 +31,8 @@ def test_config_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.ConvNeXtConfig) == 4 * (2 + 8 + 8 + 1)
     assert ctypes.sizeof(_lib.IstftHeadConfig) == 16
     assert ctypes.sizeof(_lib.ConvDesc) == 40
+    assert ctypes.sizeof(_lib.LogMelConfig) == 28
+    assert ctypes.sizeof(_lib.Config) == 8 + ctypes.sizeof(_lib.UpsamplerConfig) + ctypes.sizeof(_lib.ConvNeXtConfig) + 16 + 28
 
 
 def test_fv_create_validation_without_gpu():

@@ -156,3 +156,23 @@ def test_vocos_forward_matches_reference_wiring():
     y = orc.vocos_forward(sd, g["cfg"], g["mel"])
     assert y.shape == g["out"].shape
     _close(y, g["out"], 3e-5, 1e-5)
+
+
+def test_logmel_frontend_matches_reference():
+    """f1: LinearSpectrogram is reference + torch.stft (pinned); the slaney filterbank comes from torchaudio (absent) and is
+    checked against the torch stand-in plus KATs (unpinned)."""
+    import json
+    z = load_golden("logmel.npz")
+    for tag in "ab":
+        cfg = json.loads(bytes(z[f"{tag}_cfg"]).decode())
+        lin = orc.linear_spectrogram(z[f"{tag}_wave"], cfg["n_fft"], cfg["win_length"], cfg["hop_length"])
+        _close(lin, z[f"{tag}_linear"], 1e-5, 1e-5)
+        fb = orc.melscale_fbanks_slaney(cfg["n_fft"] // 2 + 1, cfg["f_min"], cfg["f_max"], cfg["n_mels"], cfg["sample_rate"])
+        _close(fb, z[f"{tag}_fb"], 1e-7)
+        # KAT: triangles are non-negative, each filter has one peak, slaney area normalisation => integral over Hz == 1
+        assert (fb >= 0).all() and (fb.max(0) > 0).all()
+        df = (cfg["sample_rate"] // 2) / (cfg["n_fft"] // 2)
+        if cfg["n_fft"] >= 1024:
+            area = fb.sum(0) * df      # the narrowest low filters span ~3 bins: coarse Riemann sum there
+            assert np.median(np.abs(area - 1.0)) < 0.01 and np.abs(area - 1.0).max() < 0.15
+        _close(orc.logmel_forward(z[f"{tag}_wave"], cfg), z[f"{tag}_logmel"], 2e-5)

@@ -20,7 +20,8 @@ FV_MAX_KERNELS = 8
 FV_MAX_DILATIONS = 3
 
 FV_MODEL_HIFIGAN, FV_MODEL_BIGVGAN, FV_MODEL_VOCOS, FV_MODEL_FIREFLY, FV_MODEL_CONVNEXT, FV_MODEL_ISTFT_HEAD = 1, 2, 3, 4, 5, 6
-FV_ACT_NONE, FV_ACT_SILU, FV_ACT_LEAKY_RELU, FV_ACT_GELU, FV_ACT_TANH = 0, 1, 2, 3, 4
+FV_MODEL_LOGMEL = 7
+FV_ACT_NONE, FV_ACT_SILU, FV_ACT_LEAKY_RELU, FV_ACT_GELU, FV_ACT_TANH, FV_ACT_LOG_CLAMP = 0, 1, 2, 3, 4, 5
 
 EXPORTS = (
     "fv_create", "fv_load_weight", "fv_finalize", "fv_destroy", "fv_output_length", "fv_output_channels",
@@ -52,9 +53,14 @@ class IstftHeadConfig(ctypes.Structure):
     _fields_ = [("dim", _i32), ("n_fft", _i32), ("hop_length", _i32), ("win_length", _i32)]
 
 
+class LogMelConfig(ctypes.Structure):
+    _fields_ = [("sample_rate", _i32), ("n_fft", _i32), ("win_length", _i32), ("hop_length", _i32), ("n_mels", _i32),
+                ("f_min", ctypes.c_float), ("f_max", ctypes.c_float)]
+
+
 class Config(ctypes.Structure):
     _fields_ = [("abi_version", _i32), ("model", _i32), ("ups", UpsamplerConfig), ("backbone", ConvNeXtConfig),
-                ("head", IstftHeadConfig)]
+                ("head", IstftHeadConfig), ("mel", LogMelConfig)]
 
 
 class ConvDesc(ctypes.Structure):

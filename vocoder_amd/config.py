@@ -27,6 +27,7 @@ TARGET_ALIASES = {
     "fish_vocoder.modules.generators.vocos": "vocoder_amd.modules.generators.vocos",
     "fish_vocoder.modules.generators.unify": "vocoder_amd.modules.generators.unify",
     "fish_vocoder.modules.encoders.convnext": "vocoder_amd.modules.encoders.convnext",
+    "fish_vocoder.data.transforms.spectrogram": "vocoder_amd.data.transforms.spectrogram",
 }
 
 _INTERP = re.compile(r"\$\{([^${}]+)\}")

@@ -34,6 +34,7 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
         case FV_ACT_LEAKY_RELU: return v >= 0.f ? v : v * slope;
         case FV_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
         case FV_ACT_TANH: return tanhf(v);
+        case FV_ACT_LOG_CLAMP: return logf(fmaxf(v, 1e-5f));
         default: return v;
     }
 }

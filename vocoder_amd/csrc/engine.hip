@@ -237,6 +237,18 @@ struct IstftHeadModel {
     }
 };
 
+struct LogMelModel {
+    fv_logmel_config cfg{};
+    ConvLayer stft;   // (2*nb) x hop x (n_fft/hop): windowed real DFT in polyphase form (rows [0,nb) Re, [nb,2nb) Im)
+    ConvLayer mel;    // n_mels x nb pointwise: slaney filterbank, epilogue log(clamp(., 1e-5))
+    int nb = 0, taps = 0, pad_l = 0, pad_r = 0;
+    int frames(int L) const { return 1 + (L + pad_l + pad_r - cfg.n_fft) / cfg.hop_length; }
+    void destroy() {
+        conv_layer_destroy(stft);
+        conv_layer_destroy(mel);
+    }
+};
+
 }  // namespace fv
 
 using namespace fv;
@@ -249,6 +261,7 @@ struct fv_engine {
     UpsamplerModel ups;
     ConvNeXtModel cnx;
     IstftHeadModel head;
+    LogMelModel mel;
     bool has_ups = false, has_cnx = false, has_head = false;
     Profiler prof;
     bool profiling = false;
@@ -395,6 +408,8 @@ struct fv_engine {
     fv_status build_upsampler(const std::string& pfx, bool bigvgan);
     fv_status build_convnext(const std::string& pfx);
     fv_status build_head(const std::string& pfx);
+    fv_status build_logmel(const std::string& pfx);
+    fv_status run_logmel(const float* d_in, float* d_out, int B, int L, float* ws, hipStream_t s);
 
     fv_status run_model(const float* d_in, float* d_out, int batch, int t_in, float* ws, hipStream_t s);
     fv_status run_upsampler(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
@@ -412,6 +427,7 @@ struct fv_engine {
         ups.destroy();
         cnx.destroy();
         head.destroy();
+        mel.destroy();
     }
 };
 
@@ -821,6 +837,102 @@ fv_status fv_engine::run_head(const float* d_in, float* d_out, int B, int T, flo
     return FV_OK;
 }
 
+
+// slaney mel scale of torchaudio.functional.melscale_fbanks (third-party, restated from the published formula; the
+// reference call site is data/transforms/spectrogram.py:83-91)
+static double hz_to_mel_slaney(double f) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_hz / f_sp + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+static double mel_to_hz_slaney(double m) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, logstep = std::log(6.4) / 27.0, min_log_mel = min_log_hz / f_sp;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+fv_status fv_engine::build_logmel(const std::string& pfx) {
+    const fv_logmel_config& c = cfg.mel;
+    mel.cfg = c;
+    const int N = c.n_fft, hop = c.hop_length, nb = N / 2 + 1, taps = N / hop;
+    mel.nb = nb;
+    mel.taps = taps;
+    mel.pad_l = (c.win_length - hop) / 2;        // spectrogram.py:30-33
+    mel.pad_r = (c.win_length - hop + 1) / 2;
+    std::vector<float> win(N);
+    if (const HostTensor* t = find(pfx + "spectrogram.window")) {
+        if (t->numel() != N) {
+            set_error("'%sspectrogram.window' has %lld taps, expected %d", pfx.c_str(), (long long)t->numel(), N);
+            return FV_ERR_SHAPE;
+        }
+        win = t->data;
+    } else {
+        for (int n = 0; n < N; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / N));   // hann, periodic
+    }
+    // STFT as a stride-1 conv over the polyphase signal: X_k[t] = sum_{r<hop} sum_{q<taps} w[qh+r] e^{-2 pi i k (qh+r)/N} yp[r][t+q]
+    std::vector<float> wst((size_t)2 * nb * hop * taps);
+    for (int k = 0; k < nb; ++k)
+        for (int r = 0; r < hop; ++r)
+            for (int q = 0; q < taps; ++q) {
+                const int n = q * hop + r;
+                const double ang = 2.0 * M_PI * (double)(((int64_t)k * n) % N) / N;
+                wst[((size_t)k * hop + r) * taps + q] = (float)(win[n] * std::cos(ang));
+                wst[((size_t)(nb + k) * hop + r) * taps + q] = (float)(-(double)win[n] * std::sin(ang));
+            }
+    fv_status st;
+    if ((st = conv_layer_create(mel.stft, false, hop, 2 * nb, taps, 1, 0, 1, wst.data(), nullptr))) return st;
+    // filterbank (n_freqs, n_mels) -> pointwise conv weight (n_mels, n_freqs)
+    std::vector<float> fbw((size_t)c.n_mels * nb);
+    if (const HostTensor* t = find(pfx + "mel_scale.fb")) {
+        if (t->numel() != (int64_t)nb * c.n_mels) {
+            set_error("'%smel_scale.fb' has %lld elements, expected %d x %d", pfx.c_str(), (long long)t->numel(), nb, c.n_mels);
+            return FV_ERR_SHAPE;
+        }
+        for (int f = 0; f < nb; ++f)
+            for (int m = 0; m < c.n_mels; ++m) fbw[(size_t)m * nb + f] = t->data[(size_t)f * c.n_mels + m];
+    } else {
+        const double f_max = c.f_max > 0 ? c.f_max : (double)(c.sample_rate / 2);
+        const double m_min = hz_to_mel_slaney(c.f_min), m_max = hz_to_mel_slaney(f_max);
+        std::vector<double> f_pts(c.n_mels + 2);
+        for (int i = 0; i < c.n_mels + 2; ++i) f_pts[i] = mel_to_hz_slaney(m_min + (m_max - m_min) * i / (c.n_mels + 1));
+        for (int f = 0; f < nb; ++f) {
+            const double freq = (double)(c.sample_rate / 2) * f / (nb - 1);
+            for (int m = 0; m < c.n_mels; ++m) {
+                const double down = (freq - f_pts[m]) / (f_pts[m + 1] - f_pts[m]);
+                const double up = (f_pts[m + 2] - freq) / (f_pts[m + 2] - f_pts[m + 1]);
+                const double v = std::max(0.0, std::min(down, up)) * (2.0 / (f_pts[m + 2] - f_pts[m]));
+                fbw[(size_t)m * nb + f] = (float)v;
+            }
+        }
+    }
+    return conv_layer_create(mel.mel, false, nb, c.n_mels, 1, 1, 0, 1, fbw.data(), nullptr);
+}
+
+fv_status fv_engine::run_logmel(const float* d_in, float* d_out, int B, int L, float* ws, hipStream_t s) {
+    const int hop = mel.cfg.hop_length, nb = mel.nb;
+    const int T = mel.frames(L);
+    const int TP = T + mel.taps - 1;
+    const size_t n_yp = ((size_t)B * hop * TP + 63) / 64 * 64, n_sp = ((size_t)B * 2 * nb * T + 63) / 64 * 64;
+    float* Yp = ws;
+    float* Sp = ws + n_yp;
+    float* Mg = Sp + n_sp;
+    FV_PROF(s, "polyphase_reflect", 0.0, 8.0 * B * (double)hop * TP,
+            launch_polyphase_reflect(d_in, Yp, B, L, hop, TP, mel.pad_l, mel.pad_r, s));
+    fv_status st;
+    ConvRun r;
+    r.batch = B;
+    r.t_in = TP;
+    r.x = Yp;
+    r.y = Sp;
+    if ((st = conv_layer_run(mel.stft, r, s))) return st;
+    FV_PROF(s, "magnitude", 4.0 * B * nb * T, 12.0 * B * nb * T, launch_magnitude(Sp, Mg, B, nb, T, s));
+    r = ConvRun();
+    r.batch = B;
+    r.t_in = T;
+    r.x = Mg;
+    r.y = d_out;
+    r.post_act = FV_ACT_LOG_CLAMP;   // compress(): log(clamp(x, 1e-5))  (spectrogram.py:93-94)
+    return conv_layer_run(mel.mel, r, s);
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -899,9 +1011,19 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
             }
             break;
         case FV_MODEL_CONVNEXT: break;
+        case FV_MODEL_LOGMEL: {
+            const fv_logmel_config& m = cfg->mel;
+            if (m.n_fft < 2 || m.n_fft % 2 || m.hop_length < 1 || m.win_length != m.n_fft || m.n_fft % m.hop_length ||
+                m.n_mels < 1 || m.sample_rate < 2 || m.f_min < 0) {
+                set_error("logmel: need even n_fft == win_length, n_fft a multiple of hop_length, n_mels >= 1");
+                st = FV_ERR_INVALID;
+            }
+            break;
+        }
         default: set_error("fv_create: unknown model kind %d", cfg->model); st = FV_ERR_INVALID;
     }
-    if (!st && cfg->model != FV_MODEL_HIFIGAN && cfg->model != FV_MODEL_BIGVGAN && cfg->model != FV_MODEL_ISTFT_HEAD) {
+    if (!st && cfg->model != FV_MODEL_HIFIGAN && cfg->model != FV_MODEL_BIGVGAN && cfg->model != FV_MODEL_ISTFT_HEAD &&
+        cfg->model != FV_MODEL_LOGMEL) {
         const fv_convnext_config& b = cfg->backbone;
         if (b.num_stages < 1 || b.num_stages > FV_MAX_STAGES || b.input_channels < 1 || b.kernel_size < 1 || b.kernel_size % 2 == 0) {
             set_error("convnext: invalid num_stages / input_channels / kernel_size");
@@ -960,6 +1082,7 @@ FV_API fv_status fv_finalize(fv_engine* e) {
         case FV_MODEL_BIGVGAN: st = e->build_upsampler("", true); break;
         case FV_MODEL_CONVNEXT: st = e->build_convnext(""); break;
         case FV_MODEL_ISTFT_HEAD: st = e->build_head(""); break;
+        case FV_MODEL_LOGMEL: st = e->build_logmel(""); break;
         case FV_MODEL_VOCOS:
             st = e->build_convnext("backbone.");
             if (!st) st = e->build_head("head.");
@@ -986,11 +1109,13 @@ FV_API void fv_destroy(fv_engine* e) { delete e; }
 FV_API int32_t fv_input_channels(const fv_engine* e) {
     if (!e) return 0;
     if (e->cfg.model == FV_MODEL_ISTFT_HEAD) return e->cfg.head.dim;
+    if (e->cfg.model == FV_MODEL_LOGMEL) return 1;
     return (e->cfg.model == FV_MODEL_HIFIGAN || e->cfg.model == FV_MODEL_BIGVGAN) ? e->cfg.ups.num_mels
                                                                                     : e->cfg.backbone.input_channels;
 }
 FV_API int32_t fv_output_channels(const fv_engine* e) {
     if (!e) return 0;
+    if (e->cfg.model == FV_MODEL_LOGMEL) return e->cfg.mel.n_mels;
     return e->cfg.model == FV_MODEL_CONVNEXT ? e->cfg.backbone.dims[e->cfg.backbone.num_stages - 1] : 1;
 }
 FV_API int64_t fv_output_length(const fv_engine* e, int32_t t_in) {
@@ -1001,6 +1126,7 @@ FV_API int64_t fv_output_length(const fv_engine* e, int32_t t_in) {
         case FV_MODEL_FIREFLY: return e->ups.out_len(t_in);
         case FV_MODEL_VOCOS:
         case FV_MODEL_ISTFT_HEAD: return (int64_t)t_in * e->cfg.head.hop_length;
+        case FV_MODEL_LOGMEL: return std::max(0, e->mel.frames(t_in));
         default: return t_in;
     }
 }
@@ -1027,6 +1153,12 @@ FV_API size_t fv_workspace_bytes(const fv_engine* e, int32_t batch, int32_t t_in
         case FV_MODEL_BIGVGAN: elems = ups_ws_elems(e, batch, t_in); break;
         case FV_MODEL_CONVNEXT: elems = cnx_ws_elems(e, batch, t_in); break;
         case FV_MODEL_ISTFT_HEAD: elems = head_ws_elems(e, batch, t_in); break;
+        case FV_MODEL_LOGMEL: {
+            const size_t T = (size_t)std::max(1, e->mel.frames(t_in));
+            elems = ((size_t)batch * e->cfg.mel.hop_length * (T + e->mel.taps) + 64) +
+                    ((size_t)batch * 3 * e->mel.nb * T + 128);
+            break;
+        }
         case FV_MODEL_VOCOS: {
             const size_t mid = align_up((size_t)e->cnx.out_dim() * t_in * batch, 64);
             elems = mid + std::max(cnx_ws_elems(e, batch, t_in), head_ws_elems(e, batch, t_in));
@@ -1123,6 +1255,13 @@ fv_status fv_engine::run_model(const float* d_in, float* d_out, int batch, int t
         case FV_MODEL_BIGVGAN: return e->run_upsampler(d_in, d_out, batch, t_in, ws, s);
         case FV_MODEL_CONVNEXT: return e->run_convnext(d_in, d_out, batch, t_in, ws, s);
         case FV_MODEL_ISTFT_HEAD: return e->run_head(d_in, d_out, batch, t_in, ws, s);
+        case FV_MODEL_LOGMEL:
+            if (e->mel.frames(t_in) < 1 || t_in <= std::max(e->mel.pad_l, e->mel.pad_r)) {
+                set_error("logmel: %d samples is too short for reflect padding %d/%d and one %d-sample frame", t_in, e->mel.pad_l,
+                          e->mel.pad_r, e->cfg.mel.n_fft);
+                return FV_ERR_INVALID;
+            }
+            return e->run_logmel(d_in, d_out, batch, t_in, ws, s);
         case FV_MODEL_VOCOS: {
             const size_t mid = align_up((size_t)e->cnx.out_dim() * t_in * batch, 64);
             fv_status st = e->run_convnext(d_in, ws, batch, t_in, ws + mid, s);

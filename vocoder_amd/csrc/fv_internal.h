@@ -170,6 +170,13 @@ fv_status launch_aa_snake(const float* x, float* y, const float* alpha_eff, cons
 fv_status launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                            float* y, int B, int C, int T, int k, float eps, hipStream_t s);
 
+// Log-mel front-end glue (small_kernels.hip)
+// yp[b][r][tp] = wave[b][reflect(tp*hop + r - pad_l)] (0 past the padded length): polyphase layout so that the STFT becomes
+// a stride-1 conv with hop channels and n_fft/hop taps
+fv_status launch_polyphase_reflect(const float* wave, float* yp, int B, int L, int hop, int TP, int pad_l, int pad_r, hipStream_t s);
+// mag[b][k][t] = sqrt(re^2 + im^2 + 1e-6) from spec rows [0,nb) = Re, [nb,2nb) = Im
+fv_status launch_magnitude(const float* spec, float* mag, int B, int nb, int T, hipStream_t s);
+
 // ISTFT head glue: h (B, 2*n_fft, T) rows [0,nb) = log-mag, [n_fft, n_fft+nb) = phase -> spec (B, 2*nbp, T):
 // rows [0,nb) = Re, [nbp, nbp+nb) = Im, zero padded to nbp = round_up(nb, 8)
 fv_status launch_istft_spec(const float* h, float* spec, int B, int n_fft, int T, int nb, int nbp, hipStream_t s);

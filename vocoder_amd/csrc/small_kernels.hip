@@ -423,4 +423,59 @@ fv_status launch_istft_ola(const float* frames, const float* win2, float* y, int
     return FV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Log-mel front-end (fish_vocoder/data/transforms/spectrogram.py:25-56): reflect padding + polyphase re-layout, magnitude.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void polyphase_reflect_kernel(const float* __restrict__ wave, float* __restrict__ yp,
+                                                                int L, int hop, int TP, int pad_l, int pad_r) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* wb = wave + (long long)b * L;
+    const long long lpad = (long long)L + pad_l + pad_r;
+    for (int i = ty; i < 32; i += 8) {   // read: consecutive lanes = consecutive samples (r) of frame slot t0 + i
+        const int tp = t0 + i, r = r0 + tx;
+        float v = 0.f;
+        const long long pos = (long long)tp * hop + r;
+        if (tp < TP && r < hop && pos < lpad) {
+            long long idx = pos - pad_l;
+            if (idx < 0) idx = -idx;
+            if (idx >= L) idx = 2LL * (L - 1) - idx;
+            idx = idx < 0 ? 0 : (idx >= L ? L - 1 : idx);
+            v = wb[idx];
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    float* yb = yp + (long long)b * hop * TP;
+    for (int i = ty; i < 32; i += 8) {   // write: consecutive lanes = consecutive frame slots
+        const int r = r0 + i, tp = t0 + tx;
+        if (r < hop && tp < TP) yb[(long long)r * TP + tp] = tile[tx][i];
+    }
+}
+
+fv_status launch_polyphase_reflect(const float* wave, float* yp, int B, int L, int hop, int TP, int pad_l, int pad_r, hipStream_t s) {
+    hipLaunchKernelGGL(polyphase_reflect_kernel, dim3((TP + 31) / 32, (hop + 31) / 32, B), dim3(256), 0, s, wave, yp, L, hop, TP,
+                       pad_l, pad_r);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
+__global__ __launch_bounds__(256) void magnitude_kernel(const float* __restrict__ spec, float* __restrict__ mag, int nb, int T) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per = (long long)nb * T;
+    if (i >= per) return;
+    const int b = blockIdx.y;
+    const float re = spec[(long long)b * 2 * per + i], im = spec[(long long)b * 2 * per + per + i];
+    mag[(long long)b * per + i] = sqrtf(fmaf(re, re, fmaf(im, im, 1e-6f)));
+}
+
+fv_status launch_magnitude(const float* spec, float* mag, int B, int nb, int T, hipStream_t s) {
+    const long long per = (long long)nb * T;
+    hipLaunchKernelGGL(magnitude_kernel, dim3((unsigned)((per + 255) / 256), B), dim3(256), 0, s, spec, mag, nb, T);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
 }  // namespace fv

@@ -73,10 +73,21 @@ def istft_head_config(*, dim, n_fft, hop_length, win_length, padding="same") -> 
     return c
 
 
+def logmel_config(*, sample_rate=44100, n_fft=2048, win_length=2048, hop_length=512, n_mels=128, center=False,
+                  f_min=0.0, f_max=None) -> _lib.LogMelConfig:
+    if center:
+        raise NotImplementedError("LogMelSpectrogram(center=True) is out of scope (the reference default is False)")
+    c = _lib.LogMelConfig()
+    c.sample_rate, c.n_fft, c.win_length, c.hop_length, c.n_mels = int(sample_rate), int(n_fft), int(win_length), int(hop_length), int(n_mels)
+    c.f_min = float(f_min)
+    c.f_max = float(f_max or sample_rate // 2)
+    return c
+
+
 class Engine:
     """Owns one ``fv_engine`` on the current device.  ``state_dict`` uses the reference's key names."""
 
-    def __init__(self, model_kind: int, *, ups=None, backbone=None, head=None,
+    def __init__(self, model_kind: int, *, ups=None, backbone=None, head=None, mel=None,
                  state_dict: Mapping[str, "np.ndarray | torch.Tensor"], device=None):
         self._h = ctypes.c_void_p()
         self._lib = _lib.lib()
@@ -93,6 +104,8 @@ class Engine:
             cfg.backbone = backbone
         if head is not None:
             cfg.head = head
+        if mel is not None:
+            cfg.mel = mel
         with torch.cuda.device(self.device):
             check(self._lib.fv_create(ctypes.byref(cfg), ctypes.byref(self._h)))
             try:
