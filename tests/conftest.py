@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The native pieces are built in-tree by __graft_entry__.build(); build them here if a fresh checkout has not yet
+    (hipcc cross-compiles gfx950 without a GPU, ~1 min; gcc for the oracle)."""
+    from vocoder_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+        _lib.build()
+    from oracle import oracle as orc
+    orc.build()
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name))
     d = {k: z[k] for k in z.files}
