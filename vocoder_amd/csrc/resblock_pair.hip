@@ -20,6 +20,10 @@ namespace fv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef FV_X_PAIRWAVES
+#define FV_X_PAIRWAVES 2   // min waves per SIMD the register allocator must leave room for
+#endif
+
 template <int KS, int DIL, int C>
 struct PairGeom {
     static constexpr int W1 = kPairCols / C;            // c1 output columns per workgroup (256 at C=16, 128 at C=32: ~40 KB of LDS, 4 workgroups per CU)
@@ -35,35 +39,44 @@ struct PairGeom {
 
 __device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
 
-// As[r][col] = silu(x[r][t0 - HP + col]) for r < C, col < WA_RAW (0 outside [0, T)); LDS row stride WA.
-template <int C, int WA_RAW, int WA, int HP>
-__device__ __forceinline__ void stage_window(const float* __restrict__ xb, float* __restrict__ As, int tid, int t0, int T) {
-    constexpr int TOT = C * WA_RAW;
-    constexpr int BATCH = 8;
-    constexpr int NB = (TOT + 256 * BATCH - 1) / (256 * BATCH);
-#pragma unroll 1
-    for (int bb = 0; bb < NB; ++bb) {
-        float v[BATCH];
-        int dst[BATCH];
-        bool ok[BATCH];
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i) {
-            int e = tid + (bb * BATCH + i) * 256;
-            const bool in = e < TOT;
-            e = in ? e : TOT - 1;
-            const int r = e / WA_RAW, col = e - r * WA_RAW;
-            const int t = t0 - HP + col;
-            ok[i] = in && t >= 0 && t < T;
-            dst[i] = in ? r * WA + col : -1;
-            const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-            v[i] = xb[(long long)r * T + tc];
-        }
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i)
-            if (dst[i] >= 0) As[dst[i]] = ok[i] ? silu_f(v[i]) : 0.f;
-    }
+// Buffer descriptor over `bytes` bytes at a wave-uniform address.  readfirstlane makes the uniformity provable to hipcc
+// (otherwise every buffer op is wrapped in a waterfall loop).  Raw buffer loads return 0 and raw buffer stores are dropped
+// for offsets >= bytes — that hardware bounds check replaces the clamp / select / branch VALU code of flat accesses.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// As[r][col] = silu(x[r][t0 - HP + col]) for r < C, col < WA_RAW (0 outside [0, T): silu(0) = 0 is the conv's zero padding).
+// Each wave stages C/4 whole rows: per element one buffer load (row descriptor in SGPRs, column offset in a VGPR, out-of-
+// range columns come back as 0 from the hardware bounds check), silu, one ds_write — the PMC profile of the first version
+// showed the kernel bound by VALU issue (1400 VALU vs 96 MFMA instructions per wave), most of it index / clamp / 64-bit
+// address arithmetic around these loads.
+template <int C, int WA_RAW, int WA, int HP>
+__device__ __forceinline__ void stage_window(const float* __restrict__ xb, float* __restrict__ As, int wave, int lane, int t0,
+                                             int T) {
+    constexpr int ROWS = C / 4;                  // rows per wave
+    constexpr int NI = (WA_RAW + 63) / 64;       // columns per lane
+    float v[ROWS][NI];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+        const int r = wave * ROWS + rr;
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(xb + (long long)r * T, (unsigned)T * 4u);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            v[rr][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (t0 - HP + lane + 64 * i) * 4, 0, 0));
+    }
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int col = lane + 64 * i;
+            if (col < WA_RAW) As[(wave * ROWS + rr) * WA + col] = silu_f(v[rr][i]);
+        }
+}
 
 // acc[i][jn] += sum over (cc, tap j, pair pp) of W-fragment x B-fragment, B element = bsrc[(cc*8 + 2pp)*STRIDE + jn*32 + j*DILX]
 // (bsrc already carries the lane's k-half row and column).  One step (= one tap of one 8-channel sub-chunk) deep software
@@ -169,7 +182,7 @@ __device__ __forceinline__ void gemm16_resident(const float4* __restrict__ w, in
 // C = 32 (MT = 1) and C = 64 (MT = 2): 32x32x2 MFMA.  Each wave owns NT n-tiles of 32 columns and all m-tiles.
 // ---------------------------------------------------------------------------------------------------------------
 template <int KS, int DIL, int C>
-__global__ __launch_bounds__(256) void resblock_pair32_kernel(const PairParams p) {
+__global__ __launch_bounds__(256, FV_X_PAIRWAVES) void resblock_pair32_kernel(const PairParams p) {
     using G = PairGeom<KS, DIL, C>;
     constexpr int MT = C / 32;
     constexpr int NT = G::W1 / 32 / 4;   // n-tiles per wave
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(256) void resblock_pair32_kernel(const PairParams p
 
     // phase 1: A = silu(x) window.  Loads are unconditional on clamped addresses and issued in batches of 8 so that
     // their latencies overlap (a guarded load per element compiles to a branch + vmcnt(0) each).
-    stage_window<C, G::WA_RAW, G::WA, G::HP>(xb, As, tid, t0, p.T);
+    stage_window<C, G::WA_RAW, G::WA, G::HP>(xb, As, wave, lane, t0, p.T);
     __syncthreads();
 
     const int ncol = wave * (NT * 32) + (lane & 31);
@@ -229,33 +242,33 @@ __global__ __launch_bounds__(256) void resblock_pair32_kernel(const PairParams p
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         gemm32_resident<KS, G::WB, 1, MT, NT, NCH>(p.w2, lane, Bs + krow * G::WB + ncol, acc);
-        float* __restrict__ yb = p.y + (long long)b * C * p.T;
+        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb, (unsigned)(C * p.T) * 4u);
+        const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * C * p.T, (unsigned)(C * p.T) * 4u);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
                 const float bias = p.b2[m];
-                long long o[NT];
-                bool ok[NT];
+                // byte offset inside this batch item, or 0xFFFFFFFF (out of range: loads give 0, stores are dropped)
+                unsigned o[NT];
                 float xr[NT], yo[NT];
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) {
                     const int n = ncol + jn * 32;
                     const int t = t0 + n;
-                    ok[jn] = n < G::TT && t < p.T;
-                    o[jn] = ok[jn] ? (long long)m * p.T + t : 0;
-                    xr[jn] = xb[o[jn]];
+                    o[jn] = (n < G::TT && t < p.T) ? (unsigned)(m * p.T + t) * 4u : 0xFFFFFFFFu;
+                    xr[jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, o[jn], 0, 0));
                 }
                 if (p.out_mode == OUT_ACCUM) {
 #pragma unroll
-                    for (int jn = 0; jn < NT; ++jn) yo[jn] = yb[o[jn]];
+                    for (int jn = 0; jn < NT; ++jn) yo[jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, o[jn], 0, 0));
                 }
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) {
                     float v = acc[i][jn][r] + bias + xr[jn];
                     if (p.out_mode == OUT_ACCUM) v = (yo[jn] + v) * p.out_scale;
-                    if (ok[jn]) yb[o[jn]] = v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, o[jn], 0, 0);
                 }
             }
     }
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(256) void resblock_pair32_kernel(const PairParams p
 // Weights packed as [tap][lane] float4 = the four channel quads of that tap.
 // ---------------------------------------------------------------------------------------------------------------
 template <int KS, int DIL>
-__global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairParams p) {
+__global__ __launch_bounds__(256, FV_X_PAIRWAVES) void resblock_pair16_kernel(const PairParams p) {
     constexpr int C = 16;
     using G = PairGeom<KS, DIL, C>;
     constexpr int NT = G::W1 / 16 / 4;   // 8 n-tiles of 16 columns per wave
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairParams p
     const int t0 = tile * G::TT;
     const float* __restrict__ xb = p.x + (long long)b * C * p.T;
 
-    stage_window<C, G::WA_RAW, G::WA, G::HP>(xb, As, tid, t0, p.T);
+    stage_window<C, G::WA_RAW, G::WA, G::HP>(xb, As, wave, lane, t0, p.T);
     __syncthreads();
 
     const int ncol = wave * (NT * 16) + (lane & 15);
@@ -310,31 +323,30 @@ __global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairParams p
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         gemm16_resident<KS, G::WB, 1, NT>(p.w2, lane, Bs + krow * G::WB + ncol, acc);
-        float* __restrict__ yb = p.y + (long long)b * C * p.T;
+        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb, (unsigned)(C * p.T) * 4u);
+        const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * C * p.T, (unsigned)(C * p.T) * 4u);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = 4 * krow + r;
             const float bias = p.b2[m];
-            long long o[NT];
-            bool ok[NT];
+            unsigned o[NT];   // byte offset inside this batch item, 0xFFFFFFFF = masked (see resblock_pair32_kernel)
             float xr[NT], yo[NT];
 #pragma unroll
             for (int jn = 0; jn < NT; ++jn) {
                 const int n = ncol + jn * 16;
                 const int t = t0 + n;
-                ok[jn] = n < G::TT && t < p.T;
-                o[jn] = ok[jn] ? (long long)m * p.T + t : 0;
-                xr[jn] = xb[o[jn]];
+                o[jn] = (n < G::TT && t < p.T) ? (unsigned)(m * p.T + t) * 4u : 0xFFFFFFFFu;
+                xr[jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, o[jn], 0, 0));
             }
             if (p.out_mode == OUT_ACCUM) {
 #pragma unroll
-                for (int jn = 0; jn < NT; ++jn) yo[jn] = yb[o[jn]];
+                for (int jn = 0; jn < NT; ++jn) yo[jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, o[jn], 0, 0));
             }
 #pragma unroll
             for (int jn = 0; jn < NT; ++jn) {
                 float v = acc[jn][r] + bias + xr[jn];
                 if (p.out_mode == OUT_ACCUM) v = (yo[jn] + v) * p.out_scale;
-                if (ok[jn]) yb[o[jn]] = v;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, o[jn], 0, 0);
             }
         }
     }
