@@ -156,6 +156,11 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         set_error("conv_layer_run: non-positive output length %lld", tout);
         return FV_ERR_INVALID;
     }
+    if ((long long)L.c_out * tout >= (1LL << 30) || (long long)L.c_in * r.t_in >= (1LL << 30)) {
+        set_error("conv_layer_run: a batch item of %lld elements exceeds the 4 GiB buffer-addressing span",
+                  (long long)std::max<long long>((long long)L.c_out * tout, (long long)L.c_in * r.t_in));
+        return FV_ERR_UNSUPPORTED;
+    }
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.x = r.x;
@@ -191,7 +196,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     // (Vocos: T = 94 frames per clip would waste 27 % of a 128-column tile)
     int launch_batch = r.batch;
     if (!L.transposed && L.ks == 1 && L.pad_l == 0 && r.batch > 1 &&
-        (long long)r.batch * std::max<long long>((long long)L.c_in * r.t_in, (long long)L.c_out * tout) < (1LL << 31)) {
+        (long long)r.batch * std::max<long long>((long long)L.c_in * r.t_in, (long long)L.c_out * tout) < (1LL << 30)) {
         const int cfg_flat = choose_tile(L.M, (long long)p.N * r.batch, 1);
         if (cfg_flat != TILE_SPLITK_32x64) {
             cfg = cfg_flat;

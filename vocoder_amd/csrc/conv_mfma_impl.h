@@ -39,47 +39,76 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     }
 }
 
+// Buffer descriptor over `bytes` bytes at a wave-uniform address (readfirstlane makes the uniformity provable, otherwise
+// hipcc wraps every buffer op in a waterfall loop).  Raw buffer loads return 0 and raw buffer stores are dropped for byte
+// offsets >= bytes: that hardware bounds check replaces clamp / select / branch VALU code around flat accesses.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <int N>
+__device__ __forceinline__ void act_apply_all(float (&v)[N], int act, float slope) {
+    switch (act) {   // one wave-uniform branch for the whole register tile, not one per value
+        case FV_ACT_NONE: break;
+        case FV_ACT_SILU:
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = v[i] * __frcp_rn(1.0f + __expf(-v[i]));
+            break;
+        default:
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = act_apply(v[i], act, slope);
+    }
+}
+
 // Fused epilogue shared by the conv kernels: bias, layer-scale, residual, post-activation, MRF accumulate, polyphase
 // scatter.  acc follows the 32x32 MFMA C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+// All global traffic goes through raw buffer ops on byte offsets relative to the output tensor (masked elements get offset
+// 0xFFFFFFFF: loads return 0, stores are dropped) — no 64-bit address arithmetic, no per-element branches.
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][NT], int b, int mt0, int ncol0, int lane) {
-    float* __restrict__ yb = p.y + (long long)b * p.y_bstride;
-    const float* __restrict__ rb = p.res ? p.res + (long long)b * p.y_bstride : nullptr;
+    // in flat mode the tensor spans all batch items (b == 0), otherwise one item
+    const unsigned span = (unsigned)((p.flat ? (long long)p.y_bstride * (p.n_total / p.N) : p.y_bstride) * 4);
+    const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
+    const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
+    const bool has_res = p.res != nullptr;
     const bool accum = p.out_mode == OUT_ACCUM;
+    // column part of the element offset (independent of the row) and its validity
+    int coff[NT];
+    bool cok[NT];
+#pragma unroll
+    for (int jn = 0; jn < NT; ++jn) {
+        const int n = ncol0 + jn * 32;
+        if (p.convt) {
+            coff[jn] = n * p.u - p.pad_t;   // + phase added per row
+            cok[jn] = n < p.N;
+        } else if (p.flat) {
+            const int bb = n / p.N;         // column = (batch item, t)
+            coff[jn] = bb * (int)p.y_bstride + (n - bb * p.N);
+            cok[jn] = n < p.n_total;
+        } else {
+            coff[jn] = n;
+            cok[jn] = n < p.N;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        // column part of the output offset (independent of the row) and its validity
-        int coff[NT];
-        bool cok[NT];
-#pragma unroll
-        for (int jn = 0; jn < NT; ++jn) {
-            const int n = ncol0 + jn * 32;
-            if (p.convt) {
-                coff[jn] = n * p.u - p.pad_t;   // + phase added per row
-                cok[jn] = n < p.N;
-            } else if (p.flat) {
-                const int bb = n / p.N;         // column = (batch item, t)
-                coff[jn] = bb * (int)p.y_bstride + (n - bb * p.N);
-                cok[jn] = n < p.n_total;
-            } else {
-                coff[jn] = n;
-                cok[jn] = n < p.N;
-            }
-        }
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             // 4 rows (r & 3) x NT columns at a time: issue all residual / accumulate loads, then compute, then store
-            int off[4][NT];
-            bool ok[4][NT];
-            float rv[4][NT], yo[4][NT], bias[4], gm[4];
+            unsigned off[4 * NT];
+            float val[4 * NT], rv[4 * NT], yo[4 * NT];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int m = (mt0 + i) * 32 + rr + 8 * rq + 4 * (lane >> 5);
                 const bool mok = m < p.M;
                 const int mc = mok ? m : 0;
-                bias[rr] = p.bias[mc];
-                gm[rr] = p.gamma ? p.gamma[mc] : 1.0f;
-                int row_off, ph = 0;   // per-item offsets fit 32 bits (C * T < 2^31)
+                const float bias = p.bias[mc];
+                const float gm = p.gamma ? p.gamma[mc] : 1.0f;
+                int row_off, ph = 0;   // element offsets fit 32 bits (host guarantees the tensor is < 4 GiB)
                 if (p.convt) {
                     const int co = mc / p.u;
                     ph = mc - co * p.u;
@@ -90,34 +119,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) {
                     const int t = coff[jn] + ph;
-                    bool v = mok && cok[jn];
-                    if (p.convt) v = v && t >= 0 && t < p.Tout;
-                    ok[rr][jn] = v;
-                    off[rr][jn] = v ? row_off + t : 0;   // offset 0 is always a valid element
+                    bool ok = mok && cok[jn];
+                    if (p.convt) ok = ok && t >= 0 && t < p.Tout;
+                    off[rr * NT + jn] = ok ? (unsigned)(row_off + t) * 4u : 0xFFFFFFFFu;
+                    val[rr * NT + jn] = (acc[i][jn][rq * 4 + rr] + bias) * gm;
                 }
             }
-            if (rb) {
+            if (has_res) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int jn = 0; jn < NT; ++jn) rv[rr][jn] = rb[off[rr][jn]];
+                for (int q = 0; q < 4 * NT; ++q) rv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, off[q], 0, 0));
             }
             if (accum) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
+                for (int q = 0; q < 4 * NT; ++q) yo[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, off[q], 0, 0));
+            }
+            if (has_res) {
 #pragma unroll
-                    for (int jn = 0; jn < NT; ++jn) yo[rr][jn] = yb[off[rr][jn]];
+                for (int q = 0; q < 4 * NT; ++q) val[q] += rv[q];
+            }
+            act_apply_all(val, p.post_act, p.slope);
+            if (accum) {
+#pragma unroll
+                for (int q = 0; q < 4 * NT; ++q) val[q] = (yo[q] + val[q]) * p.out_scale;
             }
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                for (int jn = 0; jn < NT; ++jn) {
-                    float v = (acc[i][jn][rq * 4 + rr] + bias[rr]) * gm[rr];
-                    if (rb) v += rv[rr][jn];
-                    v = act_apply(v, p.post_act, p.slope);
-                    if (accum) v = (yo[rr][jn] + v) * p.out_scale;
-                    if (ok[rr][jn]) yb[off[rr][jn]] = v;
-                }
+            for (int q = 0; q < 4 * NT; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[q]), yrs, off[q], 0, 0);
         }
     }
 }
@@ -187,9 +213,12 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- staging plan: thread handles elements e = tid + i*256 of the [8][W] chunk window (same for every chunk) ----
-    int st_off[NE];     // clamped offset (row * Tin + t) relative to the chunk's first channel row; < 0: always zero
-    int st_row[KS == 1 ? NE : 1];   // ks == 1 only: channel row inside the chunk (the offset may carry a batch term)
+    // ---- staging plan: thread handles elements e = sid + i*NTHR of the [CH][WL] chunk window (same for every chunk) ----
+    // st_voff = byte offset of the element relative to the chunk's first channel row, or 0xFFFFFFFF outside [0, Tin):
+    // the loads are raw buffer loads on a per-chunk descriptor, so out-of-range offsets — that marker, and rows of
+    // zero-padded channels past C_in — come back as 0 from the hardware bounds check (no clamp / select / 64-bit VALU).
+    unsigned st_voff[NE];
+    int st_row[KS == 1 ? NE : 1];   // flat mode only: the descriptor spans every batch item, rows are checked explicitly
     const int sid = PRIV ? lane : tid;
     const int tbase = n0 - p.pad_l + (PRIV ? wn * (NT * 32) : 0);
 #pragma unroll
@@ -209,40 +238,41 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
             boff = bb * (int)p.x_bstride;
         }
         ok = ok && t >= 0 && t < p.Tin;
-        const int tc = t < 0 ? 0 : (t > p.Tin - 1 ? p.Tin - 1 : t);
-        st_off[i] = ok ? boff + r * p.Tin + tc : -1;
+        st_voff[i] = ok ? (unsigned)(boff + r * p.Tin + t) * 4u : 0xFFFFFFFFu;
         if (KS == 1) st_row[i < NE ? i : 0] = r;
     }
-    // Staging is split in two halves one chunk apart: load_chunk only ISSUES the global loads (no dependent ALU, so no
-    // wait), store_chunk — one chunk of MFMAs later — applies the bounds mask and the activation and writes LDS.
+    // Staging is split in two halves one chunk apart: load_chunk only ISSUES the loads (no dependent ALU, so no wait),
+    // store_chunk — one chunk of MFMAs later — applies the activation and writes LDS (act(0) == 0 keeps the padding).
     float stage[NE];
+    const long long x_items = flat ? (long long)(p.n_total / p.N) : 1;   // batch items spanned by the descriptor
     auto load_chunk = [&](int c) {
         const int cbase = c * CH;
-        const float* __restrict__ xc = xb + (long long)cbase * p.Tin;
-        const int lim = (p.Cin - cbase) * p.Tin;   // offsets >= lim belong to zero-padded channels (>= Cin)
+        const long long span = x_items * p.x_bstride - (long long)cbase * p.Tin;   // elements from this chunk's first row
+        const long long rows = (long long)(p.Cin - cbase) * p.Tin;
+        const __amdgpu_buffer_rsrc_t xrs =
+            uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)((flat ? span : (rows < span ? rows : span)) * 4));
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const bool ok = st_off[i] >= 0 && (KS == 1 ? st_row[KS == 1 ? i : 0] < p.Cin - cbase : st_off[i] < lim);
-            stage[i] = xc[ok ? st_off[i] : 0];   // unconditional load on an always-valid address
+            unsigned off = st_voff[i];
+            if (KS == 1 && flat) off = st_row[KS == 1 ? i : 0] < p.Cin - cbase ? off : 0xFFFFFFFFu;
+            stage[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
         }
     };
     auto store_chunk = [&](float* dst, int c) {
-        const int lim = (p.Cin - c * CH) * p.Tin;
+        (void)c;
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int e = sid + i * NTHR;
-            const bool ok = st_off[i] >= 0 && (KS == 1 ? st_row[KS == 1 ? i : 0] < p.Cin - c * CH : st_off[i] < lim);
             float v = stage[i];
             if (p.pre_act == FV_ACT_SILU) {
                 v = v * __frcp_rn(1.0f + __expf(-v));
             } else if (p.pre_act != FV_ACT_NONE) {
                 v = act_apply(v, p.pre_act, p.slope);
             }
-            if (e < TOT) dst[e] = ok ? v : 0.f;
+            if (e < TOT) dst[e] = v;
         }
     };
 
-    // A-operand: packed as [m_tile][chunk][tap][lane] float4 (4 channel pairs); wave-uniform base + lane
     const int mt0 = (m_blk * WM + wm) * MT;
     // Weights of m-tile mt are one contiguous stream over the global k-step index g = sub_chunk * KS + tap.  They are
     // fetched with raw buffer loads: descriptor + wave-uniform byte offset in SGPRs, the per-lane part (lane * 16 B) in

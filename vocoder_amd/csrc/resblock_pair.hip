@@ -39,17 +39,6 @@ struct PairGeom {
 
 __device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
 
-// Buffer descriptor over `bytes` bytes at a wave-uniform address.  readfirstlane makes the uniformity provable to hipcc
-// (otherwise every buffer op is wrapped in a waterfall loop).  Raw buffer loads return 0 and raw buffer stores are dropped
-// for offsets >= bytes — that hardware bounds check replaces the clamp / select / branch VALU code of flat accesses.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long a = (unsigned long long)base;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
-                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-
 // As[r][col] = silu(x[r][t0 - HP + col]) for r < C, col < WA_RAW (0 outside [0, T): silu(0) = 0 is the conv's zero padding).
 // Each wave stages C/4 whole rows: per element one buffer load (row descriptor in SGPRs, column offset in a VGPR, out-of-
 // range columns come back as 0 from the hardware bounds check), silu, one ds_write — the PMC profile of the first version
