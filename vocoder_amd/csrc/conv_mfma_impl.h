@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_splitk_kernel(const ConvPara
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
 
-    int st_off[NE];
+    unsigned st_voff[NE];   // byte offset inside the chunk's rows, 0xFFFFFFFF outside [0, Tin) (see conv_mfma_kernel)
     const int tbase = n0 - p.pad_l;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
@@ -424,20 +424,14 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_splitk_kernel(const ConvPara
         const int col = e - r * W;
         const int t = tbase + col;
         const bool ok = in_tile && t >= 0 && t < p.Tin;
-        const int tc = t < 0 ? 0 : (t > p.Tin - 1 ? p.Tin - 1 : t);
-        st_off[i] = ok ? r * p.Tin + tc : -1;
+        st_voff[i] = ok ? (unsigned)(r * p.Tin + t) * 4u : 0xFFFFFFFFu;
     }
     float stage[NE];
     auto load_chunk = [&](int c) {
         const int cbase = c * kChunk;
-        const float* __restrict__ xc = xb + (long long)cbase * p.Tin;
-        const int lim = (p.Cin - cbase) * p.Tin;
+        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)((p.Cin - cbase) * p.Tin) * 4u);
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const bool ok = st_off[i] >= 0 && st_off[i] < lim;
-            const float v = xc[ok ? st_off[i] : 0];
-            stage[i] = ok ? v : 0.f;
-        }
+        for (int i = 0; i < NE; ++i) stage[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_voff[i], 0, 0));
     };
     auto store_chunk = [&](float* dst) {
 #pragma unroll
