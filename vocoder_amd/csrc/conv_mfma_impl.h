@@ -30,7 +30,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
-        case FV_ACT_SILU: return v * __frcp_rn(1.0f + __expf(-v));
+        case FV_ACT_SILU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
         case FV_ACT_LEAKY_RELU: return v >= 0.f ? v : v * slope;
         case FV_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
         case FV_ACT_TANH: return tanhf(v);
@@ -56,7 +56,7 @@ __device__ __forceinline__ void act_apply_all(float (&v)[N], int act, float slop
         case FV_ACT_NONE: break;
         case FV_ACT_SILU:
 #pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = v[i] * __frcp_rn(1.0f + __expf(-v[i]));
+            for (int i = 0; i < N; ++i) v[i] = v[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[i]));
             break;
         default:
 #pragma unroll
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
             const int e = sid + i * NTHR;
             float v = stage[i];
             if (p.pre_act == FV_ACT_SILU) {
-                v = v * __frcp_rn(1.0f + __expf(-v));
+                v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
             } else if (p.pre_act != FV_ACT_NONE) {
                 v = act_apply(v, p.pre_act, p.slope);
             }
