@@ -86,7 +86,7 @@ typedef struct fv_upsampler_config {
     int32_t resblock_dilation_sizes[FV_MAX_KERNELS][FV_MAX_DILATIONS];
     int32_t num_mels;
     int32_t upsample_initial_channel;
-    int32_t use_template; /* must be 0: every shipped YAML sets use_template: false (hifigan.yaml:9) */
+    int32_t use_template; /* 1: pitch-template noise_convs branch (the ctor default; every shipped YAML sets false) */
     int32_t pre_conv_kernel_size;
     int32_t post_conv_kernel_size;
 } fv_upsampler_config;
@@ -166,6 +166,12 @@ FV_API size_t fv_workspace_bytes(const fv_engine* e, int32_t batch, int32_t t_in
  * 256-byte aligned.  Asynchronous on `stream`. */
 FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32_t batch, int32_t t_in, void* d_workspace,
                      size_t workspace_bytes, void* stream);
+
+/* Same, for generators built with use_template=1: d_template is the pitch template (batch, 1, fv_output_length) that the
+ * reference adds through strided `noise_convs` after every up-sampling stage (hifigan.py:192-204,233-234;
+ * forward(x, template), hifigan.py:226).  fv_forward == fv_forward_template with d_template = NULL. */
+FV_API fv_status fv_forward_template(fv_engine* e, const float* d_in, const float* d_template, float* d_out, int32_t batch,
+                                     int32_t t_in, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* -------- single fused conv layer (the hot kernel on its own; used by the parity tests and the roofline
  *          bench).  Stands in for one weight-normed nn.Conv1d / nn.ConvTranspose1d call plus the elementwise

@@ -251,7 +251,19 @@ def resblock1_forward(sd, prefix, x, k, dilations):
     return x
 
 
-def hifigan_forward(sd, cfg, mel, collect=None) -> np.ndarray:
+def noise_conv(sd, prefix, template, stride) -> np.ndarray:
+    """noise_convs[i](template): Conv1d(1, C, k=2*stride, stride=stride, padding=stride//2), or Conv1d(1, C, 1) for the
+    last stage (hifigan.py:192-204).  template: (B, 1, T_audio)."""
+    w = _c(sd[f"{prefix}.weight"])            # (C, 1, k)
+    b = _c(sd[f"{prefix}.bias"])
+    k = w.shape[2]
+    pad = stride // 2 if k > 1 else 0
+    tp = np.pad(_c(template)[:, 0].astype(np.float64), ((0, 0), (pad, pad)))
+    win = np.lib.stride_tricks.sliding_window_view(tp, k, axis=1)[:, ::stride]      # (B, T_out, k)
+    return (np.einsum("btk,ck->bct", win, w[:, 0].astype(np.float64)) + b[None, :, None]).astype(np.float32)
+
+
+def hifigan_forward(sd, cfg, mel, collect=None, template=None) -> np.ndarray:
     """HiFiGANGenerator.forward with use_template=False (hifigan.py:226-249).
 
     cfg keys = the reference ctor kwargs (hifigan.py:137-151).  `collect`, if a dict, receives
@@ -262,8 +274,9 @@ def hifigan_forward(sd, cfg, mel, collect=None) -> np.ndarray:
     rks = list(cfg["resblock_kernel_sizes"])
     rds = [list(d) for d in cfg["resblock_dilation_sizes"]]
     assert prod(rates) == cfg["hop_length"], f"hop_length must be {prod(rates)}"  # hifigan.py:154-156
-    if cfg.get("use_template", False):
-        raise NotImplementedError("use_template=True is out of scope (SURVEY §0.7)")
+    use_template = bool(cfg.get("use_template", False))
+    if use_template and template is None:
+        raise TypeError("use_template=True needs a template (B, 1, T_mel * hop_length)")
     pk, qk = cfg.get("pre_conv_kernel_size", 7), cfg.get("post_conv_kernel_size", 7)
 
     x = conv1d(mel, folded_weight(sd, "conv_pre"), _bias(sd, "conv_pre"), padding=_get_padding(pk))
@@ -273,6 +286,8 @@ def hifigan_forward(sd, cfg, mel, collect=None) -> np.ndarray:
         x = silu(x)                                                           # hifigan.py:230
         x = conv_transpose1d(x, folded_weight(sd, f"ups.{i}"), _bias(sd, f"ups.{i}"),
                              stride=u, padding=(k - u) // 2)                  # hifigan.py:231
+        if use_template:                                                      # hifigan.py:233-234
+            x = x + noise_conv(sd, f"noise_convs.{i}", template, int(prod(rates[i + 1:])))
         if collect is not None:
             collect[f"ups.{i}"] = x
         # ParralelBlock: stack(...).mean(0)  (hifigan.py:132-133)

@@ -218,6 +218,11 @@ def gen_hifigan(name, cfg, seed, B, T, mel_seed, stages=True):
     g = HiFiGANGenerator(**cfg).eval()
     g.load_state_dict(_t(sd), strict=True)
     mel = syn.synthetic_mel(B, cfg["num_mels"], T, mel_seed)
+    if cfg.get("use_template"):
+        tmpl = np.random.default_rng(mel_seed + 1).normal(0.0, 0.5, size=(B, 1, T * cfg["hop_length"])).astype(np.float32)
+        out = g(torch.from_numpy(mel), template=torch.from_numpy(tmpl)).numpy()
+        _save(name, cfg=_cfg_arr(cfg), seed=seed, mel=mel, template=tmpl, out=out, pinned=True)
+        return
     acts = {}
     if stages:
         for i in range(len(cfg["upsample_rates"])):
@@ -392,6 +397,7 @@ def main():
     gen_hifigan("hifigan_v1_t12.npz", dict(syn.HIFIGAN_V1_44K), seed=0, B=1, T=12, mel_seed=1234, stages=False)
     # single-frame clip (ragged minimum)
     gen_hifigan("hifigan_tiny_t1.npz", tiny, seed=3, B=1, T=1, mel_seed=23, stages=False)
+    gen_hifigan("hifigan_template.npz", dict(tiny, use_template=True), seed=13, B=2, T=9, mel_seed=27)
     gen_ops()
     gen_snake()
     cn = dict(input_channels=20, depths=[1, 2], dims=[16, 32], drop_path_rate=0.1, kernel_size=7)

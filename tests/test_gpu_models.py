@@ -91,8 +91,8 @@ def test_strict_loading_errors():
         _hifigan_engine(g["cfg"], wrong)
     with pytest.raises(FishVocError, match="hop_length must be"):
         _hifigan_engine(dict(g["cfg"], hop_length=17), sd)
-    with pytest.raises(FishVocError, match="use_template"):
-        _hifigan_engine(dict(g["cfg"], use_template=True), sd)
+    with pytest.raises(FishVocError, match="noise_convs"):
+        _hifigan_engine(dict(g["cfg"], use_template=True), sd)      # template generator needs the noise_convs weights
 
 
 def test_bigvgan_golden_and_oracle():
@@ -211,3 +211,30 @@ def test_narrow_stage_configs_use_fused_pairs_and_match():
     ref = orc.hifigan_forward(sd, cfg, mel)
     y = _fwd(_hifigan_engine(cfg, sd), mel)
     assert np.abs(y - ref).max() <= TOL
+
+
+def test_template_branch_golden_and_module():
+    """use_template=True: forward(x, template) with the strided noise_convs (reference hifigan.py:226-234)."""
+    from vocoder_amd.modules.generators import HiFiGANGenerator
+    from vocoder_amd.engine import FishVocError
+    g = load_golden("hifigan_template.npz")
+    sd = syn.hifigan_state_dict(g["cfg"], g["seed"])
+    gen = HiFiGANGenerator(**g["cfg"])
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    gen = gen.eval().cuda()
+    y = gen(torch.from_numpy(g["mel"]).cuda(), template=torch.from_numpy(g["template"]).cuda())
+    assert np.abs(y.cpu().numpy() - g["out"]).max() <= TOL
+    with pytest.raises(TypeError):
+        gen(torch.from_numpy(g["mel"]).cuda())
+    eng = _hifigan_engine(g["cfg"], sd)
+    with pytest.raises(FishVocError, match="needs a template"):
+        eng(torch.from_numpy(g["mel"]).cuda())
+    # full V1 config with a template vs the oracle
+    cfg = dict(syn.HIFIGAN_V1_44K, use_template=True)
+    sd = syn.hifigan_state_dict(cfg, 5)
+    mel = syn.synthetic_mel(2, 80, 7, seed=8)
+    tmpl = np.random.default_rng(1).normal(0, 0.5, size=(2, 1, 7 * 512)).astype(np.float32)
+    ref = orc.hifigan_forward(sd, cfg, mel, template=tmpl)
+    y = _hifigan_engine(cfg, sd)(torch.from_numpy(mel).cuda(), None, torch.from_numpy(tmpl).cuda())
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy() - ref).max() <= TOL

@@ -46,8 +46,9 @@ def test_fv_create_validation_without_gpu():
     h = ctypes.c_void_p()
     assert L.fv_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"hop_length must be 512" in L.fv_last_error()
-    cfg.ups = upsampler_config(**dict(syn.HIFIGAN_V1_44K, use_template=True))
-    assert L.fv_create(ctypes.byref(cfg), ctypes.byref(h)) == -2
+    cfg.ups = upsampler_config(**dict(syn.HIFIGAN_V1_44K, use_template=True, upsample_rates=[8, 8, 2, 2, 2, 1],
+                                      upsample_kernel_sizes=[16, 16, 8, 2, 2, 1]))
+    assert L.fv_create(ctypes.byref(cfg), ctypes.byref(h)) == -2   # stride_f0 = 1 before the last stage: length mismatch upstream
     cfg.abi_version = 99
     assert L.fv_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
 
@@ -81,8 +82,10 @@ def test_dropin_state_dict_keys_and_strict_load():
     gen.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     with pytest.raises(RuntimeError):
         gen.load_state_dict({k: torch.from_numpy(v) for k, v in list(sd.items())[1:]}, strict=True)
-    with pytest.raises(NotImplementedError):
-        HiFiGANGenerator(**dict(cfg, use_template=True))
+    tg = HiFiGANGenerator(**dict(cfg, use_template=True))      # the ctor default upstream: noise_convs.{i}.{weight,bias}
+    assert list(tg.state_dict().keys()) == list(syn.hifigan_state_dict(dict(cfg, use_template=True), 3).keys())
+    with pytest.raises(TypeError):
+        tg.eval()(torch.zeros(1, 20, 4))
     with pytest.raises(AssertionError):
         HiFiGANGenerator(**dict(cfg, hop_length=15))
     # no CPU fallback: a CPU tensor must fail loudly, never compute

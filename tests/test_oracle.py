@@ -77,8 +77,15 @@ def test_hifigan_rejects_bad_hop_and_template():
     sd = syn.hifigan_state_dict(cfg, g["seed"])
     with pytest.raises(AssertionError):
         orc.hifigan_forward(sd, dict(cfg, hop_length=cfg["hop_length"] + 1), g["mel"])
-    with pytest.raises(NotImplementedError):
-        orc.hifigan_forward(sd, dict(cfg, use_template=True), g["mel"])
+    with pytest.raises(TypeError):
+        orc.hifigan_forward(sd, dict(cfg, use_template=True), g["mel"])   # template missing
+
+
+def test_hifigan_template_branch_matches_reference():
+    """use_template=True (the reference ctor default): strided noise_convs on the pitch template (hifigan.py:192-204,233)."""
+    g = load_golden("hifigan_template.npz")
+    sd = syn.hifigan_state_dict(g["cfg"], g["seed"])
+    _close(orc.hifigan_forward(sd, g["cfg"], g["mel"], template=g["template"]), g["out"], 2e-5)
 
 
 def test_convnext_forward_matches_reference():

@@ -27,7 +27,7 @@ EXPORTS = (
     "fv_create", "fv_load_weight", "fv_finalize", "fv_destroy", "fv_output_length", "fv_output_channels",
     "fv_input_channels", "fv_workspace_bytes", "fv_forward", "fv_conv_create", "fv_conv_output_length",
     "fv_conv_forward", "fv_conv_destroy", "fv_last_error", "fv_abi_version", "fv_last_kernel",
-    "fv_profile_begin", "fv_profile_end", "fv_conv_pair_forward",
+    "fv_profile_begin", "fv_profile_end", "fv_conv_pair_forward", "fv_forward_template",
 )
 
 _i32 = ctypes.c_int32
@@ -110,6 +110,8 @@ def lib() -> ctypes.CDLL:
     L.fv_workspace_bytes.restype = ctypes.c_size_t
     L.fv_forward.argtypes = [vp, vp, vp, _i32, _i32, vp, ctypes.c_size_t, vp]
     L.fv_forward.restype = _i32
+    L.fv_forward_template.argtypes = [vp, vp, vp, vp, _i32, _i32, vp, ctypes.c_size_t, vp]
+    L.fv_forward_template.restype = _i32
     L.fv_conv_create.argtypes = [ctypes.POINTER(ConvDesc), fp, fp, ctypes.POINTER(vp)]
     L.fv_conv_create.restype = _i32
     L.fv_conv_output_length.argtypes = [vp, _i32]

@@ -135,6 +135,9 @@ struct ResBranch {
 struct UpStage {
     ConvLayer up;
     int ch = 0;
+    // use_template: noise_convs[i] = Conv1d(1, ch, k, stride, pad) on the pitch template (hifigan.py:192-204)
+    float *d_nw = nullptr, *d_nb = nullptr;
+    int nk = 0, nstride = 1, npad = 0;
     std::vector<std::unique_ptr<ResBranch>> branches;
 };
 
@@ -167,6 +170,8 @@ struct UpsamplerModel {
         conv_layer_destroy(conv_pre);
         for (auto& st : stages) {
             conv_layer_destroy(st->up);
+            if (st->d_nw) (void)hipFree(st->d_nw);
+            if (st->d_nb) (void)hipFree(st->d_nb);
             for (auto& br : st->branches) {
                 for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
                     conv_layer_destroy(br->c1[n]);
@@ -270,10 +275,12 @@ struct fv_engine {
         const void* in;
         void* out;
         void* ws;
+        const void* tmpl;
         int batch, t_in;
         hipStream_t stream;
         bool operator==(const GraphKey& o) const {
-            return in == o.in && out == o.out && ws == o.ws && batch == o.batch && t_in == o.t_in && stream == o.stream;
+            return in == o.in && out == o.out && ws == o.ws && tmpl == o.tmpl && batch == o.batch && t_in == o.t_in &&
+                   stream == o.stream;
         }
     };
     struct GraphEntry {
@@ -413,6 +420,7 @@ struct fv_engine {
 
     fv_status run_model(const float* d_in, float* d_out, int batch, int t_in, float* ws, hipStream_t s);
     fv_status run_upsampler(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
+    const float* cur_template = nullptr;   // set by fv_forward_template for the duration of one call
     fv_status run_convnext(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
     fv_status run_head(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
 
@@ -454,6 +462,19 @@ fv_status fv_engine::build_upsampler(const std::string& pfx, bool bigvgan) {
         auto stg = std::make_unique<UpStage>();
         stg->ch = ch;
         if ((st = make_conv(stg->up, pfx + "ups." + std::to_string(i), true, cin, ch, k, 1, (k - u) / 2, u))) return st;
+        if (c.use_template) {
+            int s_f0 = 1;
+            for (int q = i + 1; q < c.num_upsamples; ++q) s_f0 *= c.upsample_rates[q];
+            const bool last_stage = i + 1 == c.num_upsamples;
+            stg->nk = last_stage ? 1 : 2 * s_f0;
+            stg->nstride = last_stage ? 1 : s_f0;
+            stg->npad = last_stage ? 0 : s_f0 / 2;
+            const std::string np_ = pfx + "noise_convs." + std::to_string(i);
+            const HostTensor* t;
+            if ((st = need(np_ + ".weight", {ch, 1, stg->nk}, &t, true))) return st;
+            if ((st = upload(t->data, &stg->d_nw))) return st;
+            if ((st = make_dev_vec(np_ + ".bias", ch, &stg->d_nb))) return st;
+        }
         for (int j = 0; j < c.num_kernels; ++j) {
             auto br = std::make_unique<ResBranch>();
             br->k = c.resblock_kernel_sizes[j];
@@ -644,6 +665,11 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
         if ((st = conv_layer_run(stg->up, r, s))) return st;
         t = (int)stg->up.out_len(t);
         const int ch = stg->ch;
+        if (ups.cfg.use_template) {   // x = x + noise_convs[i](template)  (hifigan.py:233-234)
+            const int Ta = (int)ups.out_len(T);
+            FV_PROF(s, "noise_conv_add", 2.0 * B * ch * stg->nk * t, 8.0 * B * ch * t,
+                    launch_noise_conv_add(cur_template, stg->d_nw, stg->d_nb, S, B, ch, t, Ta, stg->nk, stg->nstride, stg->npad, s));
+        }
         if (multi) FV_HIP_CHECK(hipEventRecord(bev_fork[stage_idx], s));
         // ParralelBlock / stack-mean of the three ResBlock1 / AMPBlock branches (hifigan.py:132-133, bigvgan.py:358-365)
         for (int j = 0; j < nk; ++j) {
@@ -953,9 +979,16 @@ static fv_status validate_ups(const fv_upsampler_config& c) {
         set_error("hop_length must be %lld", (long long)prod);
         return FV_ERR_INVALID;
     }
-    if (c.use_template) {  // SURVEY §0.7
-        set_error("use_template=True is not supported (every shipped config sets use_template: false)");
-        return FV_ERR_UNSUPPORTED;
+    if (c.use_template) {
+        // noise_convs[i] must produce exactly the stage's length: stride_f0 even (or 1), as with every power-of-two rate
+        int s_f0 = 1;
+        for (int i = c.num_upsamples - 1; i >= 1; --i) {
+            s_f0 *= c.upsample_rates[i];
+            if (s_f0 % 2) {
+                set_error("use_template: the product of upsample_rates[%d:] = %d must be even", i, s_f0);
+                return FV_ERR_UNSUPPORTED;
+            }
+        }
     }
     if (c.num_mels < 1 || c.upsample_initial_channel < 1 || c.pre_conv_kernel_size < 1 || c.post_conv_kernel_size < 1 ||
         c.pre_conv_kernel_size % 2 == 0 || c.post_conv_kernel_size % 2 == 0) {
@@ -1174,7 +1207,12 @@ FV_API size_t fv_workspace_bytes(const fv_engine* e, int32_t batch, int32_t t_in
 }
 
 FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32_t batch, int32_t t_in, void* d_workspace,
-                     size_t workspace_bytes, void* stream) {
+                            size_t workspace_bytes, void* stream) {
+    return fv_forward_template(e, d_in, nullptr, d_out, batch, t_in, d_workspace, workspace_bytes, stream);
+}
+
+FV_API fv_status fv_forward_template(fv_engine* e, const float* d_in, const float* d_template, float* d_out, int32_t batch,
+                                     int32_t t_in, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (!e || !d_in || !d_out) {
         set_error("fv_forward: null argument");
         return FV_ERR_INVALID;
@@ -1192,6 +1230,17 @@ FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32
         set_error("fv_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
         return FV_ERR_INVALID;
     }
+    const bool wants_template = (e->cfg.model == FV_MODEL_HIFIGAN || e->cfg.model == FV_MODEL_BIGVGAN || e->cfg.model == FV_MODEL_FIREFLY) &&
+                                e->cfg.ups.use_template;
+    if (wants_template && !d_template) {
+        set_error("fv_forward: this generator was built with use_template=True and needs a template (B, 1, T*hop)");
+        return FV_ERR_INVALID;
+    }
+    if (!wants_template && d_template) {
+        set_error("fv_forward: template given but the generator was built with use_template=False");
+        return FV_ERR_INVALID;
+    }
+    e->cur_template = d_template;
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)d_workspace;
     struct ProfGuard {
@@ -1202,7 +1251,7 @@ FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32
     // hipGraph replay: a forward is ~110 launches plus fork/join events; at small batch the host launch cost dominates
     // (p50 clip latency).  The launch sequence is static for a given (pointers, batch, frames, stream), so the second
     // consecutive call with the same key is stream-captured (including the branch streams) and later calls replay it.
-    fv_engine::GraphKey key{d_in, d_out, d_workspace, batch, t_in, s};
+    fv_engine::GraphKey key{d_in, d_out, d_workspace, d_template, batch, t_in, s};
     const bool graphable = e->use_graph && !e->profiling && s != nullptr;
     if (graphable) {
         for (auto& g : e->graphs)

@@ -170,6 +170,10 @@ fv_status launch_aa_snake(const float* x, float* y, const float* alpha_eff, cons
 fv_status launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                            float* y, int B, int C, int T, int k, float eps, hipStream_t s);
 
+// x[b][c][t] += bias[c] + sum_j w[c][j] * template[b][t*stride + j - pad]  (use_template branch, hifigan.py:233-234)
+fv_status launch_noise_conv_add(const float* tmpl, const float* w, const float* bias, float* x, int B, int C, int T, int Ta,
+                                int k, int stride, int pad, hipStream_t s);
+
 // Log-mel front-end glue (small_kernels.hip)
 // yp[b][r][tp] = wave[b][reflect(tp*hop + r - pad_l)] (0 past the padded length): polyphase layout so that the STFT becomes
 // a stride-1 conv with hop channels and n_fft/hop taps

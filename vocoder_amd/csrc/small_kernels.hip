@@ -424,6 +424,49 @@ fv_status launch_istft_ola(const float* frames, const float* win2, float* y, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pitch-template branch of the up-sampling stages (use_template=True, fish_vocoder/modules/generators/hifigan.py:192-204,
+// 233-234):  x[b][c][t] += bias[c] + sum_j w[c][j] * template[b][t*stride + j - pad]   — a strided Conv1d(1 -> C).
+// Workgroup = 32 output columns x all channels; the template window is staged transposed ([tap][column]) so the FIR reads
+// are conflict-free; the weights of a channel are read by 32 lanes at once (broadcast).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void noise_conv_add_kernel(const float* __restrict__ tmpl, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ x, int C,
+                                                             int T, int Ta, int k, int stride, int pad, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float win[];   // [k][33]
+    const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
+    const int t0 = tile * 32;
+    const float* tb = tmpl + (long long)b * Ta;
+    for (int e = threadIdx.x; e < k * 32; e += 256) {
+        const int j = e % k, tt = e / k;
+        const long long src = (long long)(t0 + tt) * stride + j - pad;
+        win[j * 33 + tt] = (src >= 0 && src < Ta && t0 + tt < T) ? tb[src] : 0.f;
+    }
+    __syncthreads();
+    const int col = threadIdx.x & 31, cg = threadIdx.x >> 5;   // two channel groups per wave64
+    const int t = t0 + col;
+    for (int c = cg; c < C; c += 8) {
+        const float* wc = w + (long long)c * k;
+        float acc = bias[c];
+        for (int j = 0; j < k; ++j) acc = fmaf(wc[j], win[j * 33 + col], acc);
+        if (t < T) x[((long long)b * C + c) * T + t] += acc;
+    }
+}
+
+fv_status launch_noise_conv_add(const float* tmpl, const float* w, const float* bias, float* x, int B, int C, int T, int Ta,
+                                int k, int stride, int pad, hipStream_t s) {
+    const int n_tiles = (T + 31) / 32;
+    const size_t lds = (size_t)k * 33 * sizeof(float);
+    if (lds > 64 * 1024) {
+        set_error("noise_conv: kernel size %d needs %zu B of LDS (> 64 KiB)", k, lds);
+        return FV_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(noise_conv_add_kernel, dim3(B * n_tiles), dim3(256), lds, s, tmpl, w, bias, x, C, T, Ta, k, stride, pad,
+                       n_tiles);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Log-mel front-end (fish_vocoder/data/transforms/spectrogram.py:25-56): reflect padding + polyphase re-layout, magnitude.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void polyphase_reflect_kernel(const float* __restrict__ wave, float* __restrict__ yp,

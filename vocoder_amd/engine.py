@@ -141,7 +141,7 @@ class Engine:
     def workspace_bytes(self, batch: int, t_in: int) -> int:
         return int(self._lib.fv_workspace_bytes(self._h, int(batch), int(t_in)))
 
-    def forward(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, out: torch.Tensor | None = None, template: torch.Tensor | None = None) -> torch.Tensor:
         _require_cuda(x, "Engine.forward")
         if x.dim() != 3 or x.shape[1] != self.in_channels:
             raise ValueError(f"expected input of shape (B, {self.in_channels}, T), got {tuple(x.shape)}")
@@ -152,6 +152,13 @@ class Engine:
         L = self.output_length(T)
         if out is None:
             out = torch.empty((B, self.out_channels, L), dtype=torch.float32, device=x.device)
+        tptr = None
+        if template is not None:
+            _require_cuda(template, "Engine.forward template")
+            template = template.contiguous()
+            if tuple(template.shape) != (B, 1, L):
+                raise ValueError(f"expected template of shape {(B, 1, L)}, got {tuple(template.shape)}")
+            tptr = template.data_ptr()
         need = self.workspace_bytes(B, T)
         if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != x.device:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
@@ -164,15 +171,16 @@ class Engine:
                     self._side = torch.cuda.Stream(x.device)
                 side = self._side
                 side.wait_stream(cur)
-                check(self._lib.fv_forward(self._h, x.data_ptr(), out.data_ptr(), B, T, self._ws.data_ptr(),
-                                           self._ws.numel() * 4, int(side.cuda_stream)))
+                check(self._lib.fv_forward_template(self._h, x.data_ptr(), tptr, out.data_ptr(), B, T, self._ws.data_ptr(),
+                                                    self._ws.numel() * 4, int(side.cuda_stream)))
                 cur.wait_stream(side)
             else:
-                check(self._lib.fv_forward(self._h, x.data_ptr(), out.data_ptr(), B, T, self._ws.data_ptr(),
-                                           self._ws.numel() * 4, int(cur.cuda_stream)))
+                check(self._lib.fv_forward_template(self._h, x.data_ptr(), tptr, out.data_ptr(), B, T, self._ws.data_ptr(),
+                                                    self._ws.numel() * 4, int(cur.cuda_stream)))
         return out
 
-    __call__ = forward
+    def __call__(self, x, out=None, template=None):
+        return self.forward(x, out, template)
 
     def profile(self, x: torch.Tensor, repeats: int = 3) -> list[dict]:
         """Per-kernel hipEvent timings of `repeats` forwards (fv_profile_begin/end): a list of

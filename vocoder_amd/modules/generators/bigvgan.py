@@ -19,7 +19,7 @@ from torch.nn.utils.parametrizations import weight_norm
 from .. import _base
 from ... import _lib
 from ...engine import Engine, upsampler_config
-from .hifigan import ResBlockParams, _normal_init, get_padding
+from .hifigan import ResBlockParams, _normal_init, get_padding, noise_conv_params
 
 
 def kaiser_sinc_filter1d(cutoff: float, half_width: float, kernel_size: int) -> torch.Tensor:
@@ -105,21 +105,19 @@ class BigVGANGenerator(_base.EngineModule):
     ):
         super().__init__()
         assert prod(upsample_rates) == hop_length, f"hop_length must be {prod(upsample_rates)}"
-        if use_template:
-            raise NotImplementedError("use_template=True is out of scope; pass use_template=False")
         if activation is not SnakeBeta:
             raise NotImplementedError("only activation=SnakeBeta (the reference default, bigvgan.py:266) is built")
-        self.use_template = False
+        self.use_template = bool(use_template)
         self.num_upsamples, self.num_kernels = len(upsample_rates), len(resblock_kernel_sizes)
         self._cfg = dict(
             hop_length=hop_length, upsample_rates=list(upsample_rates),
             upsample_kernel_sizes=list(upsample_kernel_sizes), resblock_kernel_sizes=list(resblock_kernel_sizes),
             resblock_dilation_sizes=[list(d) for d in resblock_dilation_sizes], num_mels=num_mels,
-            upsample_initial_channel=upsample_initial_channel, use_template=False,
+            upsample_initial_channel=upsample_initial_channel, use_template=self.use_template,
             pre_conv_kernel_size=pre_conv_kernel_size, post_conv_kernel_size=post_conv_kernel_size)
         c0 = upsample_initial_channel
         self.conv_pre = weight_norm(nn.Conv1d(num_mels, c0, pre_conv_kernel_size, padding=get_padding(pre_conv_kernel_size)))
-        self.noise_convs = nn.ModuleList()
+        self.noise_convs = noise_conv_params(c0, upsample_rates) if self.use_template else nn.ModuleList()
         self.ups = nn.ModuleList(
             weight_norm(nn.ConvTranspose1d(c0 >> i, c0 >> (i + 1), k, u, padding=(k - u) // 2))
             for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)))
@@ -136,6 +134,6 @@ class BigVGANGenerator(_base.EngineModule):
         return Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**self._cfg), state_dict=state_dict)
 
     def forward(self, x, template=None):
-        if template is not None:
-            raise NotImplementedError("template input is only used with use_template=True (out of scope)")
-        return self._run(x)
+        if self.use_template and template is None:
+            raise TypeError("use_template=True: forward needs template (B, 1, T_mel * hop_length)")
+        return self._run(x, template if self.use_template else None)

@@ -32,6 +32,21 @@ def _normal_init(module: nn.Module, std: float = 0.01) -> None:
             m.weight = m.weight.detach().normal_(0.0, std)
 
 
+def noise_conv_params(c0: int, upsample_rates) -> nn.ModuleList:
+    """``noise_convs.{i}``: strided Conv1d(1 -> C_i) applied to the pitch template after up-sampling stage i
+    (reference hifigan.py:192-204); plain convs, no weight-norm."""
+    convs = nn.ModuleList()
+    n = len(upsample_rates)
+    for i in range(n):
+        ch = c0 >> (i + 1)
+        if i + 1 < n:
+            s = int(prod(upsample_rates[i + 1:]))
+            convs.append(nn.Conv1d(1, ch, kernel_size=2 * s, stride=s, padding=s // 2))
+        else:
+            convs.append(nn.Conv1d(1, ch, kernel_size=1))
+    return convs
+
+
 class ResBlockParams(nn.Module):
     """Parameter container named like ResBlock1 / AMPBlock: ``convs1.{n}`` (dilated) and ``convs2.{n}``."""
 
@@ -75,27 +90,23 @@ class HiFiGANGenerator(_base.EngineModule):
     ):
         super().__init__()
         assert prod(upsample_rates) == hop_length, f"hop_length must be {prod(upsample_rates)}"
-        if use_template:
-            raise NotImplementedError(
-                "use_template=True (pitch-template noise_convs, hifigan.py:192-204) is out of scope: every shipped "
-                "config sets `use_template: false`; pass use_template=False")
         act = post_activation()
         if not isinstance(act, nn.SiLU):
             raise NotImplementedError("post_activation must be nn.SiLU (the reference default, hifigan.py:150)")
         self.activation_post = act  # no parameters; kept for repr/state parity
-        self.use_template = False
+        self.use_template = bool(use_template)
         self.num_upsamples = len(upsample_rates)
         self.num_kernels = len(resblock_kernel_sizes)
         self._cfg = dict(
             hop_length=hop_length, upsample_rates=list(upsample_rates),
             upsample_kernel_sizes=list(upsample_kernel_sizes), resblock_kernel_sizes=list(resblock_kernel_sizes),
             resblock_dilation_sizes=[list(d) for d in resblock_dilation_sizes], num_mels=num_mels,
-            upsample_initial_channel=upsample_initial_channel, use_template=False,
+            upsample_initial_channel=upsample_initial_channel, use_template=self.use_template,
             pre_conv_kernel_size=pre_conv_kernel_size, post_conv_kernel_size=post_conv_kernel_size)
 
         c0 = upsample_initial_channel
         self.conv_pre = weight_norm(nn.Conv1d(num_mels, c0, pre_conv_kernel_size, padding=get_padding(pre_conv_kernel_size)))
-        self.noise_convs = nn.ModuleList()  # empty without a template, as upstream
+        self.noise_convs = noise_conv_params(c0, upsample_rates) if self.use_template else nn.ModuleList()
         self.ups = nn.ModuleList(
             weight_norm(nn.ConvTranspose1d(c0 >> i, c0 >> (i + 1), k, u, padding=(k - u) // 2))
             for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)))
@@ -111,6 +122,6 @@ class HiFiGANGenerator(_base.EngineModule):
         return Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**self._cfg), state_dict=state_dict)
 
     def forward(self, x, template=None):
-        if template is not None:
-            raise NotImplementedError("template input is only used with use_template=True (out of scope)")
-        return self._run(x)
+        if self.use_template and template is None:
+            raise TypeError("use_template=True: forward needs template (B, 1, T_mel * hop_length)")
+        return self._run(x, template if self.use_template else None)   # like upstream, an unused template is ignored

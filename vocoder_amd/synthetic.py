@@ -56,6 +56,14 @@ def hifigan_state_dict(cfg: dict, seed: int = 0) -> dict:
     nm = cfg["num_mels"]
     pk, qk = cfg.get("pre_conv_kernel_size", 7), cfg.get("post_conv_kernel_size", 7)
     _put_wn(sd, "conv_pre", rng, (c0, nm, pk), nm * pk, 0.35, c0)
+    if cfg.get("use_template", False):   # reference key order: conv_pre, noise_convs, ups, resblocks, conv_post
+        rates = list(cfg["upsample_rates"])
+        for i in range(len(rates)):
+            ch = c0 // 2 ** (i + 1)
+            s_f0 = int(np.prod(rates[i + 1:])) if i + 1 < len(rates) else 1
+            k = 2 * s_f0 if i + 1 < len(rates) else 1
+            sd[f"noise_convs.{i}.weight"] = rng.normal(0.0, 0.5 / sqrt(k), size=(ch, 1, k)).astype(np.float32)
+            sd[f"noise_convs.{i}.bias"] = rng.normal(0.0, 0.05, size=ch).astype(np.float32)
     for i, (u, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
         cin, cout = c0 // 2**i, c0 // 2 ** (i + 1)
         # ConvTranspose1d weight is (C_in, C_out, k): weight-norm dim 0 = C_in
