@@ -75,6 +75,15 @@ typedef enum fv_act {
     FV_ACT_LOG_CLAMP = 5   /* log(clamp(x, min=1e-5)) (spectrogram.py:93-94) */
 } fv_act;
 
+/* Arithmetic of the MFMA-bound conv layers.  The reference computes in fp32; FV_PRECISION_F32 reproduces that
+ * with exact-fp32 matrix instructions and is the default.  FV_PRECISION_F16X3 is opt-in: each fp32 operand is split in two
+ * fp16 planes and three fp16 products accumulate in fp32 (error ~2^-22 per product instead of 2^-24; activations must
+ * stay below 65504 in magnitude) — same API, same parity tolerance, several times the throughput. */
+typedef enum fv_precision {
+    FV_PRECISION_F32 = 0,
+    FV_PRECISION_F16X3 = 1
+} fv_precision;
+
 /* HiFiGANGenerator / BigVGANGenerator ctor kwargs (hifigan.py:137-151, bigvgan.py:256-270). */
 typedef struct fv_upsampler_config {
     int32_t hop_length;
@@ -150,6 +159,10 @@ FV_API fv_status fv_finalize(fv_engine* e);
 
 FV_API void fv_destroy(fv_engine* e);
 
+/* Selects the arithmetic of the conv layers (fv_precision).  Call between fv_create and fv_finalize (the weight planes
+ * are packed at finalize; later -> FV_ERR_STATE).  No reference counterpart: torch runs this path in fp32 only. */
+FV_API fv_status fv_set_precision(fv_engine* e, int32_t precision);
+
 /* -------- forward: replaces `self.generator(input_spec)` (gan.py:286) -------- */
 
 /* Output length per clip for T_in input frames (T_mel * hop_length for the generators). */
@@ -200,6 +213,9 @@ FV_API fv_status fv_conv_forward(fv_conv* c, const float* d_x, float* d_y, const
  * k in {3, 7, 11}, dilation in {1, 3, 5} (else FV_ERR_UNSUPPORTED).  d_y must not alias d_x. */
 FV_API fv_status fv_conv_pair_forward(fv_conv* c1, fv_conv* c2, const float* d_x, float* d_y, int32_t batch, int32_t t,
                                       void* stream);
+/* fv_precision for the following fv_conv_forward calls on this layer; layers the split-fp16 kernels do not cover
+ * (transposed, C_in < 32, kernel size not in {3, 7, 11}) keep running in fp32. */
+FV_API fv_status fv_conv_set_precision(fv_conv* c, int32_t precision);
 FV_API void fv_conv_destroy(fv_conv* c);
 
 /* -------- per-launch timing (measurement aid; bench.py's roofline leg) --------

@@ -1,0 +1,105 @@
+"""GPU: the opt-in f16x3 precision mode (split-fp16 MFMA, vocoder_amd/csrc/conv_f16x3_impl.h) against the CPU oracle.
+Same tolerance as the fp32 path: |d| <= 1e-4 absolute (north_star); the split keeps ~22 mantissa bits per product, so the
+observed error must also stay in the fp32-roundoff class (<= 2e-5 of the output scale)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test on a box without a GPU"
+    return torch.device("cuda:0")
+
+
+def _conv(w, b, x, res, precision, **kw):
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import FusedConv
+    conv = FusedConv(w, b, **kw).set_precision(precision)
+    xt = torch.from_numpy(x).to(_dev())
+    rt = None if res is None else torch.from_numpy(res).to(_dev())
+    y = conv(xt, rt)
+    torch.cuda.synchronize()
+    return y.cpu().numpy(), _lib.last_kernel()
+
+
+CASES = [
+    # (Cin, Cout, k, dil, B, T)
+    (128, 128, 11, 1, 2, 517), (128, 128, 7, 3, 1, 300), (128, 128, 3, 5, 2, 1000),
+    (256, 256, 11, 5, 1, 97), (256, 256, 3, 1, 2, 688), (256, 256, 7, 1, 1, 130),
+    (64, 64, 11, 3, 2, 700), (64, 64, 7, 5, 1, 1025), (64, 64, 3, 1, 3, 259),
+    (48, 96, 7, 1, 2, 200),      # C_in not a multiple of 16 chunks? 48 = 3 chunks; M = 96 -> partial m-block
+    (40, 64, 3, 3, 1, 77),       # C_in = 40 -> zero-padded half chunk
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,d,B,T", CASES)
+def test_f16x3_conv_matches_oracle(cin, cout, k, d, B, T):
+    from vocoder_amd import _lib
+    rng = np.random.default_rng(cin * 1000 + cout + k * 7 + d)
+    x = (rng.normal(size=(B, cin, T)) * 3.0).astype(np.float32)
+    w = (rng.normal(size=(cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    pad = (k * d - d) // 2
+    ref = orc.conv1d(orc.silu(x), w, b, dilation=d, padding=pad)
+    res = rng.normal(size=ref.shape).astype(np.float32)
+    y, kern = _conv(w, b, x, res, "f16x3", dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
+    assert kern.startswith("conv_f16x3"), kern
+    ref = ref + res
+    err = np.abs(y - ref).max()
+    scale = max(np.abs(ref).max(), 1.0)
+    assert err <= 1e-4 and err <= 2e-5 * scale, f"max|d|={err:.3e} scale={scale:.2f} ({kern})"
+    # and it must be at least as close to the oracle as 4x the exact-fp32 kernel's own error (fp32-class accuracy)
+    y32, kern32 = _conv(w, b, x, res, "f32", dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
+    assert kern32.startswith("conv_mfma"), kern32
+    err32 = np.abs(y32 - ref).max()
+    assert err <= max(4 * err32, 2e-6 * scale), f"f16x3 {err:.3e} vs f32 {err32:.3e}"
+
+
+def test_f16x3_wide_dynamic_range():
+    """Activations spanning 1e-6 .. 1e3 and weights spanning 2^-20 of their maximum: the split must degrade gracefully
+    (absolute error bounded by the fp32-roundoff of the large terms)."""
+    from vocoder_amd import _lib
+    rng = np.random.default_rng(11)
+    cin = cout = 64
+    k, d, T = 7, 1, 400
+    x = (rng.normal(size=(1, cin, T)) * np.exp(rng.uniform(np.log(1e-6), np.log(1e3), size=(1, cin, T)))).astype(np.float32)
+    w = (rng.normal(size=(cout, cin, k)) * np.exp2(rng.uniform(-20, 0, size=(cout, cin, k)))).astype(np.float32)
+    pad = (k - 1) // 2
+    y, kern = _conv(w, None, x, None, "f16x3", dilation=d, padding=pad)
+    assert kern.startswith("conv_f16x3"), kern
+    ref64 = orc.conv1d(x.astype(np.float64).astype(np.float32), w, None, dilation=d, padding=pad)
+    mag = orc.conv1d(np.abs(x), np.abs(w), None, dilation=d, padding=pad)   # sum |x w|
+    rel = np.abs(y - ref64) / np.maximum(mag, 1e-30)
+    assert rel.max() < 2e-6, rel.max()
+
+
+def test_f16x3_falls_back_to_f32_kernels_where_not_covered():
+    from vocoder_amd import _lib
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(1, 16, 100)).astype(np.float32)
+    w = rng.normal(size=(16, 16, 3)).astype(np.float32) * 0.1
+    y, kern = _conv(w, None, x, None, "f16x3", padding=1)
+    assert kern.startswith("conv_mfma"), kern
+    np.testing.assert_allclose(y, orc.conv1d(x, w, None, padding=1), atol=1e-5)
+
+
+def test_f16x3_hifigan_model_matches_oracle():
+    """Whole generator in f16x3 mode vs the oracle (tolerance 1e-4 on the waveform, north_star)."""
+    from vocoder_amd import synthetic
+    from vocoder_amd.modules.generators.hifigan import HiFiGANGenerator
+    cfg = dict(synthetic.HIFIGAN_V1_44K)
+    sd = synthetic.hifigan_state_dict(cfg, seed=0)
+    mel = synthetic.synthetic_mel(1, cfg["num_mels"], 12, seed=1)
+    ref = orc.hifigan_forward(sd, cfg, mel)
+    gen = HiFiGANGenerator(**cfg).eval()
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    gen.precision = "f16x3"
+    y = gen.to(_dev())(torch.from_numpy(mel).to(_dev())).cpu().numpy()
+    assert np.abs(y - ref).max() <= 1e-4, np.abs(y - ref).max()
+    prof = gen.engine(_dev()).profile(torch.from_numpy(mel).to(_dev()))
+    assert any(r["kernel"].startswith("conv_f16x3") for r in prof), [r["kernel"] for r in prof][:5]

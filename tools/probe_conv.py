@@ -12,6 +12,7 @@ from vocoder_amd.engine import FusedConv
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"])
 ap.add_argument("--quick", action="store_true", help="MFMA-bound stages, d=1 only, no transposed convs")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -26,7 +27,7 @@ for C, T in stages:
     for k in (3, 7, 11):
         for d in ((1,) if args.quick else (1, 3, 5)):
             w = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
-            conv = FusedConv(w, np.zeros(C, np.float32), dilation=d, padding=(k * d - d) // 2, pre_act=_lib.FV_ACT_SILU)
+            conv = FusedConv(w, np.zeros(C, np.float32), dilation=d, padding=(k * d - d) // 2, pre_act=_lib.FV_ACT_SILU).set_precision(args.precision)
             x = torch.randn(B, C, T, device=dev)
             r = torch.randn(B, C, T, device=dev)
             y = torch.empty_like(x)

@@ -21,6 +21,8 @@ FV_MAX_DILATIONS = 3
 
 FV_MODEL_HIFIGAN, FV_MODEL_BIGVGAN, FV_MODEL_VOCOS, FV_MODEL_FIREFLY, FV_MODEL_CONVNEXT, FV_MODEL_ISTFT_HEAD = 1, 2, 3, 4, 5, 6
 FV_MODEL_LOGMEL = 7
+FV_PRECISION_F32, FV_PRECISION_F16X3 = 0, 1
+PRECISIONS = {"f32": FV_PRECISION_F32, "f16x3": FV_PRECISION_F16X3}
 FV_ACT_NONE, FV_ACT_SILU, FV_ACT_LEAKY_RELU, FV_ACT_GELU, FV_ACT_TANH, FV_ACT_LOG_CLAMP = 0, 1, 2, 3, 4, 5
 
 EXPORTS = (
@@ -28,6 +30,7 @@ EXPORTS = (
     "fv_input_channels", "fv_workspace_bytes", "fv_forward", "fv_conv_create", "fv_conv_output_length",
     "fv_conv_forward", "fv_conv_destroy", "fv_last_error", "fv_abi_version", "fv_last_kernel",
     "fv_profile_begin", "fv_profile_end", "fv_conv_pair_forward", "fv_forward_template",
+    "fv_set_precision", "fv_conv_set_precision",
 )
 
 _i32 = ctypes.c_int32
@@ -122,6 +125,10 @@ def lib() -> ctypes.CDLL:
     L.fv_conv_destroy.restype = None
     L.fv_conv_pair_forward.argtypes = [vp, vp, vp, vp, _i32, _i32, vp]
     L.fv_conv_pair_forward.restype = _i32
+    L.fv_set_precision.argtypes = [vp, _i32]
+    L.fv_set_precision.restype = _i32
+    L.fv_conv_set_precision.argtypes = [vp, _i32]
+    L.fv_conv_set_precision.restype = _i32
     L.fv_profile_begin.argtypes = [vp]
     L.fv_profile_begin.restype = _i32
     L.fv_profile_end.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]

@@ -1,5 +1,6 @@
 // Host side of the fused conv layer: weight re-layout into MFMA fragment order, tile selection, dispatch.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "fv_internal.h"
@@ -35,8 +36,52 @@ static void pack_conv_weights(const std::vector<float>& wc, int M, int Cin, int 
                 }
 }
 
+// f16x3 precision mode (conv_f16x3_impl.h).  Packed layout, 16-byte units (8 halfs):
+//   [((m_tile * nch16 + chunk) * ks + tap) * 3 + plane] * 64 + lane,   halfs i = 0..7:
+//   plane(Wc[m_tile*32 + (lane & 31)][chunk*16 + 8*(lane >> 5) + i][tap] * s_w),   planes: wh, wl = w*s_w - wh, wh * 2^-11
+// = the A fragment of v_mfma_f32_32x32x16_f16 for k-block (chunk, tap).  s_w: power of two with max|w| * s_w in [2^13, 2^14).
+static float pack_conv_weights_f16x3(const std::vector<float>& wc, int M, int Cin, int ks, int m_pad, int nch16,
+                                     std::vector<_Float16>& out) {
+    float wmax = 0.f;
+    for (float v : wc) wmax = std::max(wmax, std::fabs(v));
+    int e = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) {
+        (void)std::frexp(wmax, &e);   // wmax = f * 2^e, f in [0.5, 1)
+        e = 14 - e;                   // wmax * 2^e in [2^13, 2^14)
+    }
+    const float s_w = std::ldexp(1.0f, e);
+    const int mtiles = m_pad / 32;
+    // + 4 zero k-blocks after the last m-tile: the weight prefetch runs a few blocks past the end
+    out.assign(((size_t)mtiles * nch16 * ks + 4) * 3 * 64 * 8, (_Float16)0.f);
+    for (int mt = 0; mt < mtiles; ++mt)
+        for (int c = 0; c < nch16; ++c)
+            for (int j = 0; j < ks; ++j)
+                for (int l = 0; l < 64; ++l) {
+                    const int m = mt * 32 + (l & 31);
+                    if (m >= M) continue;
+                    const size_t blk = (((size_t)mt * nch16 + c) * ks + j) * 3;
+                    for (int i = 0; i < 8; ++i) {
+                        const int ci = c * 16 + 8 * (l >> 5) + i;
+                        if (ci >= Cin) continue;
+                        const float w = wc[((size_t)m * Cin + ci) * ks + j] * s_w;   // exact: power-of-two scale
+                        const _Float16 wh = (_Float16)w;
+                        const _Float16 wl = (_Float16)(w - (float)wh);
+                        const _Float16 whs = (_Float16)((float)wh * (1.0f / 2048.0f));
+                        out[((blk + 0) * 64 + l) * 8 + i] = wh;
+                        out[((blk + 1) * 64 + l) * 8 + i] = wl;
+                        out[((blk + 2) * 64 + l) * 8 + i] = whs;
+                    }
+                }
+    return s_w;
+}
+
+// layers the split-fp16 kernels cover: MFMA-bound stride-1 convs with the ResBlock kernel sizes
+static bool f16x3_eligible(bool transposed, int c_in, int M, int ks, int dil) {
+    return !transposed && c_in >= 32 && M >= 64 && (ks == 3 || ks == 7 || ks == 11) && (dil == 1 || dil == 3 || dil == 5);
+}
+
 fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, int k, int dil, int padding,
-                            int stride, const float* host_w, const float* host_bias) {
+                            int stride, const float* host_w, const float* host_bias, bool with_f16x3) {
     if (c_in <= 0 || c_out <= 0 || k <= 0 || dil <= 0 || stride <= 0 || padding < 0) {
         set_error("conv_layer_create: invalid geometry (c_in=%d c_out=%d k=%d dil=%d pad=%d stride=%d)", c_in, c_out,
                   k, dil, padding, stride);
@@ -89,6 +134,13 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
     FV_HIP_CHECK(hipMalloc((void**)&L.d_bias, bias.size() * sizeof(float)));
     FV_HIP_CHECK(hipMemcpy(L.d_wp, packed.data(), L.wp_bytes, hipMemcpyHostToDevice));
     FV_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (with_f16x3 && f16x3_eligible(transposed, c_in, L.M, L.ks, L.dil)) {
+        L.nch16 = (c_in + 15) / 16;
+        std::vector<_Float16> ph;
+        L.w_scale = pack_conv_weights_f16x3(wc, L.M, c_in, L.ks, L.m_pad, L.nch16, ph);
+        FV_HIP_CHECK(hipMalloc(&L.d_wph, ph.size() * sizeof(_Float16)));
+        FV_HIP_CHECK(hipMemcpy(L.d_wph, ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    }
     if (!transposed && c_in == 16 && c_out == 16) {
         // v_mfma_f32_16x16x4_f32 A fragments: [tap][lane] float4, .q = W[lane & 15][4q + (lane >> 4)][tap]
         std::vector<float> p16((size_t)k * 64 * 4);
@@ -106,6 +158,8 @@ void conv_layer_destroy(ConvLayer& L) {
     if (L.d_wp) (void)hipFree(L.d_wp);
     if (L.d_bias) (void)hipFree(L.d_bias);
     if (L.d_wp16) (void)hipFree(L.d_wp16);
+    if (L.d_wph) (void)hipFree(L.d_wph);
+    L.d_wph = nullptr;
     L.d_wp16 = nullptr;
     L.d_wp = nullptr;
     L.d_bias = nullptr;
@@ -141,6 +195,55 @@ static int choose_tile(int M, long long N, int batch) {
 }
 
 static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64"};
+
+static const char* const kSplitNames[SPLIT_COUNT] = {"128x256", "128x128", "64x256"};
+
+// f16x3 precision mode: tile choice + dispatch of the split-fp16 kernel (p already describes the layer call)
+static fv_status conv_layer_run_f16x3(const ConvLayer& L, const ConvRun& r, ConvParams& p, hipStream_t stream) {
+    p.wph = L.d_wph;
+    p.nch16 = L.nch16;
+    p.nch16_real = L.nch16;
+    p.acc_scale = 1.0f / L.w_scale;
+    int cfg;
+    if (L.M <= 64) {
+        cfg = SPLIT_64x256;
+    } else {
+        // 256-column tiles unless they leave the chip under-filled or pad a lot more columns than 128-column ones
+        const long long t256 = (p.N + 255) / 256, t128 = (p.N + 127) / 128;
+        const long long blocks256 = t256 * ((L.M + 127) / 128) * r.batch;
+        cfg = (blocks256 < 512 || t128 * 128 * 1.04 < t256 * 256.0) ? SPLIT_128x128 : SPLIT_128x256;
+    }
+    const int mb = cfg == SPLIT_64x256 ? 64 : 128, nb = cfg == SPLIT_128x128 ? 128 : 256;
+    p.m_blks = (L.M + mb - 1) / mb;
+    p.n_tiles = (p.N + nb - 1) / nb;
+    const int prof_idx = prof_begin(stream);
+    bool ok = false;
+    switch (L.ks) {
+        case 3: ok = launch_conv_f16x3_k3(p, cfg, r.batch, stream); break;
+        case 7: ok = launch_conv_f16x3_k7(p, cfg, r.batch, stream); break;
+        case 11: ok = launch_conv_f16x3_k11(p, cfg, r.batch, stream); break;
+        default: break;
+    }
+    if (!ok) {
+        set_error("conv_layer_run: no f16x3 kernel for (k=%d, dilation=%d)", L.ks, L.dil);
+        return FV_ERR_UNSUPPORTED;
+    }
+    static thread_local char name[96];
+    std::snprintf(name, sizeof(name), "conv_f16x3<k=%d d=%d tile=%s>", L.ks, L.dil, kSplitNames[cfg]);
+    set_last_kernel(name);
+    if (prof_idx >= 0) {
+        const long long tout = L.out_len(r.t_in);
+        const double macs = (double)L.c_in * L.c_out * L.k * (double)tout * r.batch;
+        double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
+        if (r.res) elems += (double)L.c_out * tout;
+        if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
+        char lbl[160];
+        std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d grid=%d", name, L.c_in, L.c_out, r.batch * p.m_blks * p.n_tiles);
+        prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
+    }
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
 
 fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t stream) {
     if (!L.d_wp) {
@@ -190,6 +293,9 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     p.Cout = L.c_out;
     p.x_bstride = (long long)L.c_in * r.t_in;
     p.y_bstride = (long long)L.c_out * tout;
+    p.acc_scale = 1.0f;
+
+    if (L.precision == FV_PRECISION_F16X3 && L.d_wph) return conv_layer_run_f16x3(L, r, p, stream);
 
     int cfg = choose_tile(L.M, p.N, r.batch);
     // pointwise convs have no halo, so batch and time flatten into one GEMM column axis: no per-item partial tiles

@@ -122,7 +122,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     bool ok = mok && cok[jn];
                     if (p.convt) ok = ok && t >= 0 && t < p.Tout;
                     off[rr * NT + jn] = ok ? (unsigned)(row_off + t) * 4u : 0xFFFFFFFFu;
-                    val[rr * NT + jn] = (acc[i][jn][rq * 4 + rr] + bias) * gm;
+                    val[rr * NT + jn] = fmaf(acc[i][jn][rq * 4 + rr], p.acc_scale, bias) * gm;   // acc_scale == 1: exact
                 }
             }
             if (has_res) {

@@ -270,6 +270,7 @@ struct fv_engine {
     bool has_ups = false, has_cnx = false, has_head = false;
     Profiler prof;
     bool profiling = false;
+    int precision = FV_PRECISION_F32;   // fv_set_precision
     bool fuse_pairs = true;   // FV_NO_PAIR_FUSION=1 in the environment disables the fused (c1, c2) kernels (A/B runs)
     struct GraphKey {
         const void* in;
@@ -372,7 +373,10 @@ struct fv_engine {
         if (st) return st;
         st = vec(prefix + ".bias", c_out, b);
         if (st) return st;
-        return conv_layer_create(L, transposed, c_in, c_out, k, dil, padding, stride, w.data(), b.data());
+        st = conv_layer_create(L, transposed, c_in, c_out, k, dil, padding, stride, w.data(), b.data(),
+                               precision == FV_PRECISION_F16X3);
+        L.precision = precision;
+        return st;
     }
     fv_status make_dev_vec(const std::string& name, int64_t n, float** d) {
         std::vector<float> v;
@@ -1103,6 +1107,23 @@ FV_API fv_status fv_load_weight(fv_engine* e, const char* name, const float* hos
     return FV_OK;
 }
 
+FV_API fv_status fv_set_precision(fv_engine* e, int32_t precision) {
+    if (!e) {
+        set_error("fv_set_precision: null engine");
+        return FV_ERR_INVALID;
+    }
+    if (precision != FV_PRECISION_F32 && precision != FV_PRECISION_F16X3) {
+        set_error("fv_set_precision: unknown precision %d", precision);
+        return FV_ERR_INVALID;
+    }
+    if (e->finalized) {
+        set_error("fv_set_precision: engine already finalized (the weight planes are packed at fv_finalize)");
+        return FV_ERR_STATE;
+    }
+    e->precision = precision;
+    return FV_OK;
+}
+
 FV_API fv_status fv_finalize(fv_engine* e) {
     if (!e) {
         set_error("fv_finalize: null engine");
@@ -1413,7 +1434,7 @@ FV_API fv_status fv_conv_create(const fv_conv_desc* d, const float* host_weight,
     c->desc = *d;
     fv_status st = conv_layer_create(c->L, d->transposed != 0, d->c_in, d->c_out, d->kernel_size,
                                      d->transposed ? 1 : d->dilation, d->padding, d->transposed ? d->stride : 1,
-                                     host_weight, host_bias);
+                                     host_weight, host_bias, /*with_f16x3=*/true);
     if (st) {
         conv_layer_destroy(c->L);
         delete c;
@@ -1455,6 +1476,15 @@ FV_API fv_status fv_conv_pair_forward(fv_conv* c1, fv_conv* c2, const float* d_x
         return FV_ERR_INVALID;
     }
     return conv_pair_run(c1->L, c2->L, d_x, d_y, batch, t, OUT_SET, 1.0f, (hipStream_t)stream);
+}
+
+FV_API fv_status fv_conv_set_precision(fv_conv* c, int32_t precision) {
+    if (!c || (precision != FV_PRECISION_F32 && precision != FV_PRECISION_F16X3)) {
+        set_error("fv_conv_set_precision: invalid argument");
+        return FV_ERR_INVALID;
+    }
+    c->L.precision = precision;
+    return FV_OK;
 }
 
 FV_API void fv_conv_destroy(fv_conv* c) {

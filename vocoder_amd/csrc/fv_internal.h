@@ -76,6 +76,11 @@ struct ConvParams {
     long long x_bstride, y_bstride;
     int flat;            // pointwise convs (ks == 1): GEMM columns run over the flattened (batch, time) axis
     int n_total;         // flat: batch * N
+    float acc_scale;     // accumulator scale applied before the bias (1 for the fp32 kernels, 1/s_w for f16x3)
+    // f16x3 precision mode (conv_f16x3_impl.h)
+    const void* wph;     // split fp16 weight planes, see pack_conv_weights_f16x3()
+    int nch16;           // 16-channel chunks in the packed planes
+    int nch16_real;      // ceil(Cin / 16)
 };
 
 struct ConvLayer {
@@ -86,6 +91,10 @@ struct ConvLayer {
     int M = 0, ks = 0, pad_l = 0, nchunk = 0, nchunk_real = 0, m_pad = 0;
     float4* d_wp = nullptr;
     float4* d_wp16 = nullptr;  // 16x16x4-fragment layout, only for 16 -> 16 channel Conv1d (fused pair kernel)
+    void* d_wph = nullptr;     // f16x3 mode: (wh, wl, wh * 2^-11) fp16 planes in 32x32x16 fragment order (optional)
+    float w_scale = 1.f;       // s_w: power of two folded into those planes
+    int nch16 = 0;
+    int precision = FV_PRECISION_F32;   // FV_PRECISION_F16X3: conv_layer_run uses the split-fp16 kernel (needs d_wph)
     float* d_bias = nullptr;
     size_t wp_bytes = 0;
 
@@ -102,8 +111,9 @@ struct ConvLayer {
 };
 
 // Builds the device-side layer from an already-folded torch-layout weight (host).  bias may be NULL.
+// with_f16x3: also pack the split fp16 planes when the layer is eligible for the f16x3 kernels.
 fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, int k, int dil, int padding,
-                            int stride, const float* host_w, const float* host_bias);
+                            int stride, const float* host_w, const float* host_bias, bool with_f16x3 = false);
 void conv_layer_destroy(ConvLayer& L);
 
 struct ConvRun {
@@ -126,6 +136,11 @@ bool launch_conv_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_misc(const ConvParams& p, int cfg, int batch, hipStream_t s);   // k=2, 4, 5, 13 ...
 bool launch_conv_generic(const ConvParams& p, int cfg, int batch, hipStream_t s, size_t* lds_bytes);
+// f16x3 precision mode: tiles of the split-fp16 kernel (rows x columns per workgroup)
+enum SplitCfg : int { SPLIT_128x256 = 0, SPLIT_128x128 = 1, SPLIT_64x256 = 2, SPLIT_COUNT };
+bool launch_conv_f16x3_k3(const ConvParams& p, int cfg, int batch, hipStream_t s);
+bool launch_conv_f16x3_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
+bool launch_conv_f16x3_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
 
 #ifndef FV_X_PAIRCOLS
 #define FV_X_PAIRCOLS 4096

@@ -67,7 +67,7 @@ class LogMelSpectrogram(_base.EngineModule):
         self.mel_scale = _MelScaleBuffers(melscale_fbanks_slaney(n_fft // 2 + 1, f_min, self.f_max, n_mels, sample_rate))
 
     def _make_engine(self, state_dict):
-        return Engine(_lib.FV_MODEL_LOGMEL, mel=logmel_config(**self._cfg), state_dict=state_dict)
+        return Engine(_lib.FV_MODEL_LOGMEL, mel=logmel_config(**self._cfg), state_dict=state_dict, precision=self.precision)
 
     def compress(self, x: torch.Tensor) -> torch.Tensor:
         return torch.log(torch.clamp(x, min=1e-5))

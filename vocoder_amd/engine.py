@@ -88,7 +88,12 @@ class Engine:
     """Owns one ``fv_engine`` on the current device.  ``state_dict`` uses the reference's key names."""
 
     def __init__(self, model_kind: int, *, ups=None, backbone=None, head=None, mel=None,
-                 state_dict: Mapping[str, "np.ndarray | torch.Tensor"], device=None):
+                 state_dict: Mapping[str, "np.ndarray | torch.Tensor"], device=None, precision: str = "f32"):
+        """``precision``: "f32" (exact-fp32 MFMA, the reference's arithmetic; default) or "f16x3" (opt-in split-fp16
+        MFMA for the MFMA-bound convs, fp32-class accuracy, see include/fishvoc.h ``fv_precision``)."""
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
+        self.precision = precision
         self._h = ctypes.c_void_p()
         self._lib = _lib.lib()
         if not torch.cuda.is_available():
@@ -109,6 +114,7 @@ class Engine:
         with torch.cuda.device(self.device):
             check(self._lib.fv_create(ctypes.byref(cfg), ctypes.byref(self._h)))
             try:
+                check(self._lib.fv_set_precision(self._h, _lib.PRECISIONS[precision]))
                 for name, t in state_dict.items():
                     a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
                     a = np.ascontiguousarray(a, dtype=np.float32)
@@ -226,6 +232,11 @@ class FusedConv:
 
     def output_length(self, t_in: int) -> int:
         return int(self._lib.fv_conv_output_length(self._h, int(t_in)))
+
+    def set_precision(self, precision: str) -> "FusedConv":
+        """"f32" (default) or "f16x3" (split-fp16 MFMA where the layer shape has such a kernel)."""
+        check(self._lib.fv_conv_set_precision(self._h, _lib.PRECISIONS[precision]))
+        return self
 
     def __call__(self, x: torch.Tensor, residual: torch.Tensor | None = None, out: torch.Tensor | None = None):
         _require_cuda(x, "FusedConv")

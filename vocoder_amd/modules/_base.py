@@ -16,11 +16,26 @@ class EngineModule(nn.Module):
     def __init__(self):
         super().__init__()
         object.__setattr__(self, "_engine", None)
+        object.__setattr__(self, "_precision", "f32")
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_engine())
 
     # -- subclasses implement -------------------------------------------------------------
     def _make_engine(self, state_dict):  # pragma: no cover - abstract
         raise NotImplementedError
+
+    # -- arithmetic of the MFMA-bound convs: "f32" (exact fp32, the reference's; default) or "f16x3" (opt-in) ----------
+    @property
+    def precision(self) -> str:
+        return self.__dict__.get("_precision", "f32")
+
+    @precision.setter
+    def precision(self, value: str) -> None:
+        from .. import _lib
+        if value not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {value!r}")
+        if value != self.precision:
+            self.invalidate_engine()
+        object.__setattr__(self, "_precision", value)
 
     # -- engine cache ----------------------------------------------------------------------
     def invalidate_engine(self) -> None:

@@ -61,7 +61,7 @@ class ConvNeXtEncoder(_base.EngineModule):
                 nn.init.constant_(m.bias, 0)
 
     def _make_engine(self, state_dict):
-        return Engine(_lib.FV_MODEL_CONVNEXT, backbone=convnext_config(**self._cfg), state_dict=state_dict)
+        return Engine(_lib.FV_MODEL_CONVNEXT, backbone=convnext_config(**self._cfg), state_dict=state_dict, precision=self.precision)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._run(x)

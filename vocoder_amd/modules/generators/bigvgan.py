@@ -131,7 +131,7 @@ class BigVGANGenerator(_base.EngineModule):
         _normal_init(self.conv_post)
 
     def _make_engine(self, state_dict):
-        return Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**self._cfg), state_dict=state_dict)
+        return Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**self._cfg), state_dict=state_dict, precision=self.precision)
 
     def forward(self, x, template=None):
         if self.use_template and template is None:

@@ -32,7 +32,7 @@ class ISTFTHead(_base.EngineModule):
         self.out = nn.Conv1d(dim, n_fft * 2, 1)
 
     def _make_engine(self, state_dict):
-        return Engine(_lib.FV_MODEL_ISTFT_HEAD, head=istft_head_config(**self._cfg), state_dict=state_dict)
+        return Engine(_lib.FV_MODEL_ISTFT_HEAD, head=istft_head_config(**self._cfg), state_dict=state_dict, precision=self.precision)
 
     def forward(self, x: torch.Tensor, template=None) -> torch.Tensor:
         return self._run(x)[:, 0, :]
