@@ -103,3 +103,24 @@ def test_f16x3_hifigan_model_matches_oracle():
     assert np.abs(y - ref).max() <= 1e-4, np.abs(y - ref).max()
     prof = gen.engine(_dev()).profile(torch.from_numpy(mel).to(_dev()))
     assert any(r["kernel"].startswith("conv_f16x3") for r in prof), [r["kernel"] for r in prof][:5]
+
+
+def test_f16x3_full_size_engine_is_deterministic_and_close_to_f32():
+    """BASELINE-size clips (T_mel = 86, 8 clips): the f16x3 engine must give bit-identical waveforms run after run (a
+    compiler-scheduled VALU -> SDWA hazard once made the activation split timing-dependent) and stay within 1e-4 of the
+    exact-fp32 engine — also through the no-activation (c2) and accumulate paths that only the engine exercises."""
+    from vocoder_amd import _lib, synthetic
+    from vocoder_amd.engine import Engine, upsampler_config
+    cfg = dict(synthetic.HIFIGAN_V1_44K)
+    sd = synthetic.hifigan_state_dict(cfg, seed=0)
+    mel = torch.from_numpy(synthetic.synthetic_mel(8, cfg["num_mels"], 86, seed=5)).to(_dev())
+    e32 = Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**cfg), state_dict=sd)
+    ref = e32(mel).clone()
+    e16 = Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**cfg), state_dict=sd, precision="f16x3")
+    y0 = e16(mel).clone()
+    torch.cuda.synchronize()
+    assert float((y0 - ref).abs().max()) <= 1e-4
+    for _ in range(12):
+        y = e16(mel)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y0)

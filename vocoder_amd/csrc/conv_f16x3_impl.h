@@ -23,6 +23,10 @@
 //   * Wave tile 32 x (NT*32): waves are stacked along M so no two waves of a workgroup fetch the same weights.
 #pragma once
 
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
 #include "conv_mfma_impl.h"
 
 namespace fv {
@@ -30,13 +34,65 @@ namespace fv {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
+// Epilogue of the split kernel: same arithmetic as conv_epilogue (non-transposed, non-flat layers only), but the residual /
+// accumulate operands of the WHOLE register tile are requested before anything is stored — one HBM round trip per tile
+// instead of one per 4-row group (res may alias y, so the compiler cannot hoist those loads across the stores itself).
+// The split kernel's MFMA phase is ~5x shorter than the fp32 kernel's, which makes that latency visible.
+template <int NTE>
+__device__ __forceinline__ void conv_epilogue_bulk(const ConvParams& p, f32x16 (&acc)[NTE], int b, int mt, int ncol0, int lane) {
+    const unsigned span = (unsigned)(p.y_bstride * 4);
+    const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
+    const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
+    const bool has_res = p.res != nullptr;
+    const bool accum = p.out_mode == OUT_ACCUM;
+    auto offset = [&](int r, int jn) -> unsigned {   // byte offset of accumulator register r of n-tile jn, or the OOB marker
+        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int n = ncol0 + jn * 32;
+        return (m < p.M && n < p.N) ? (unsigned)(m * p.N + n) * 4u : 0xFFFFFFFFu;
+    };
+    float rv[NTE][16];
+    if (has_res) {
+#pragma unroll
+        for (int jn = 0; jn < NTE; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[jn][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, offset(r, jn), 0, 0));
+    }
+    float bias[16];   // layer-scale (gamma) never occurs on the layers this kernel serves; the host checks
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        bias[r] = p.bias[m < p.M ? m : 0];
+    }
+#pragma unroll
+    for (int jn = 0; jn < NTE; ++jn) {
+        float val[16], yo[16];
+        if (accum) {   // MRF accumulate (2 of 18 launches per stage): one extra round trip per n-tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yo[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, offset(r, jn), 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            val[r] = fmaf(acc[jn][r], p.acc_scale, bias[r]);
+            if (has_res) val[r] += rv[jn][r];
+        }
+        act_apply_all(val, p.post_act, p.slope);
+        if (accum) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) val[r] = (yo[r] + val[r]) * p.out_scale;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[r]), yrs, offset(r, jn), 0, 0);
+    }
+}
+
 constexpr int kChunk16 = 16;
-constexpr int kF16Prefetch = 2;   // weight prefetch distance in k-blocks (one block = 16 channels x 1 tap = 3*NT MFMAs)
+constexpr int kF16WeightPrefetch = 2;   // weight prefetch distance in k-blocks (one block = 16 channels x 1 tap = 3*NT MFMAs)
+constexpr int kF16FragPrefetch = 1;     // activation-fragment prefetch distance in groups of two n-tiles (6 MFMAs)
 
 template <int KS, int DIL, int WM, int WN, int NT>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(NT % 2 == 0, "B fragments are loaded two n-tiles at a time");
+    static_assert(NT % 4 == 0, "B fragments are loaded two n-tiles at a time, the epilogue handles four");
     constexpr int N_BLK = WN * NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
     constexpr int W = N_BLK + SPAN;
@@ -83,16 +139,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
         st_off[i] = ok ? (unsigned)(8 * h * p.Tin + t) * 4u : 0xC0000000u;
     }
     float stage[NE][8];
-    auto load_chunk = [&](int c) {
+    __amdgpu_buffer_rsrc_t xrs;
+    auto chunk_rsrc = [&](int c) {
         const int cbase = c * kChunk16;
         const long long rows = (long long)(p.Cin - cbase) * p.Tin;   // rows of zero-padded channels read as 0
-        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)(rows * 4));
-#pragma unroll
-        for (int i = 0; i < NE; ++i)
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                stage[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_off[i] + (unsigned)r * row_b, 0, 0));
+        xrs = uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)(rows * 4));
     };
+    auto load_item = [&](int i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            stage[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_off[i] + (unsigned)r * row_b, 0, 0));
+    };
+    const bool silu = p.pre_act == FV_ACT_SILU;   // the host only dispatches this kernel with pre_act in {NONE, SILU}
+    // activate, split, pack.  Kept element-wise on purpose: a two-at-a-time formulation (v_cvt_pk_f16_f32 on float pairs,
+    // halves re-read with v_cvt_f32_f16_sdwa) compiled by hipcc 7.2 produced timing-dependent wrong splits on gfx950 —
+    // a VALU-write -> SDWA-read hazard one wait state short — and was no faster.
     auto store_chunk = [&](h8* dst) {
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
@@ -101,11 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 float v = stage[i][r];
-                if (p.pre_act == FV_ACT_SILU) {
-                    v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-                } else if (p.pre_act != FV_ACT_NONE) {
-                    v = act_apply(v, p.pre_act, p.slope);
-                }
+                if (silu) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
                 const _Float16 vh = (_Float16)v;
                 hi[r] = vh;
                 lo[r] = (_Float16)((v - (float)vh) * 2048.0f);
@@ -125,64 +182,90 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
     auto load_a = [&](h8 (&dst)[3], int goff_b) {   // goff_b = g * 3072, wave-uniform
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wbase + goff_b + q * 1024, 0);
+            // voffset carries the constant plane offset so that it folds into the instruction's immediate field: one
+            // SALU add per k-block instead of three
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + q * 1024, wbase + goff_b, 0);
             dst[q] = __builtin_bit_cast(h8, v);
         }
     };
     // ---- activation fragments: two n-tiles x (xh, xl) per group ----
     const int b_lane = (lane >> 5) * W + wn * (NT * 32) + (lane & 31);
+    // request order = reverse of the order of first use (xh of n-tile 0 is consumed first): LDS returns in order, so the wait
+    // before the first MFMA of a group covers the whole group and the other three waits disappear
     auto load_bgrp = [&](h8 (&dst)[2][2], const h8* xsb, int j, int grp) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int q = 1; q >= 0; --q)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) dst[u][q] = xsb[q * PLANE + b_lane + (grp * 2 + u) * 32 + j * DIL];
+            for (int u = 1; u >= 0; --u) dst[u][q] = xsb[q * PLANE + b_lane + (grp * 2 + u) * 32 + j * DIL];
     };
 
-    constexpr int DA = kF16Prefetch;
+    constexpr int DA = kF16WeightPrefetch;
+    constexpr int PB = kF16FragPrefetch;
     constexpr int NG = NT / 2;
-    h8 aq[DA + 1][3];
-    h8 bq[2][2][2];
+    constexpr int G = KS * NG;            // fragment groups per chunk
+    constexpr int RA = DA + 1;            // weight-fragment ring: k-block j of a chunk lives in slot j % RA
+    h8 aq[RA][3];
+    h8 bq[PB + 1][2][2];
     const int nch = p.nch16_real;
-    load_chunk(0);
+    chunk_rsrc(0);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) load_item(i);
 #pragma unroll
     for (int d = 0; d < DA; ++d) load_a(aq[d], d * 3072);
     for (int c = 0; c < nch; ++c) {
         h8* xsb = xs[c & 1];
         store_chunk(xsb);
         __syncthreads();
-        if (c + 1 < nch) load_chunk(c + 1);
+        const bool more = c + 1 < nch;
+        if (more) chunk_rsrc(c + 1);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) load_item(i);
+        }
         const int gchunk_b = __builtin_amdgcn_readfirstlane((c * KS + DA) * 3072);
-        load_bgrp(bq[0], xsb, 0, 0);
+#pragma unroll
+        for (int s0 = 0; s0 < PB; ++s0) load_bgrp(bq[s0], xsb, s0 / NG, s0 % NG);
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
-            load_a(aq[DA], gchunk_b + j * 3072);
+            load_a(aq[(j + DA) % RA], gchunk_b + j * 3072);
 #pragma unroll
             for (int grp = 0; grp < NG; ++grp) {
-                const int cur_idx = (j * NG + grp) & 1;   // compile-time after unrolling
-                if (grp + 1 < NG) load_bgrp(bq[cur_idx ^ 1], xsb, j, grp + 1);
-                else if (j + 1 < KS) load_bgrp(bq[cur_idx ^ 1], xsb, j + 1, 0);
+                constexpr int RING = PB + 1;
+                const int sidx = j * NG + grp;            // compile-time after unrolling
+                const int cur = sidx % RING;
+                if (sidx + PB < G) load_bgrp(bq[(sidx + PB) % RING], xsb, (sidx + PB) / NG, (sidx + PB) % NG);
                 __builtin_amdgcn_sched_barrier(0);
+                // product-major order: consecutive MFMAs never share an accumulator
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int jn = grp * 2 + u;
-                    acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[0][0], bq[cur_idx][u][0], acc[0][jn], 0, 0, 0);
-                    acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[0][1], bq[cur_idx][u][0], acc[0][jn], 0, 0, 0);
-                    acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[0][2], bq[cur_idx][u][1], acc[0][jn], 0, 0, 0);
-                }
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int jn = grp * 2 + u;
+                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[j % RA][q], bq[cur][u][q == 2 ? 1 : 0], acc[0][jn], 0, 0, 0);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        // the DA fragments in flight for the next chunk sit in slots (KS + d) % RA: move them to slots d (once per chunk;
+        // a per-tap rotation cost 2 v_mov per MFMA)
+        if (KS % RA != 0) {
+            h8 t[DA][3];
 #pragma unroll
             for (int d = 0; d < DA; ++d)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) aq[d][q] = aq[d + 1][q];
+                for (int q = 0; q < 3; ++q) t[d][q] = aq[(KS + d) % RA][q];
+#pragma unroll
+            for (int d = 0; d < DA; ++d)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) aq[d][q] = t[d][q];
         }
     }
 
-    // epilogue in two column halves (bounds the live registers): acc * 1/s_w + bias ...
+    // epilogue in groups of four n-tiles (64 accumulator registers; bounds the live registers)
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        f32x16(&sub)[1][NT / 2] = reinterpret_cast<f32x16(&)[1][NT / 2]>(acc[0][hf * (NT / 2)]);
-        conv_epilogue<1, NT / 2>(p, sub, b, mt0, n0 + wn * (NT * 32) + hf * (NT / 2) * 32 + (lane & 31), lane);
+    for (int hf = 0; hf < NT / 4; ++hf) {
+        f32x16(&sub)[4] = reinterpret_cast<f32x16(&)[4]>(acc[0][hf * 4]);
+        conv_epilogue_bulk<4>(p, sub, b, mt0, n0 + wn * (NT * 32) + hf * 128 + (lane & 31), lane);
     }
 }
 
@@ -190,7 +273,6 @@ template <int KS, int DIL>
 inline bool launch_f16x3_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
     const int grid = batch * p.m_blks * p.n_tiles;
     switch (cfg) {
-        case SPLIT_128x256: hipLaunchKernelGGL((conv_f16x3_kernel<KS, DIL, 4, 1, 8>), dim3(grid), dim3(256), 0, s, p); return true;
         case SPLIT_128x128: hipLaunchKernelGGL((conv_f16x3_kernel<KS, DIL, 4, 1, 4>), dim3(grid), dim3(256), 0, s, p); return true;
         case SPLIT_64x256: hipLaunchKernelGGL((conv_f16x3_kernel<KS, DIL, 2, 2, 4>), dim3(grid), dim3(256), 0, s, p); return true;
         default: return false;

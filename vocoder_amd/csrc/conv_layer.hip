@@ -1,6 +1,7 @@
 // Host side of the fused conv layer: weight re-layout into MFMA fragment order, tile selection, dispatch.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "fv_internal.h"
@@ -196,7 +197,7 @@ static int choose_tile(int M, long long N, int batch) {
 
 static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64"};
 
-static const char* const kSplitNames[SPLIT_COUNT] = {"128x256", "128x128", "64x256"};
+static const char* const kSplitNames[SPLIT_COUNT] = {"128x128", "64x256"};
 
 // f16x3 precision mode: tile choice + dispatch of the split-fp16 kernel (p already describes the layer call)
 static fv_status conv_layer_run_f16x3(const ConvLayer& L, const ConvRun& r, ConvParams& p, hipStream_t stream) {
@@ -204,16 +205,9 @@ static fv_status conv_layer_run_f16x3(const ConvLayer& L, const ConvRun& r, Conv
     p.nch16 = L.nch16;
     p.nch16_real = L.nch16;
     p.acc_scale = 1.0f / L.w_scale;
-    int cfg;
-    if (L.M <= 64) {
-        cfg = SPLIT_64x256;
-    } else {
-        // 256-column tiles unless they leave the chip under-filled or pad a lot more columns than 128-column ones
-        const long long t256 = (p.N + 255) / 256, t128 = (p.N + 127) / 128;
-        const long long blocks256 = t256 * ((L.M + 127) / 128) * r.batch;
-        cfg = (blocks256 < 512 || t128 * 128 * 1.04 < t256 * 256.0) ? SPLIT_128x128 : SPLIT_128x256;
-    }
-    const int mb = cfg == SPLIT_64x256 ? 64 : 128, nb = cfg == SPLIT_128x128 ? 128 : 256;
+    // wave tile 32 x 128 either way (64 accumulator registers); waves stacked along M when there are >= 128 rows
+    const int cfg = L.M <= 64 ? SPLIT_64x256 : SPLIT_128x128;
+    const int mb = cfg == SPLIT_64x256 ? 64 : 128, nb = cfg == SPLIT_64x256 ? 256 : 128;
     p.m_blks = (L.M + mb - 1) / mb;
     p.n_tiles = (p.N + nb - 1) / nb;
     const int prof_idx = prof_begin(stream);
@@ -295,7 +289,9 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     p.y_bstride = (long long)L.c_out * tout;
     p.acc_scale = 1.0f;
 
-    if (L.precision == FV_PRECISION_F16X3 && L.d_wph) return conv_layer_run_f16x3(L, r, p, stream);
+    // the split kernels implement the pre-activations of the MFMA-bound layers only (none / SiLU)
+    if (L.precision == FV_PRECISION_F16X3 && L.d_wph && !r.gamma && (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU))
+        return conv_layer_run_f16x3(L, r, p, stream);
 
     int cfg = choose_tile(L.M, p.N, r.batch);
     // pointwise convs have no halo, so batch and time flatten into one GEMM column axis: no per-item partial tiles

@@ -33,6 +33,18 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 void set_last_kernel(const char* name) { g_kernel = name; }
+int num_cus() {
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached = n;
+        cached_dev = dev;
+    }
+    return cached;
+}
 
 static thread_local Profiler* g_prof = nullptr;
 Profiler* current_profiler() { return g_prof; }
