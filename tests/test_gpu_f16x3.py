@@ -124,3 +124,44 @@ def test_f16x3_full_size_engine_is_deterministic_and_close_to_f32():
         y = e16(mel)
         torch.cuda.synchronize()
         assert torch.equal(y, y0)
+
+
+POINTWISE = [(128, 512, 2, 94), (512, 128, 3, 94), (512, 2048, 1, 50), (2048, 512, 2, 33), (256, 512, 4, 94), (64, 128, 2, 700)]
+
+
+@pytest.mark.parametrize("cin,cout,B,T", POINTWISE)
+def test_f16x3_pointwise_conv_matches_oracle(cin, cout, B, T):
+    """ConvNeXt pointwise GEMMs (k = 1): flattened (batch, time) columns, GELU epilogue, residual."""
+    from vocoder_amd import _lib
+    rng = np.random.default_rng(cin + cout + B)
+    x = (rng.normal(size=(B, cin, T)) * 2.0).astype(np.float32)
+    w = (rng.normal(size=(cout, cin, 1)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    ref = orc.gelu(orc.conv1d(x, w, b))
+    y, kern = _conv(w, b, x, None, "f16x3", post_act=_lib.FV_ACT_GELU)
+    assert kern.startswith("conv_f16x3<k=1"), kern
+    scale = max(np.abs(ref).max(), 1.0)
+    err = np.abs(y - ref).max()
+    assert err <= 1e-4 and err <= 2e-5 * scale, f"max|d|={err:.3e} ({kern})"
+    res = rng.normal(size=ref.shape).astype(np.float32)
+    ref2 = orc.conv1d(x, w, b) + res
+    y2, _ = _conv(w, b, x, res, "f16x3")
+    assert np.abs(y2 - ref2).max() <= 2e-5 * max(np.abs(ref2).max(), 1.0)
+
+
+def test_f16x3_vocos_and_convnext_match_oracle():
+    """Whole ConvNeXt / Vocos forwards in f16x3 mode (pointwise GEMMs with layer scale + in-place residual)."""
+    from vocoder_amd import _lib, synthetic as syn
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config
+    cfg = dict(backbone=dict(input_channels=80, depths=[1, 1, 2, 1], dims=[128, 256, 512, 1024], kernel_size=7),
+               head=dict(dim=1024, n_fft=1024, hop_length=256, win_length=1024, padding="same"))
+    sd = syn.vocos_state_dict(cfg, seed=3)
+    mel = syn.synthetic_mel(3, 80, 10, seed=9)
+    ref = orc.vocos_forward(sd, cfg, mel)
+    eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), head=istft_head_config(**cfg["head"]),
+                 state_dict=sd, precision="f16x3")
+    x = torch.from_numpy(mel).to(_dev())
+    y = eng(x).cpu().numpy()
+    assert np.abs(y - ref).max() <= 1e-4, np.abs(y - ref).max()
+    prof = eng.profile(x)
+    assert any(r["kernel"].startswith("conv_f16x3<k=1") for r in prof), [r["kernel"] for r in prof][:8]

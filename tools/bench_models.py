@@ -7,6 +7,8 @@ import torch
 from vocoder_amd import _lib, synthetic as syn
 from vocoder_amd.engine import Engine, convnext_config, istft_head_config, upsampler_config
 
+PREC = sys.argv[1] if len(sys.argv) > 1 else "f32"   # f32 | f16x3
+
 def run(name, eng, mel, sr, steps=10):
     out = torch.empty((mel.shape[0], 1, eng.output_length(mel.shape[2])), device="cuda")
     for _ in range(3):
@@ -21,16 +23,16 @@ def run(name, eng, mel, sr, steps=10):
     tab = eng.profile(mel, repeats=2)
     tot = sum(r["total_ms"] for r in tab) / 2
     top = sorted(tab, key=lambda r: -r["total_ms"])[:6]
-    print(json.dumps({"model": name, "batch": mel.shape[0], "ms_per_step": dt * 1e3, "samples_per_s": n / dt,
+    print(json.dumps({"model": name, "precision": PREC, "batch": mel.shape[0], "ms_per_step": dt * 1e3, "samples_per_s": n / dt,
                       "x_realtime": n / dt / sr, "finite": bool(torch.isfinite(out).all()),
                       "serialized_kernel_ms": tot,
                       "top_kernels": [(r["kernel"], round(r["total_ms"] / 2, 3), round(r["flops_per_launch"] / r["avg_ms"] / 1e9, 1)) for r in top]}))
 
 cfg = dict(syn.BIGVGAN_24K)
-eng = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=syn.bigvgan_state_dict(cfg, 0))
+eng = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=syn.bigvgan_state_dict(cfg, 0), precision=PREC)
 run("bigvgan-24k", eng, torch.from_numpy(syn.synthetic_mel(64, 80, 94, 1)).cuda(), 24000)
 del eng
 cfg = dict(syn.VOCOS_24K)
 eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), head=istft_head_config(**cfg["head"]),
-             state_dict=syn.vocos_state_dict(cfg, 0))
+             state_dict=syn.vocos_state_dict(cfg, 0), precision=PREC)
 run("vocos-24k", eng, torch.from_numpy(syn.synthetic_mel(128, 80, 94, 2)).cuda(), 24000)

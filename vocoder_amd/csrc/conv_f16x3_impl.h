@@ -34,21 +34,32 @@ namespace fv {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
-// Epilogue of the split kernel: same arithmetic as conv_epilogue (non-transposed, non-flat layers only), but the residual /
-// accumulate operands of the WHOLE register tile are requested before anything is stored — one HBM round trip per tile
-// instead of one per 4-row group (res may alias y, so the compiler cannot hoist those loads across the stores itself).
-// The split kernel's MFMA phase is ~5x shorter than the fp32 kernel's, which makes that latency visible.
+// Epilogue of the split kernel: same arithmetic as conv_epilogue (non-transposed layers), but the residual operand of the
+// WHOLE register tile is requested before anything is stored — one HBM round trip per tile instead of one per 4-row group
+// (res may alias y, so the compiler cannot hoist those loads across the stores itself).  The split kernel's MFMA phase is
+// ~5x shorter than the fp32 kernel's, which makes that latency visible.
 template <int NTE>
 __device__ __forceinline__ void conv_epilogue_bulk(const ConvParams& p, f32x16 (&acc)[NTE], int b, int mt, int ncol0, int lane) {
-    const unsigned span = (unsigned)(p.y_bstride * 4);
+    // flat mode (pointwise convs): the column axis runs over (batch item, t) and the descriptor spans every item
+    const unsigned span = (unsigned)((p.flat ? (long long)p.y_bstride * (p.n_total / p.N) : p.y_bstride) * 4);
     const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
     const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
     const bool has_res = p.res != nullptr;
     const bool accum = p.out_mode == OUT_ACCUM;
+    int coff[NTE];   // element offset of the column (row part excluded), -1 when the column does not exist
+#pragma unroll
+    for (int jn = 0; jn < NTE; ++jn) {
+        const int n = ncol0 + jn * 32;
+        if (p.flat) {
+            const int bb = n / p.N;
+            coff[jn] = n < p.n_total ? bb * (int)p.y_bstride + (n - bb * p.N) : -1;
+        } else {
+            coff[jn] = n < p.N ? n : -1;
+        }
+    }
     auto offset = [&](int r, int jn) -> unsigned {   // byte offset of accumulator register r of n-tile jn, or the OOB marker
         const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int n = ncol0 + jn * 32;
-        return (m < p.M && n < p.N) ? (unsigned)(m * p.N + n) * 4u : 0xFFFFFFFFu;
+        return (m < p.M && coff[jn] >= 0) ? (unsigned)(m * p.N + coff[jn]) * 4u : 0xFFFFFFFFu;
     };
     float rv[NTE][16];
     if (has_res) {
@@ -57,11 +68,18 @@ __device__ __forceinline__ void conv_epilogue_bulk(const ConvParams& p, f32x16 (
 #pragma unroll
             for (int r = 0; r < 16; ++r) rv[jn][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, offset(r, jn), 0, 0));
     }
-    float bias[16];   // layer-scale (gamma) never occurs on the layers this kernel serves; the host checks
+    float bias[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        bias[r] = p.bias[m < p.M ? m : 0];
+        const int mc = m < p.M ? m : 0;
+        // layer scale (ConvNeXt gamma, applied to conv + bias before the residual) folds into scale and bias
+        const float g = p.gamma ? p.gamma[mc] : 1.0f;
+        bias[r] = p.bias[mc] * g;
+        if (p.gamma) {
+#pragma unroll
+            for (int jn = 0; jn < NTE; ++jn) acc[jn][r] *= g;
+        }
     }
 #pragma unroll
     for (int jn = 0; jn < NTE; ++jn) {
@@ -87,7 +105,8 @@ __device__ __forceinline__ void conv_epilogue_bulk(const ConvParams& p, f32x16 (
 
 constexpr int kChunk16 = 16;
 constexpr int kF16WeightPrefetch = 2;   // weight prefetch distance in k-blocks (one block = 16 channels x 1 tap = 3*NT MFMAs)
-constexpr int kF16FragPrefetch = 1;     // activation-fragment prefetch distance in groups of two n-tiles (6 MFMAs)
+// 16-channel sub-chunks staged per barrier: pointwise convs have one k-block per sub-chunk, so they stage four
+constexpr int f16_subs_for(int ks) { return ks == 1 ? 4 : 1; }
 
 template <int KS, int DIL, int WM, int WN, int NT>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) {
@@ -96,11 +115,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
     constexpr int N_BLK = WN * NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
     constexpr int W = N_BLK + SPAN;
-    constexpr int ITEMS = 2 * W;                       // (k-half, column) staging items of 8 channels each
+    constexpr int SUBS = f16_subs_for(KS);
+    constexpr int ITEMS = SUBS * 2 * W;                // (sub-chunk, k-half, column) staging items of 8 channels each
     constexpr int NE = (ITEMS + 255) / 256;
-    constexpr int PLANE = 2 * W;                       // 16-byte slots per plane
-    __shared__ h8 xs[2][2 * PLANE];                    // [buffer][plane][k-half][column]
+    constexpr int PLANE = 2 * W;                       // 16-byte slots per plane of one sub-chunk
+    constexpr int SUB_SLOTS = 2 * PLANE;               // (xh, xl) planes
+    __shared__ h8 xs[2][SUBS * SUB_SLOTS];             // [buffer][sub-chunk][plane][k-half][column]
     static_assert(sizeof(h8) == 16, "h8 is one 16-byte LDS slot");
+    static_assert(sizeof(xs) <= 65536, "static LDS limit");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -111,9 +133,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
     const int n_tile = bid % p.n_tiles;
     bid /= p.n_tiles;
     const int m_blk = bid % p.m_blks;
-    const int b = bid / p.m_blks;
+    const int b = bid / p.m_blks;                      // 0 in flat mode
     const int n0 = n_tile * N_BLK;
     const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
+    const bool flat = KS == 1 && p.flat;
 
     f32x16 acc[1][NT];
 #pragma unroll
@@ -121,9 +144,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
 
-    // ---- staging plan: item e = tid + i*256 -> (k-half h, column col); eight channel rows 8h .. 8h+7 of the chunk ----
-    // st_off = byte offset of (row 8h, t) inside the chunk, or a marker >= 0xC0000000 when t is outside [0, Tin): adding
-    // the row offsets (< 2^30) cannot wrap it, and the raw buffer load returns 0 beyond the descriptor's span.
+    // ---- staging plan: item e = tid + i*256 -> (sub-chunk, k-half h, column col); eight channel rows of the chunk ----
+    // st_off = byte offset of (row 16*sub + 8h, t) relative to the chunk's first row, or a marker >= 0xC0000000 when the
+    // column does not exist: adding the row offsets (< 2^30) cannot wrap it, and the raw buffer load returns 0 beyond the
+    // descriptor's span (which also zero-fills the channels past C_in of the last chunk).
     unsigned st_off[NE];
     const int tbase = n0 - p.pad_l;
     const unsigned row_b = (unsigned)p.Tin * 4u;
@@ -132,18 +156,29 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
         int e = tid + i * 256;
         const bool in_tile = e < ITEMS;
         e = in_tile ? e : ITEMS - 1;
-        const int h = e / W;
-        const int col = e - h * W;
-        const int t = tbase + col;
-        const bool ok = in_tile && t >= 0 && t < p.Tin;
-        st_off[i] = ok ? (unsigned)(8 * h * p.Tin + t) * 4u : 0xC0000000u;
+        const int sh = e / W;                          // sub * 2 + h
+        const int col = e - sh * W;
+        int t = tbase + col;
+        int boff = 0;
+        bool ok = in_tile;
+        if (flat) {
+            ok = ok && t < p.n_total;
+            const int bb = t / p.N;
+            t -= bb * p.N;
+            boff = bb * (int)p.x_bstride;
+        }
+        ok = ok && t >= 0 && t < p.Tin;
+        st_off[i] = ok ? (unsigned)(boff + 8 * sh * p.Tin + t) * 4u : 0xC0000000u;
     }
     float stage[NE][8];
     __amdgpu_buffer_rsrc_t xrs;
+    const long long x_items = flat ? (long long)(p.n_total / p.N) : 1;   // batch items spanned by the descriptor
     auto chunk_rsrc = [&](int c) {
-        const int cbase = c * kChunk16;
-        const long long rows = (long long)(p.Cin - cbase) * p.Tin;   // rows of zero-padded channels read as 0
-        xrs = uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)(rows * 4));
+        const int cbase = c * kChunk16 * SUBS;
+        // flat mode: the span covers every batch item (the host guarantees C_in is a multiple of the chunk, so no row of
+        // another item can be mistaken for a padded channel); otherwise it ends with this item's last channel
+        const long long elems = flat ? x_items * p.x_bstride - (long long)cbase * p.Tin : (long long)(p.Cin - cbase) * p.Tin;
+        xrs = uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)(elems * 4));
     };
     auto load_item = [&](int i) {
 #pragma unroll
@@ -168,13 +203,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
                 lo[r] = (_Float16)((v - (float)vh) * 2048.0f);
             }
             if (e < ITEMS) {
-                dst[e] = hi;
-                dst[PLANE + e] = lo;
+                // item e = (sub * 2 + h) * W + col  ->  slot sub * SUB_SLOTS + plane * PLANE + h * W + col
+                const int sub = e / PLANE;
+                const int slot = e + sub * PLANE;
+                dst[slot] = hi;
+                dst[slot + PLANE] = lo;
             }
         }
     };
 
-    // ---- weights: k-block g = chunk * KS + tap of m-tile mt starts at byte ((mt * nch16 * KS) + g) * 3072 ----
+    // ---- weights: k-block g = chunk16 * KS + tap of m-tile mt starts at byte ((mt * nch16 * KS) + g) * 3072 ----
     const int mt0 = m_blk * WM + wm;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wph, 0, 0x7fffffff, 0x00020000);
     const int wvoff = lane * 16;
@@ -189,24 +227,26 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
         }
     };
     // ---- activation fragments: two n-tiles x (xh, xl) per group ----
-    const int b_lane = (lane >> 5) * W + wn * (NT * 32) + (lane & 31);
     // request order = reverse of the order of first use (xh of n-tile 0 is consumed first): LDS returns in order, so the wait
     // before the first MFMA of a group covers the whole group and the other three waits disappear
-    auto load_bgrp = [&](h8 (&dst)[2][2], const h8* xsb, int j, int grp) {
+    const int b_lane = (lane >> 5) * W + wn * (NT * 32) + (lane & 31);
+    auto load_bgrp = [&](h8 (&dst)[2][2], const h8* xsb, int kb, int grp) {   // kb = k-block inside the chunk
+        const int sub = kb / KS, j = kb - sub * KS;
 #pragma unroll
         for (int q = 1; q >= 0; --q)
 #pragma unroll
-            for (int u = 1; u >= 0; --u) dst[u][q] = xsb[q * PLANE + b_lane + (grp * 2 + u) * 32 + j * DIL];
+            for (int u = 1; u >= 0; --u)
+                dst[u][q] = xsb[sub * SUB_SLOTS + q * PLANE + b_lane + (grp * 2 + u) * 32 + j * DIL];
     };
 
     constexpr int DA = kF16WeightPrefetch;
-    constexpr int PB = kF16FragPrefetch;
+    constexpr int KB = SUBS * KS;         // k-blocks per LDS chunk
     constexpr int NG = NT / 2;
-    constexpr int G = KS * NG;            // fragment groups per chunk
-    constexpr int RA = DA + 1;            // weight-fragment ring: k-block j of a chunk lives in slot j % RA
+    constexpr int G = KB * NG;            // fragment groups per chunk
+    constexpr int RA = DA + 1;            // weight-fragment ring: k-block kb of a chunk lives in slot kb % RA
     h8 aq[RA][3];
-    h8 bq[PB + 1][2][2];
-    const int nch = p.nch16_real;
+    h8 bq[2][2][2];
+    const int nch = (p.nch16_real + SUBS - 1) / SUBS;   // LDS chunks; the packed planes are padded to whole chunks
     chunk_rsrc(0);
 #pragma unroll
     for (int i = 0; i < NE; ++i) load_item(i);
@@ -217,23 +257,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
         store_chunk(xsb);
         __syncthreads();
         const bool more = c + 1 < nch;
-        if (more) chunk_rsrc(c + 1);
         if (more) {
+            chunk_rsrc(c + 1);
 #pragma unroll
             for (int i = 0; i < NE; ++i) load_item(i);
         }
-        const int gchunk_b = __builtin_amdgcn_readfirstlane((c * KS + DA) * 3072);
+        const int gchunk_b = __builtin_amdgcn_readfirstlane((c * KB + DA) * 3072);
+        load_bgrp(bq[0], xsb, 0, 0);
 #pragma unroll
-        for (int s0 = 0; s0 < PB; ++s0) load_bgrp(bq[s0], xsb, s0 / NG, s0 % NG);
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            load_a(aq[(j + DA) % RA], gchunk_b + j * 3072);
+        for (int kb = 0; kb < KB; ++kb) {
+            load_a(aq[(kb + DA) % RA], gchunk_b + kb * 3072);
 #pragma unroll
             for (int grp = 0; grp < NG; ++grp) {
-                constexpr int RING = PB + 1;
-                const int sidx = j * NG + grp;            // compile-time after unrolling
-                const int cur = sidx % RING;
-                if (sidx + PB < G) load_bgrp(bq[(sidx + PB) % RING], xsb, (sidx + PB) / NG, (sidx + PB) % NG);
+                const int sidx = kb * NG + grp;            // compile-time after unrolling
+                const int cur = sidx & 1;
+                if (sidx + 1 < G) load_bgrp(bq[cur ^ 1], xsb, (sidx + 1) / NG, (sidx + 1) % NG);
                 __builtin_amdgcn_sched_barrier(0);
                 // product-major order: consecutive MFMAs never share an accumulator
 #pragma unroll
@@ -241,19 +279,19 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int jn = grp * 2 + u;
-                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[j % RA][q], bq[cur][u][q == 2 ? 1 : 0], acc[0][jn], 0, 0, 0);
+                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[kb % RA][q], bq[cur][u][q == 2 ? 1 : 0], acc[0][jn], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // the DA fragments in flight for the next chunk sit in slots (KS + d) % RA: move them to slots d (once per chunk;
+        // the DA fragments in flight for the next chunk sit in slots (KB + d) % RA: move them to slots d (once per chunk;
         // a per-tap rotation cost 2 v_mov per MFMA)
-        if (KS % RA != 0) {
+        if (KB % RA != 0) {
             h8 t[DA][3];
 #pragma unroll
             for (int d = 0; d < DA; ++d)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) t[d][q] = aq[(KS + d) % RA][q];
+                for (int q = 0; q < 3; ++q) t[d][q] = aq[(KB + d) % RA][q];
 #pragma unroll
             for (int d = 0; d < DA; ++d)
 #pragma unroll
@@ -274,7 +312,12 @@ inline bool launch_f16x3_cfg(const ConvParams& p, int cfg, int batch, hipStream_
     const int grid = batch * p.m_blks * p.n_tiles;
     switch (cfg) {
         case SPLIT_128x128: hipLaunchKernelGGL((conv_f16x3_kernel<KS, DIL, 4, 1, 4>), dim3(grid), dim3(256), 0, s, p); return true;
-        case SPLIT_64x256: hipLaunchKernelGGL((conv_f16x3_kernel<KS, DIL, 2, 2, 4>), dim3(grid), dim3(256), 0, s, p); return true;
+        case SPLIT_64x256:
+            if constexpr (KS != 1) {   // (a 256-column window of four sub-chunks would not fit the static LDS limit)
+                hipLaunchKernelGGL((conv_f16x3_kernel<KS, DIL, 2, 2, 4>), dim3(grid), dim3(256), 0, s, p);
+                return true;
+            }
+            return false;
         default: return false;
     }
 }

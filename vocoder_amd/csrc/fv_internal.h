@@ -139,6 +139,7 @@ bool launch_conv_misc(const ConvParams& p, int cfg, int batch, hipStream_t s);  
 bool launch_conv_generic(const ConvParams& p, int cfg, int batch, hipStream_t s, size_t* lds_bytes);
 // f16x3 precision mode: tiles of the split-fp16 kernel (rows x columns per workgroup)
 enum SplitCfg : int { SPLIT_128x128 = 0, SPLIT_64x256 = 1, SPLIT_COUNT };
+bool launch_conv_f16x3_k1(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_f16x3_k3(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_f16x3_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_f16x3_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
