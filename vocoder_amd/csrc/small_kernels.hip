@@ -1,6 +1,8 @@
 // HBM-bound helper kernels around the MFMA conv: narrow-output conv (conv_post), anti-aliased SnakeBeta,
 // depthwise-conv + LayerNorm, ISTFT spectrum / overlap-add.  All are coalesced along T (the contiguous axis of
 // the reference's (B, C, T) layout) and stage their reuse windows in LDS.
+#include <cstdlib>
+
 #include "conv_mfma_impl.h"
 
 namespace fv {
@@ -324,8 +326,165 @@ __global__ __launch_bounds__(256) void dwconv_ln_reg_kernel(const float* __restr
     }
 }
 
+// LDS-tiled variant (k in {1, 7}, C <= CMAX <= 1024): one workgroup owns 32 time columns of one batch item and streams the
+// channels through LDS in chunks of 64 rows (window + halo requested with coalesced raw buffer loads one chunk ahead,
+// taps and bias staged next to it), each thread keeping its C/8 FIR outputs in registers for the two-pass mean / variance.
+// The register-only kernel above issues its 7 x C/16 window loads in dependent rounds and runs at ~0.4 TB/s on the
+// short rows of the ConvNeXt path (T = 94): this one needs a tenth of the load instructions and has them all in flight.
+constexpr int DWT_TT = 32, DWT_CH = 64, DWT_PITCH = 40;
+template <int K, int CMAX>
+__global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
+                                                             const float* __restrict__ dw_b,
+                                                             const float* __restrict__ ln_w,
+                                                             const float* __restrict__ ln_b, float* __restrict__ y, int C,
+                                                             int T, float eps, int n_tiles) {
+    constexpr int WE = DWT_TT + K - 1;                    // staged columns per channel row
+    constexpr int NEL = DWT_CH * WE;
+    constexpr int NLD = (NEL + 255) / 256;
+    constexpr int NCHUNK = CMAX / DWT_CH;
+    constexpr int PAD = (K - 1) / 2;
+    static_assert(WE <= DWT_PITCH, "halo does not fit the LDS pitch");
+    __shared__ float xs[2][DWT_CH][DWT_PITCH];
+    __shared__ float wsm[2][DWT_CH][8];                   // taps 0..6, bias in slot 7
+    __shared__ float lnp[2][CMAX];
+    __shared__ float red[8][33];
+    const int tid = threadIdx.x;
+    const int col = tid & 31, cg = tid >> 5;
+    const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
+    const int t0 = tile * DWT_TT;
+    const int t = t0 + col;
+    const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(x + (long long)b * C * T, (unsigned)((long long)C * T * 4));
+    const int nchunk = (C + DWT_CH - 1) / DWT_CH;
+
+    for (int c = tid; c < C; c += 256) {
+        lnp[0][c] = ln_w[c];
+        lnp[1][c] = ln_b[c];
+    }
+    // staging plan (same for every chunk): element idx = tid + i*256 -> (row, column) of the chunk window
+    unsigned off[NLD];
+    int lds_at[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        int idx = tid + i * 256;
+        const bool in = idx < NEL;
+        idx = in ? idx : NEL - 1;
+        const int r = idx / WE, cc = idx - r * WE;
+        const int tt = t0 - PAD + cc;
+        off[i] = (in && tt >= 0 && tt < T) ? (unsigned)(r * T + tt) * 4u : 0xC0000000u;   // + chunk row offset below
+        lds_at[i] = in ? r * DWT_PITCH + cc : -1;
+    }
+    float st[NLD], stw[2] = {0.f, 0.f};   // taps + bias of the chunk: 64 rows x 8 slots = 2 per thread
+    auto issue = [&](int ch) {
+        const unsigned base = (unsigned)(ch * DWT_CH * T) * 4u;   // rows past C fall outside the descriptor -> 0
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) st[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off[i] + base, 0, 0));
+        if (K > 1) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + u * 256, r = e >> 3, j = e & 7, c = ch * DWT_CH + r;
+                stw[u] = c < C ? (j < K ? dw_w[(long long)c * K + j] : (j == 7 && dw_b ? dw_b[c] : 0.f)) : 0.f;
+            }
+        }
+    };
+    auto commit = [&](int buf) {
+        float* xsb = &xs[buf][0][0];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (lds_at[i] >= 0) xsb[lds_at[i]] = st[i];
+        if (K > 1) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) wsm[buf][(tid + u * 256) >> 3][tid & 7] = stw[u];
+        }
+    };
+
+    float h[CMAX / 8];
+    float s = 0.f;
+    issue(0);
+    commit(0);
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        if (ch < nchunk) {
+            const int buf = ch & 1;
+            if (ch + 1 < nchunk) issue(ch + 1);
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+                const int cl = cg + 8 * qq;
+                float v;
+                if (K > 1) {
+                    v = wsm[buf][cl][7];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) v = fmaf(wsm[buf][cl][j], xs[buf][cl][col + j], v);
+                } else {
+                    v = xs[buf][cl][col];
+                }
+                h[ch * 8 + qq] = v;
+                s += (ch * DWT_CH + cl < C) ? v : 0.f;
+            }
+            if (ch + 1 < nchunk) commit(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    red[cg][col] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) mean += red[g][col];
+    mean /= (float)C;
+    __syncthreads();
+    float qv = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ++ch)
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+            const int c = ch * DWT_CH + cg + 8 * qq;
+            const float d = h[ch * 8 + qq] - mean;
+            qv = fmaf(d, d, c < C ? qv : qv - d * d);
+        }
+    red[cg][col] = qv;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) var += red[g][col];
+    var /= (float)C;
+    const float inv = 1.0f / sqrtf(var + eps);
+    const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(y + (long long)b * C * T, (unsigned)((long long)C * T * 4));
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ++ch)
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+            const int c = ch * DWT_CH + cg + 8 * qq;
+            const bool ok = c < C && t < T;
+            const int cc = c < C ? c : 0;
+            const float v = (h[ch * 8 + qq] - mean) * inv * lnp[0][cc] + lnp[1][cc];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, ok ? (unsigned)(c * T + t) * 4u : 0xFFFFFFFFu, 0, 0);
+        }
+}
+
+template <int K>
+static bool launch_dwconv_ln_tile(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                                  float* y, int B, int C, int T, float eps, hipStream_t s) {
+    const int n_tiles = (T + DWT_TT - 1) / DWT_TT;
+    const dim3 grid(B * n_tiles), blk(256);
+    if (C <= 256) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 256>), grid, blk, 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
+    else if (C <= 512) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512>), grid, blk, 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
+    else if (C <= 1024) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 1024>), grid, blk, 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
+    else return false;
+    return true;
+}
+
 fv_status launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                            float* y, int B, int C, int T, int k, float eps, hipStream_t s) {
+    // per-item tensors below 1 GiB: 32-bit buffer offsets
+    if ((long long)C * T < (1LL << 28) && getenv("FV_OLD_DWLN") == nullptr) {
+        bool done = false;
+        if (!dw_w) done = launch_dwconv_ln_tile<1>(x, nullptr, nullptr, ln_w, ln_b, y, B, C, T, eps, s);
+        else if (k == 7) done = launch_dwconv_ln_tile<7>(x, dw_w, dw_b, ln_w, ln_b, y, B, C, T, eps, s);
+        if (done) {
+            FV_HIP_CHECK(hipGetLastError());
+            return FV_OK;
+        }
+    }
     if (C <= 16 * DWLN_MAXPER) {
         const int n16 = (T + 15) / 16;
         hipLaunchKernelGGL(dwconv_ln_reg_kernel, dim3(B * n16), dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, k, eps,
