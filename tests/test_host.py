@@ -164,3 +164,19 @@ def test_weight_broadcast_scatter_gather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_precision_option_is_validated_without_a_gpu():
+    """The opt-in arithmetic selector of the drop-in modules / the binding (include/fishvoc.h fv_precision)."""
+    from vocoder_amd import _lib
+    from vocoder_amd.modules.generators.hifigan import HiFiGANGenerator
+    from vocoder_amd import synthetic
+    assert _lib.PRECISIONS == {"f32": 0, "f16x3": 1}
+    gen = HiFiGANGenerator(**synthetic.HIFIGAN_V1_44K)
+    assert gen.precision == "f32"
+    gen.precision = "f16x3"
+    assert gen.precision == "f16x3"
+    with pytest.raises(ValueError):
+        gen.precision = "bf16"
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "fishvoc.h")).read()
+    assert "FV_PRECISION_F32 = 0" in hdr and "FV_PRECISION_F16X3 = 1" in hdr
