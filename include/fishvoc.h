@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 1
+#define FV_ABI_VERSION 2
 
 /* every entry point below is exported with default visibility (the library is built -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -57,8 +57,10 @@ typedef enum fv_model_kind {
     FV_MODEL_FIREFLY = 4,  /* UnifyGenerator(ConvNeXtEncoder, HiFiGANGenerator) (firefly-gan-base.yaml) */
     FV_MODEL_CONVNEXT = 5, /* ConvNeXtEncoder alone: (B, C_in, T) -> (B, dims[-1], T) */
     FV_MODEL_ISTFT_HEAD = 6, /* ISTFTHead alone: (B, dim, T) -> (B, 1, T*hop) (vocos.py:43-69) */
-    FV_MODEL_LOGMEL = 7      /* LogMelSpectrogram: (B, 1, L) wave -> (B, n_mels, frames) (data/transforms/spectrogram.py:59-104);
+    FV_MODEL_LOGMEL = 7,     /* LogMelSpectrogram: (B, 1, L) wave -> (B, n_mels, frames) (data/transforms/spectrogram.py:59-104);
                                 the step right before the generator in test.py:71 */
+    FV_MODEL_REFINEGAN = 8   /* fish_vocoder.modules.generators.refinegan.RefineGANGenerator (refinegan.py:182): forward(mel, template)
+                                with AdaIN noise supplied by the caller (fv_forward_refinegan) */
 } fv_model_kind;
 
 #define FV_MAX_STAGES 8
@@ -129,6 +131,17 @@ typedef struct fv_logmel_config {
     float f_max; /* <= 0: sample_rate // 2 */
 } fv_logmel_config;
 
+/* RefineGANGenerator ctor kwargs (refinegan.py:183-193); prod(downsample_rates) == prod(upsample_rates) == hop_length. */
+typedef struct fv_refinegan_config {
+    int32_t hop_length;
+    int32_t num_stages; /* len(downsample_rates) == len(upsample_rates) */
+    int32_t downsample_rates[FV_MAX_STAGES];
+    int32_t upsample_rates[FV_MAX_STAGES];
+    int32_t num_mels;
+    int32_t start_channels;
+    float leaky_relu_slope;
+} fv_refinegan_config;
+
 typedef struct fv_config {
     int32_t abi_version; /* = FV_ABI_VERSION */
     int32_t model;       /* fv_model_kind */
@@ -136,6 +149,7 @@ typedef struct fv_config {
     fv_convnext_config backbone; /* VOCOS, FIREFLY, CONVNEXT */
     fv_istft_head_config head;   /* VOCOS */
     fv_logmel_config mel;        /* LOGMEL */
+    fv_refinegan_config refine;  /* REFINEGAN */
 } fv_config;
 
 typedef struct fv_engine fv_engine;
@@ -185,6 +199,16 @@ FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32
  * forward(x, template), hifigan.py:226).  fv_forward == fv_forward_template with d_template = NULL. */
 FV_API fv_status fv_forward_template(fv_engine* e, const float* d_in, const float* d_template, float* d_out, int32_t batch,
                                      int32_t t_in, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* RefineGANGenerator.forward(mel, template) (refinegan.py:287-323).  d_mel: (batch, num_mels, t_in); d_template: (batch, 1,
+ * t_in * hop_length); d_out likewise.  The reference's AdaIN layers draw torch.randn_like on every call (refinegan.py:125);
+ * here the caller supplies those standard-normal samples in d_noise — fv_refinegan_noise_elems floats, laid out as the
+ * concatenation, in order of use (up-sampling stage, branch k = 3 / 7 / 11, first / second AdaIN), of (batch, C_stage, T_stage)
+ * tensors — so that a run is reproducible and parity with the reference can be pinned. */
+FV_API int64_t fv_refinegan_noise_elems(const fv_engine* e, int32_t batch, int32_t t_in);
+FV_API fv_status fv_forward_refinegan(fv_engine* e, const float* d_mel, const float* d_template, const float* d_noise,
+                                      float* d_out, int32_t batch, int32_t t_in, void* d_workspace, size_t workspace_bytes,
+                                      void* stream);
 
 /* -------- single fused conv layer (the hot kernel on its own; used by the parity tests and the roofline
  *          bench).  Stands in for one weight-normed nn.Conv1d / nn.ConvTranspose1d call plus the elementwise

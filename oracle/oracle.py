@@ -423,6 +423,82 @@ def firefly_forward(sd, cfg, mel) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------
+# RefineGAN (fish_vocoder/modules/generators/refinegan.py)
+# ------------------------------------------------------------------------------------------------
+def linear_interp(x, scale_factor) -> np.ndarray:
+    """nn.Upsample(scale_factor=s, mode="linear") = F.interpolate(..., align_corners=False) (refinegan.py:229,262):
+    L_out = floor(L_in * s); src = max((dst + 0.5) / s - 0.5, 0); i0 = floor(src), i1 = min(i0 + 1, L_in - 1);
+    y = x[i0] * (1 - frac) + x[i1] * frac  (aten upsample_linear1d with the given scale factor, fp32 coordinates)."""
+    x = _c(x)
+    lin = x.shape[-1]
+    lout = int(np.floor(lin * float(scale_factor)))
+    scale = np.float32(1.0 / float(scale_factor))
+    src = (np.arange(lout, dtype=np.float32) + np.float32(0.5)) * scale - np.float32(0.5)
+    src = np.maximum(src, np.float32(0.0))
+    i0 = np.minimum(np.floor(src).astype(np.int64), lin - 1)
+    i1 = np.minimum(i0 + 1, lin - 1)
+    lam1 = (src - i0.astype(np.float32)).astype(np.float32)
+    lam0 = np.float32(1.0) - lam1
+    return (x[..., i0] * lam0 + x[..., i1] * lam1).astype(np.float32)
+
+
+def refinegan_resblock_forward(sd, prefix, x, k, cin, cout, slope, dilations=(1, 3, 5)):
+    """refinegan.ResBlock.forward (refinegan.py:87-100): BOTH convs of a pair are dilated; no residual for the first pair
+    when the channel count changes."""
+    for n, d in enumerate(dilations):
+        xt = leaky_relu(x, slope)
+        xt = conv1d(xt, folded_weight(sd, f"{prefix}.convs1.{n}"), _bias(sd, f"{prefix}.convs1.{n}"), dilation=d,
+                    padding=_get_padding(k, d))
+        xt = leaky_relu(xt, slope)
+        xt = conv1d(xt, folded_weight(sd, f"{prefix}.convs2.{n}"), _bias(sd, f"{prefix}.convs2.{n}"), dilation=d,
+                    padding=_get_padding(k, d))
+        x = xt + x if (n != 0 or cin == cout) else xt
+    return x
+
+
+def refinegan_forward(sd, cfg, mel, template, noise) -> np.ndarray:
+    """RefineGANGenerator.forward(mel, template) (refinegan.py:287-323) with AdaIN's torch.randn_like (refinegan.py:125)
+    replaced by the given standard-normal tensors `noise` (list, in order of use: stage, branch, layer)."""
+    slope = float(cfg.get("leaky_relu_slope", 0.2))
+    downs_r, ups_r = list(cfg["downsample_rates"]), list(cfg["upsample_rates"])
+    assert prod(downs_r) == prod(ups_r) == cfg["hop_length"]               # refinegan.py:202
+    ch = cfg["start_channels"]
+    x = conv1d(template, folded_weight(sd, "template_conv"), _bias(sd, "template_conv"), padding=3)
+    downs = []
+    for i, r in enumerate(downs_r):
+        x = leaky_relu(x, slope)                                               # in place: the skip is the activated tensor
+        downs.append(x)
+        x = linear_interp(x, 1.0 / r)
+        x = refinegan_resblock_forward(sd, f"downsample_blocks.{i}.1", x, 7, ch, ch * 2, slope)
+        ch *= 2
+    m = conv1d(mel, folded_weight(sd, "mel_conv"), _bias(sd, "mel_conv"), padding=3)
+    x = np.concatenate([x, m], axis=1)
+    ch *= 2
+    it = iter(noise)
+
+    def adain(x, w):                                                           # refinegan.py:124-127
+        return leaky_relu(x + next(it) * w[None, :, None], slope)
+
+    for i, (r, down) in enumerate(zip(ups_r, reversed(downs))):
+        x = leaky_relu(x, slope)
+        x = linear_interp(x, r)
+        x = np.concatenate([x, down], axis=1)
+        p = f"upsample_conv_blocks.{i}"
+        cout = ch // 2
+        x = conv1d(x, _c(sd[f"{p}.input_conv.weight"]), _c(sd[f"{p}.input_conv.bias"]), padding=3)
+        outs = []
+        for j, k in enumerate((3, 7, 11)):
+            y = adain(x, _c(sd[f"{p}.blocks.{j}.0.weight"]))
+            y = refinegan_resblock_forward(sd, f"{p}.blocks.{j}.1", y, k, cout, cout, slope)
+            outs.append(adain(y, _c(sd[f"{p}.blocks.{j}.2.weight"])))
+        x = np.mean(np.stack(outs, 0), axis=0, dtype=np.float32)
+        ch = cout
+    x = leaky_relu(x, slope)
+    x = conv1d(x, folded_weight(sd, "output_conv"), _bias(sd, "output_conv"), padding=3)
+    return tanh(x)
+
+
+# ------------------------------------------------------------------------------------------------
 # Log-mel front-end (next row f1): fish_vocoder/data/transforms/spectrogram.py
 # ------------------------------------------------------------------------------------------------
 def _hz_to_mel_slaney(f):

@@ -379,6 +379,38 @@ def gen_logmel():
     _save("logmel.npz", pinned_linear=True, pinned_logmel=False, **arrs)
 
 
+@torch.no_grad()
+def gen_refinegan(name, cfg, seed, B, T, mel_seed):
+    """RefineGANGenerator (refinegan.py:182-323).  AdaIN draws torch.randn_like (refinegan.py:125): the draws are replaced,
+    in call order, by the seeded numpy tensors of syn.refinegan_noise, so the fixture stores only seeds."""
+    from fish_vocoder.modules.generators import refinegan as rg
+    sd = syn.refinegan_state_dict(cfg, seed)
+    g = rg.RefineGANGenerator(**cfg).eval()
+    g.load_state_dict(_t(sd), strict=True)
+    mel = syn.synthetic_mel(B, cfg["num_mels"], T, mel_seed)
+    tmpl = syn.synthetic_template(B, T, cfg["hop_length"], seed=mel_seed + 1)
+    noise = iter(syn.refinegan_noise(cfg, B, T, seed=mel_seed + 2))
+    real = torch.randn_like
+
+    def fake_randn_like(x, *a, **k):
+        n = torch.from_numpy(next(noise))
+        assert n.shape == x.shape, (n.shape, x.shape)
+        return n
+
+    torch.randn_like = fake_randn_like
+    try:
+        out = g(torch.from_numpy(mel), torch.from_numpy(tmpl)).numpy()
+    finally:
+        torch.randn_like = real
+    assert next(noise, None) is None, "unused noise tensors: the draw order changed"
+    # the linear-interpolation primitive on its own (nn.Upsample(mode="linear"), refinegan.py:229,262)
+    x = np.random.default_rng(5).normal(size=(2, 3, 37)).astype(np.float32)
+    interp = {f"interp_{tag}": nn.Upsample(scale_factor=sf, mode="linear")(torch.from_numpy(x)).numpy()
+              for tag, sf in (("d2", 0.5), ("d8", 0.125), ("u2", 2), ("u8", 8))}
+    _save(name, cfg=_cfg_arr(cfg), seed=seed, mel=mel, template=tmpl, noise_seed=mel_seed + 2, out=out, interp_x=x,
+          pinned=True, **interp)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -415,6 +447,13 @@ def main():
               head=dict(dim=64, n_fft=64, hop_length=16, win_length=64, padding="same"))
     gen_vocos("vocos_tiny.npz", vc, seed=9, B=2, T=15, mel_seed=26)
     gen_logmel()
+    rgc = dict(sampling_rate=16000, hop_length=16, downsample_rates=(2, 2, 2, 2), upsample_rates=(2, 2, 2, 2),
+               leaky_relu_slope=0.2, num_mels=12, start_channels=4)
+    gen_refinegan("refinegan_tiny.npz", rgc, seed=14, B=2, T=7, mel_seed=31)
+    # the reference defaults' rate pattern (2, 2, 8, 8) / (8, 8, 2, 2) at a reduced width
+    rgd = dict(sampling_rate=44100, hop_length=256, downsample_rates=(2, 2, 8, 8), upsample_rates=(8, 8, 2, 2),
+               leaky_relu_slope=0.2, num_mels=16, start_channels=2)
+    gen_refinegan("refinegan_rates.npz", rgd, seed=15, B=1, T=3, mel_seed=33)
 
 
 if __name__ == "__main__":

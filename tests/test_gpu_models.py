@@ -238,3 +238,50 @@ def test_template_branch_golden_and_module():
     y = _hifigan_engine(cfg, sd)(torch.from_numpy(mel).cuda(), None, torch.from_numpy(tmpl).cuda())
     torch.cuda.synchronize()
     assert np.abs(y.cpu().numpy() - ref).max() <= TOL
+
+
+@pytest.mark.parametrize("name", ["refinegan_tiny.npz", "refinegan_rates.npz"])
+def test_refinegan_golden(name):
+    """RefineGAN through the engine (fv_forward_refinegan) and through the drop-in module, against the reference capture."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, refinegan_config
+    from vocoder_amd.modules.generators.refinegan import RefineGANGenerator
+    g = load_golden(name)
+    cfg = g["cfg"]
+    sd = syn.refinegan_state_dict(cfg, g["seed"])
+    B, _, T = g["mel"].shape
+    noise = np.concatenate([n.reshape(-1) for n in syn.refinegan_noise(cfg, B, T, seed=int(g["noise_seed"]))])
+    eng = Engine(_lib.FV_MODEL_REFINEGAN, refine=refinegan_config(**cfg), state_dict=sd)
+    assert eng.noise_elems(B, T) == noise.size
+    dev = _dev()
+    y = eng(torch.from_numpy(g["mel"]).to(dev), None, torch.from_numpy(g["template"]).to(dev),
+            torch.from_numpy(noise).to(dev)).cpu().numpy()
+    err = np.abs(y - g["out"]).max()
+    assert err <= TOL, f"{name}: max|d| = {err:.3e}"
+    gen = RefineGANGenerator(**cfg).eval()
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    gen = gen.to(dev)
+    y2 = gen(torch.from_numpy(g["mel"]).to(dev), torch.from_numpy(g["template"]).to(dev), torch.from_numpy(noise).to(dev))
+    assert np.abs(y2.cpu().numpy() - g["out"]).max() <= TOL
+    y3 = gen(torch.from_numpy(g["mel"]).to(dev), torch.from_numpy(g["template"]).to(dev))   # own torch.randn draws
+    assert y3.shape == y2.shape and bool(torch.isfinite(y3).all()) and float((y3 - y2).abs().max()) > 0
+
+
+def test_refinegan_default_config_vs_oracle():
+    """The reference's default widths / rates (start_channels=16, (2,2,8,8)/(8,8,2,2), hop 256) on a short clip."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, refinegan_config
+    cfg = dict(syn.REFINEGAN_44K)
+    sd = syn.refinegan_state_dict(cfg, seed=4)
+    B, T = 2, 5
+    mel = syn.synthetic_mel(B, cfg["num_mels"], T, seed=2)
+    tmpl = syn.synthetic_template(B, T, cfg["hop_length"], seed=3)
+    noise = syn.refinegan_noise(cfg, B, T, seed=5)
+    ref = orc.refinegan_forward(sd, cfg, mel, tmpl, noise)
+    eng = Engine(_lib.FV_MODEL_REFINEGAN, refine=refinegan_config(**cfg), state_dict=sd)
+    dev = _dev()
+    y = eng(torch.from_numpy(mel).to(dev), None, torch.from_numpy(tmpl).to(dev),
+            torch.from_numpy(np.concatenate([n.reshape(-1) for n in noise])).to(dev)).cpu().numpy()
+    assert np.abs(y - ref).max() <= TOL, np.abs(y - ref).max()
+    with pytest.raises(Exception):
+        eng(torch.from_numpy(mel).to(dev))   # template + noise are mandatory

@@ -32,7 +32,9 @@ def test_config_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.IstftHeadConfig) == 16
     assert ctypes.sizeof(_lib.ConvDesc) == 40
     assert ctypes.sizeof(_lib.LogMelConfig) == 28
-    assert ctypes.sizeof(_lib.Config) == 8 + ctypes.sizeof(_lib.UpsamplerConfig) + ctypes.sizeof(_lib.ConvNeXtConfig) + 16 + 28
+    assert ctypes.sizeof(_lib.RefineGANConfig) == 4 * (2 + 8 + 8 + 3)
+    assert ctypes.sizeof(_lib.Config) == (8 + ctypes.sizeof(_lib.UpsamplerConfig) + ctypes.sizeof(_lib.ConvNeXtConfig) + 16 + 28 +
+                                          ctypes.sizeof(_lib.RefineGANConfig))
 
 
 def test_fv_create_validation_without_gpu():
@@ -180,3 +182,19 @@ def test_precision_option_is_validated_without_a_gpu():
         gen.precision = "bf16"
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "fishvoc.h")).read()
     assert "FV_PRECISION_F32 = 0" in hdr and "FV_PRECISION_F16X3 = 1" in hdr
+
+
+def test_refinegan_dropin_has_the_reference_state_dict_keys():
+    from vocoder_amd.modules.generators.refinegan import RefineGANGenerator
+    cfg = dict(sampling_rate=16000, hop_length=16, downsample_rates=(2, 2, 2, 2), upsample_rates=(2, 2, 2, 2),
+               leaky_relu_slope=0.2, num_mels=12, start_channels=4)
+    gen = RefineGANGenerator(**cfg)
+    sd = syn.refinegan_state_dict(cfg, seed=1)
+    own = gen.state_dict()
+    assert list(own.keys()) == list(sd.keys())          # same names in the same (reference) order
+    for k, v in sd.items():
+        assert tuple(own[k].shape) == v.shape, k
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert gen.noise_elems(2, 7) == sum(2 * c * t for c, t in syn.refinegan_stage_shapes(cfg, 7)) * 6
+    with pytest.raises(AssertionError):
+        RefineGANGenerator(**dict(cfg, hop_length=32))   # refinegan.py:202

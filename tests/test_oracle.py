@@ -183,3 +183,18 @@ def test_logmel_frontend_matches_reference():
             area = fb.sum(0) * df      # the narrowest low filters span ~3 bins: coarse Riemann sum there
             assert np.median(np.abs(area - 1.0)) < 0.01 and np.abs(area - 1.0).max() < 0.15
         _close(orc.logmel_forward(z[f"{tag}_wave"], cfg), z[f"{tag}_logmel"], 2e-5)
+
+
+@pytest.mark.parametrize("name", ["refinegan_tiny.npz", "refinegan_rates.npz"])
+def test_refinegan_oracle_matches_reference_golden(name):
+    """RefineGANGenerator (refinegan.py:182-323) captured from the reference with AdaIN's torch.randn_like replaced by seeded
+    samples; the oracle consumes the same samples."""
+    g = load_golden(name)
+    cfg = g["cfg"]
+    sd = syn.refinegan_state_dict(cfg, g["seed"])
+    noise = syn.refinegan_noise(cfg, g["mel"].shape[0], g["mel"].shape[2], seed=int(g["noise_seed"]))
+    y = orc.refinegan_forward(sd, cfg, g["mel"], g["template"], noise)
+    assert y.shape == g["out"].shape
+    assert np.abs(y - g["out"]).max() <= 2e-6
+    for tag, sf in (("d2", 0.5), ("d8", 0.125), ("u2", 2), ("u8", 8)):   # nn.Upsample(mode="linear"), refinegan.py:229,262
+        assert np.abs(orc.linear_interp(g["interp_x"], sf) - g[f"interp_{tag}"]).max() <= 5e-7

@@ -14,13 +14,14 @@ CSRC = os.path.join(_HERE, "csrc")
 # FV_LIB_PATH points the loader at an experimental build (A/B kernel variants); default = the in-tree library
 LIB_PATH = os.environ.get("FV_LIB_PATH") or os.path.join(CSRC, "libfishvoc_hip.so")
 
-FV_ABI_VERSION = 1
+FV_ABI_VERSION = 2
 FV_MAX_STAGES = 8
 FV_MAX_KERNELS = 8
 FV_MAX_DILATIONS = 3
 
 FV_MODEL_HIFIGAN, FV_MODEL_BIGVGAN, FV_MODEL_VOCOS, FV_MODEL_FIREFLY, FV_MODEL_CONVNEXT, FV_MODEL_ISTFT_HEAD = 1, 2, 3, 4, 5, 6
 FV_MODEL_LOGMEL = 7
+FV_MODEL_REFINEGAN = 8
 FV_PRECISION_F32, FV_PRECISION_F16X3 = 0, 1
 PRECISIONS = {"f32": FV_PRECISION_F32, "f16x3": FV_PRECISION_F16X3}
 FV_ACT_NONE, FV_ACT_SILU, FV_ACT_LEAKY_RELU, FV_ACT_GELU, FV_ACT_TANH, FV_ACT_LOG_CLAMP = 0, 1, 2, 3, 4, 5
@@ -30,7 +31,7 @@ EXPORTS = (
     "fv_input_channels", "fv_workspace_bytes", "fv_forward", "fv_conv_create", "fv_conv_output_length",
     "fv_conv_forward", "fv_conv_destroy", "fv_last_error", "fv_abi_version", "fv_last_kernel",
     "fv_profile_begin", "fv_profile_end", "fv_conv_pair_forward", "fv_forward_template",
-    "fv_set_precision", "fv_conv_set_precision",
+    "fv_set_precision", "fv_conv_set_precision", "fv_refinegan_noise_elems", "fv_forward_refinegan",
 )
 
 _i32 = ctypes.c_int32
@@ -61,9 +62,15 @@ class LogMelConfig(ctypes.Structure):
                 ("f_min", ctypes.c_float), ("f_max", ctypes.c_float)]
 
 
+class RefineGANConfig(ctypes.Structure):
+    _fields_ = [("hop_length", _i32), ("num_stages", _i32), ("downsample_rates", _i32 * FV_MAX_STAGES),
+                ("upsample_rates", _i32 * FV_MAX_STAGES), ("num_mels", _i32), ("start_channels", _i32),
+                ("leaky_relu_slope", ctypes.c_float)]
+
+
 class Config(ctypes.Structure):
     _fields_ = [("abi_version", _i32), ("model", _i32), ("ups", UpsamplerConfig), ("backbone", ConvNeXtConfig),
-                ("head", IstftHeadConfig), ("mel", LogMelConfig)]
+                ("head", IstftHeadConfig), ("mel", LogMelConfig), ("refine", RefineGANConfig)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -115,6 +122,10 @@ def lib() -> ctypes.CDLL:
     L.fv_forward.restype = _i32
     L.fv_forward_template.argtypes = [vp, vp, vp, vp, _i32, _i32, vp, ctypes.c_size_t, vp]
     L.fv_forward_template.restype = _i32
+    L.fv_refinegan_noise_elems.argtypes = [vp, _i32, _i32]
+    L.fv_refinegan_noise_elems.restype = ctypes.c_int64
+    L.fv_forward_refinegan.argtypes = [vp, vp, vp, vp, vp, _i32, _i32, vp, ctypes.c_size_t, vp]
+    L.fv_forward_refinegan.restype = _i32
     L.fv_conv_create.argtypes = [ctypes.POINTER(ConvDesc), fp, fp, ctypes.POINTER(vp)]
     L.fv_conv_create.restype = _i32
     L.fv_conv_output_length.argtypes = [vp, _i32]

@@ -24,6 +24,7 @@ CONFIG_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs"
 TARGET_ALIASES = {
     "fish_vocoder.modules.generators.hifigan": "vocoder_amd.modules.generators.hifigan",
     "fish_vocoder.modules.generators.bigvgan": "vocoder_amd.modules.generators.bigvgan",
+    "fish_vocoder.modules.generators.refinegan": "vocoder_amd.modules.generators.refinegan",
     "fish_vocoder.modules.generators.vocos": "vocoder_amd.modules.generators.vocos",
     "fish_vocoder.modules.generators.unify": "vocoder_amd.modules.generators.unify",
     "fish_vocoder.modules.encoders.convnext": "vocoder_amd.modules.encoders.convnext",

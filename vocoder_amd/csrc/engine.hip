@@ -266,6 +266,66 @@ struct LogMelModel {
     }
 };
 
+// RefineGANGenerator (refinegan.py:182-323): U-Net over the pitch template with the mel injected at the bottleneck.
+struct RefineResBlock {   // refinegan.ResBlock (refinegan.py:38-110): both convs of a pair are dilated
+    int k = 0, cin = 0, cout = 0;
+    ConvLayer c1[3], c2[3];
+    void destroy() {
+        for (int n = 0; n < 3; ++n) {
+            conv_layer_destroy(c1[n]);
+            conv_layer_destroy(c2[n]);
+        }
+    }
+};
+struct RefineUp {         // nn.Upsample + ParallelResBlock (refinegan.py:130-179,262-273)
+    int rate = 1, cin = 0, cskip = 0, cout = 0;
+    ConvLayer input_conv;
+    float* d_w1[3] = {nullptr, nullptr, nullptr};   // AdaIN weights before / after each branch's ResBlock
+    float* d_w2[3] = {nullptr, nullptr, nullptr};
+    RefineResBlock rb[3];
+};
+struct RefineModel {
+    fv_refinegan_config cfg{};
+    ConvLayer template_conv, mel_conv;
+    std::vector<std::unique_ptr<RefineResBlock>> downs;
+    std::vector<std::unique_ptr<RefineUp>> ups;
+    float *d_wout = nullptr, *d_bout = nullptr;
+    int out_cin = 0;
+    void destroy() {
+        conv_layer_destroy(template_conv);
+        conv_layer_destroy(mel_conv);
+        for (auto& d : downs) d->destroy();
+        for (auto& u : ups) {
+            conv_layer_destroy(u->input_conv);
+            for (int j = 0; j < 3; ++j) {
+                u->rb[j].destroy();
+                if (u->d_w1[j]) (void)hipFree(u->d_w1[j]);
+                if (u->d_w2[j]) (void)hipFree(u->d_w2[j]);
+            }
+        }
+        if (d_wout) (void)hipFree(d_wout);
+        if (d_bout) (void)hipFree(d_bout);
+        d_wout = d_bout = nullptr;
+        downs.clear();
+        ups.clear();
+    }
+    // tensor lengths along the U: down[i] = length after i down-sampling steps (down[0] = T * hop), up[i] likewise upwards
+    // from T.  nn.Upsample sizes its output as floor(L * scale_factor) in double (refinegan.py:229: scale_factor = 1 / rate).
+    bool lengths(int T, std::vector<int64_t>& down, std::vector<int64_t>& up) const {
+        const int S = cfg.num_stages;
+        down.assign(S + 1, 0);
+        up.assign(S + 1, 0);
+        down[0] = (int64_t)T * cfg.hop_length;
+        for (int i = 0; i < S; ++i) down[i + 1] = (int64_t)std::floor((double)down[i] * (1.0 / (double)cfg.downsample_rates[i]));
+        up[0] = T;
+        for (int i = 0; i < S; ++i) up[i + 1] = (int64_t)std::floor((double)up[i] * (double)cfg.upsample_rates[i]);
+        if (down[S] != T) return false;                        // torch.cat([x, mel_conv(mel)]) needs equal lengths
+        for (int i = 0; i < S; ++i)
+            if (up[i + 1] != down[S - 1 - i]) return false;      // torch.cat([x, down]) (refinegan.py:314)
+        return true;
+    }
+};
+
 }  // namespace fv
 
 using namespace fv;
@@ -279,6 +339,7 @@ struct fv_engine {
     ConvNeXtModel cnx;
     IstftHeadModel head;
     LogMelModel mel;
+    RefineModel refine;
     bool has_ups = false, has_cnx = false, has_head = false;
     Profiler prof;
     bool profiling = false;
@@ -289,10 +350,11 @@ struct fv_engine {
         void* out;
         void* ws;
         const void* tmpl;
+        const void* noise;
         int batch, t_in;
         hipStream_t stream;
         bool operator==(const GraphKey& o) const {
-            return in == o.in && out == o.out && ws == o.ws && tmpl == o.tmpl && batch == o.batch && t_in == o.t_in &&
+            return in == o.in && out == o.out && ws == o.ws && tmpl == o.tmpl && noise == o.noise && batch == o.batch && t_in == o.t_in &&
                    stream == o.stream;
         }
     };
@@ -434,6 +496,9 @@ struct fv_engine {
     fv_status build_logmel(const std::string& pfx);
     fv_status run_logmel(const float* d_in, float* d_out, int B, int L, float* ws, hipStream_t s);
 
+    fv_status build_refinegan();
+    fv_status run_refinegan(const float* d_mel, float* d_out, int B, int T, float* ws, hipStream_t s);
+    const float* cur_noise = nullptr;      // set by fv_forward_refinegan for the duration of one call
     fv_status run_model(const float* d_in, float* d_out, int batch, int t_in, float* ws, hipStream_t s);
     fv_status run_upsampler(const float* d_in, float* d_out, int B, int T, float* ws, hipStream_t s);
     const float* cur_template = nullptr;   // set by fv_forward_template for the duration of one call
@@ -452,6 +517,7 @@ struct fv_engine {
         cnx.destroy();
         head.destroy();
         mel.destroy();
+        refine.destroy();
     }
 };
 
@@ -1060,6 +1126,22 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
             }
             break;
         case FV_MODEL_CONVNEXT: break;
+        case FV_MODEL_REFINEGAN: {
+            const fv_refinegan_config& g = cfg->refine;
+            long long pd = 1, pu = 1;
+            bool ok = g.num_stages >= 1 && g.num_stages <= FV_MAX_STAGES && g.num_mels >= 1 && g.start_channels >= 1 && g.hop_length >= 1;
+            for (int i = 0; ok && i < g.num_stages; ++i) {
+                ok = g.downsample_rates[i] >= 1 && g.upsample_rates[i] >= 1;
+                pd *= g.downsample_rates[i];
+                pu *= g.upsample_rates[i];
+            }
+            // assert np.prod(downsample_rates) == np.prod(upsample_rates) == hop_length (refinegan.py:202)
+            if (!ok || pd != g.hop_length || pu != g.hop_length) {
+                set_error("refinegan: prod(downsample_rates) and prod(upsample_rates) must both equal hop_length (%d)", g.hop_length);
+                st = FV_ERR_INVALID;
+            }
+            break;
+        }
         case FV_MODEL_LOGMEL: {
             const fv_logmel_config& m = cfg->mel;
             if (m.n_fft < 2 || m.n_fft % 2 || m.hop_length < 1 || m.win_length != m.n_fft || m.n_fft % m.hop_length ||
@@ -1072,7 +1154,7 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
         default: set_error("fv_create: unknown model kind %d", cfg->model); st = FV_ERR_INVALID;
     }
     if (!st && cfg->model != FV_MODEL_HIFIGAN && cfg->model != FV_MODEL_BIGVGAN && cfg->model != FV_MODEL_ISTFT_HEAD &&
-        cfg->model != FV_MODEL_LOGMEL) {
+        cfg->model != FV_MODEL_LOGMEL && cfg->model != FV_MODEL_REFINEGAN) {
         const fv_convnext_config& b = cfg->backbone;
         if (b.num_stages < 1 || b.num_stages > FV_MAX_STAGES || b.input_channels < 1 || b.kernel_size < 1 || b.kernel_size % 2 == 0) {
             set_error("convnext: invalid num_stages / input_channels / kernel_size");
@@ -1149,6 +1231,7 @@ FV_API fv_status fv_finalize(fv_engine* e) {
         case FV_MODEL_CONVNEXT: st = e->build_convnext(""); break;
         case FV_MODEL_ISTFT_HEAD: st = e->build_head(""); break;
         case FV_MODEL_LOGMEL: st = e->build_logmel(""); break;
+        case FV_MODEL_REFINEGAN: st = e->build_refinegan(); break;
         case FV_MODEL_VOCOS:
             st = e->build_convnext("backbone.");
             if (!st) st = e->build_head("head.");
@@ -1176,6 +1259,7 @@ FV_API int32_t fv_input_channels(const fv_engine* e) {
     if (!e) return 0;
     if (e->cfg.model == FV_MODEL_ISTFT_HEAD) return e->cfg.head.dim;
     if (e->cfg.model == FV_MODEL_LOGMEL) return 1;
+    if (e->cfg.model == FV_MODEL_REFINEGAN) return e->cfg.refine.num_mels;
     return (e->cfg.model == FV_MODEL_HIFIGAN || e->cfg.model == FV_MODEL_BIGVGAN) ? e->cfg.ups.num_mels
                                                                                     : e->cfg.backbone.input_channels;
 }
@@ -1193,11 +1277,13 @@ FV_API int64_t fv_output_length(const fv_engine* e, int32_t t_in) {
         case FV_MODEL_VOCOS:
         case FV_MODEL_ISTFT_HEAD: return (int64_t)t_in * e->cfg.head.hop_length;
         case FV_MODEL_LOGMEL: return std::max(0, e->mel.frames(t_in));
+        case FV_MODEL_REFINEGAN: return (int64_t)t_in * e->cfg.refine.hop_length;
         default: return t_in;
     }
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static size_t refine_ws_elems(const fv_engine* e, int B, int T);
 
 static size_t ups_ws_elems(const fv_engine* e, int B, int T) {
     return (size_t)(3 + 3 * e->ups.cfg.num_kernels) * ((e->ups.max_elems(T) * B + 63) / 64 * 64);
@@ -1225,6 +1311,7 @@ FV_API size_t fv_workspace_bytes(const fv_engine* e, int32_t batch, int32_t t_in
                     ((size_t)batch * 3 * e->mel.nb * T + 128);
             break;
         }
+        case FV_MODEL_REFINEGAN: elems = refine_ws_elems(e, batch, t_in); break;
         case FV_MODEL_VOCOS: {
             const size_t mid = align_up((size_t)e->cnx.out_dim() * t_in * batch, 64);
             elems = mid + std::max(cnx_ws_elems(e, batch, t_in), head_ws_elems(e, batch, t_in));
@@ -1244,8 +1331,44 @@ FV_API fv_status fv_forward(fv_engine* e, const float* d_in, float* d_out, int32
     return fv_forward_template(e, d_in, nullptr, d_out, batch, t_in, d_workspace, workspace_bytes, stream);
 }
 
+static fv_status forward_common(fv_engine* e, const float* d_in, const float* d_template, const float* d_noise, float* d_out,
+                                int32_t batch, int32_t t_in, void* d_workspace, size_t workspace_bytes, void* stream);
+
 FV_API fv_status fv_forward_template(fv_engine* e, const float* d_in, const float* d_template, float* d_out, int32_t batch,
                                      int32_t t_in, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (e && e->cfg.model == FV_MODEL_REFINEGAN) {
+        set_error("fv_forward: a RefineGAN engine needs fv_forward_refinegan (template + AdaIN noise)");
+        return FV_ERR_INVALID;
+    }
+    return forward_common(e, d_in, d_template, nullptr, d_out, batch, t_in, d_workspace, workspace_bytes, stream);
+}
+
+FV_API int64_t fv_refinegan_noise_elems(const fv_engine* e, int32_t batch, int32_t t_in) {
+    if (!e || !e->finalized || e->cfg.model != FV_MODEL_REFINEGAN || batch < 1 || t_in < 1) return 0;
+    int64_t n = 0, t = t_in;
+    for (auto& u : e->refine.ups) {
+        t *= u->rate;
+        n += 6LL * batch * u->cout * t;
+    }
+    return n;
+}
+
+FV_API fv_status fv_forward_refinegan(fv_engine* e, const float* d_mel, const float* d_template, const float* d_noise,
+                                      float* d_out, int32_t batch, int32_t t_in, void* d_workspace, size_t workspace_bytes,
+                                      void* stream) {
+    if (!e || e->cfg.model != FV_MODEL_REFINEGAN) {
+        set_error("fv_forward_refinegan: not a RefineGAN engine");
+        return FV_ERR_INVALID;
+    }
+    if (!d_template || !d_noise) {
+        set_error("fv_forward_refinegan: template (B, 1, T*hop) and noise (fv_refinegan_noise_elems floats) are required");
+        return FV_ERR_INVALID;
+    }
+    return forward_common(e, d_mel, d_template, d_noise, d_out, batch, t_in, d_workspace, workspace_bytes, stream);
+}
+
+static fv_status forward_common(fv_engine* e, const float* d_in, const float* d_template, const float* d_noise, float* d_out,
+                                int32_t batch, int32_t t_in, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (!e || !d_in || !d_out) {
         set_error("fv_forward: null argument");
         return FV_ERR_INVALID;
@@ -1259,12 +1382,17 @@ FV_API fv_status fv_forward_template(fv_engine* e, const float* d_in, const floa
         return FV_ERR_INVALID;
     }
     const size_t need = fv_workspace_bytes(e, batch, t_in);
+    if (e->cfg.model == FV_MODEL_REFINEGAN && need == 0) {
+        set_error("refinegan: the down/up-sampling lengths do not line up for %d frames (the reference's torch.cat would fail)", t_in);
+        return FV_ERR_INVALID;
+    }
     if (!d_workspace || workspace_bytes < need) {
         set_error("fv_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
         return FV_ERR_INVALID;
     }
-    const bool wants_template = (e->cfg.model == FV_MODEL_HIFIGAN || e->cfg.model == FV_MODEL_BIGVGAN || e->cfg.model == FV_MODEL_FIREFLY) &&
-                                e->cfg.ups.use_template;
+    const bool wants_template = e->cfg.model == FV_MODEL_REFINEGAN ||
+                                ((e->cfg.model == FV_MODEL_HIFIGAN || e->cfg.model == FV_MODEL_BIGVGAN || e->cfg.model == FV_MODEL_FIREFLY) &&
+                                 e->cfg.ups.use_template);
     if (wants_template && !d_template) {
         set_error("fv_forward: this generator was built with use_template=True and needs a template (B, 1, T*hop)");
         return FV_ERR_INVALID;
@@ -1274,6 +1402,7 @@ FV_API fv_status fv_forward_template(fv_engine* e, const float* d_in, const floa
         return FV_ERR_INVALID;
     }
     e->cur_template = d_template;
+    e->cur_noise = d_noise;
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)d_workspace;
     struct ProfGuard {
@@ -1284,7 +1413,7 @@ FV_API fv_status fv_forward_template(fv_engine* e, const float* d_in, const floa
     // hipGraph replay: a forward is ~110 launches plus fork/join events; at small batch the host launch cost dominates
     // (p50 clip latency).  The launch sequence is static for a given (pointers, batch, frames, stream), so the second
     // consecutive call with the same key is stream-captured (including the branch streams) and later calls replay it.
-    fv_engine::GraphKey key{d_in, d_out, d_workspace, d_template, batch, t_in, s};
+    fv_engine::GraphKey key{d_in, d_out, d_workspace, d_template, d_noise, batch, t_in, s};
     const bool graphable = e->use_graph && !e->profiling && s != nullptr;
     if (graphable) {
         for (auto& g : e->graphs)
@@ -1330,6 +1459,234 @@ FV_API fv_status fv_forward_template(fv_engine* e, const float* d_in, const floa
 
 }  // extern "C"
 
+// ------------------------------------------------------------------------------------------------
+// RefineGAN (refinegan.py:182-323)
+// ------------------------------------------------------------------------------------------------
+fv_status fv_engine::build_refinegan() {
+    const fv_refinegan_config& c = cfg.refine;
+    refine.cfg = c;
+    const int S = c.num_stages;
+    const bool f16 = false;   // the U-Net's narrow convs stay on the exact-fp32 kernels
+    (void)f16;
+    fv_status st;
+    int ch = c.start_channels;
+    if ((st = make_conv(refine.template_conv, "template_conv", false, 1, ch, 7, 1, 3, 1))) return st;
+    auto make_resblock = [&](RefineResBlock& rb, const std::string& prefix, int cin, int cout, int k) -> fv_status {
+        rb.k = k;
+        rb.cin = cin;
+        rb.cout = cout;
+        static const int dil[3] = {1, 3, 5};
+        for (int n = 0; n < 3; ++n) {
+            fv_status s1 = make_conv(rb.c1[n], prefix + ".convs1." + std::to_string(n), false, n == 0 ? cin : cout, cout, k,
+                                     dil[n], get_padding(k, dil[n]), 1);
+            if (s1) return s1;
+        }
+        for (int n = 0; n < 3; ++n) {
+            fv_status s2 = make_conv(rb.c2[n], prefix + ".convs2." + std::to_string(n), false, cout, cout, k, dil[n],
+                                     get_padding(k, dil[n]), 1);
+            if (s2) return s2;
+        }
+        return FV_OK;
+    };
+    for (int i = 0; i < S; ++i) {
+        refine.downs.emplace_back(new RefineResBlock());
+        if ((st = make_resblock(*refine.downs.back(), "downsample_blocks." + std::to_string(i) + ".1", ch, ch * 2, 7))) return st;
+        ch *= 2;
+    }
+    if ((st = make_conv(refine.mel_conv, "mel_conv", false, c.num_mels, ch, 7, 1, 3, 1))) return st;
+    ch *= 2;
+    static const int ks[3] = {3, 7, 11};
+    for (int i = 0; i < S; ++i) {
+        refine.ups.emplace_back(new RefineUp());
+        RefineUp& u = *refine.ups.back();
+        u.rate = c.upsample_rates[i];
+        u.cin = ch;
+        u.cskip = ch / 4;
+        u.cout = ch / 2;
+        const std::string p = "upsample_conv_blocks." + std::to_string(i);
+        if ((st = make_conv(u.input_conv, p + ".input_conv", false, u.cin + u.cskip, u.cout, 7, 1, 3, 1))) return st;
+        for (int j = 0; j < 3; ++j) {
+            const std::string bp = p + ".blocks." + std::to_string(j);
+            if ((st = make_dev_vec(bp + ".0.weight", u.cout, &u.d_w1[j]))) return st;
+            if ((st = make_resblock(u.rb[j], bp + ".1", u.cout, u.cout, ks[j]))) return st;
+            if ((st = make_dev_vec(bp + ".2.weight", u.cout, &u.d_w2[j]))) return st;
+        }
+        ch = u.cout;
+    }
+    // output_conv: weight-normed Conv1d(ch -> 1, k7) + tanh on the narrow-output kernel
+    std::vector<float> w, b;
+    if ((st = conv_weight("output_conv", {1, ch, 7}, w))) return st;
+    if ((st = vec("output_conv.bias", 1, b))) return st;
+    if ((st = upload(w, &refine.d_wout))) return st;
+    if ((st = upload(b, &refine.d_bout))) return st;
+    refine.out_cin = ch;
+    return FV_OK;
+}
+
+// Workspace: S skip tensors (sized exactly) + 7 transient buffers of the largest (C x length) tensor.
+static size_t refine_max_elems(const RefineModel& m, const std::vector<int64_t>& down, const std::vector<int64_t>& up) {
+    const int S = m.cfg.num_stages;
+    int64_t mx = 0;
+    int ch = m.cfg.start_channels;
+    for (int i = 0; i < S; ++i) {
+        mx = std::max<int64_t>(mx, (int64_t)2 * ch * down[i + 1]);   // ResBlock tensors of down block i (and the interp output)
+        ch *= 2;
+    }
+    mx = std::max<int64_t>(mx, (int64_t)2 * ch * down[S]);           // cat([x, mel_conv(mel)])
+    for (int i = 0; i < S; ++i) {
+        const RefineUp& u = *m.ups[i];
+        mx = std::max<int64_t>(mx, (int64_t)(u.cin + u.cskip) * up[i + 1]);
+    }
+    return (size_t)mx;
+}
+static size_t refine_ws_elems(const fv_engine* e, int B, int T) {
+    std::vector<int64_t> down, up;
+    if (!e->refine.lengths(T, down, up)) return 0;
+    size_t skips = 0;
+    int ch = e->refine.cfg.start_channels;
+    for (int i = 0; i < e->refine.cfg.num_stages; ++i) {
+        skips += ((size_t)ch * down[i] * B + 63) / 64 * 64;
+        ch *= 2;
+    }
+    return skips + 7 * ((refine_max_elems(e->refine, down, up) * B + 63) / 64 * 64);
+}
+
+fv_status fv_engine::run_refinegan(const float* d_mel, float* d_out, int B, int T, float* ws, hipStream_t s) {
+    const RefineModel& m = refine;
+    const int S = m.cfg.num_stages;
+    const float slope = m.cfg.leaky_relu_slope;
+    std::vector<int64_t> down, up;
+    if (!m.lengths(T, down, up)) {
+        set_error("refinegan: the down/up-sampling lengths do not line up for %d frames (the reference's torch.cat would fail)", T);
+        return FV_ERR_INVALID;
+    }
+    if (down[0] >= (1LL << 31)) {
+        set_error("refinegan: clip too long");
+        return FV_ERR_UNSUPPORTED;
+    }
+    // ---- workspace ----
+    std::vector<float*> skip(S);
+    float* wp = ws;
+    {
+        int ch = m.cfg.start_channels;
+        for (int i = 0; i < S; ++i) {
+            skip[i] = wp;
+            wp += ((size_t)ch * down[i] * B + 63) / 64 * 64;
+            ch *= 2;
+        }
+    }
+    const size_t me = (refine_max_elems(m, down, up) * B + 63) / 64 * 64;
+    float* P[7];
+    for (int i = 0; i < 7; ++i) P[i] = wp + (size_t)i * me;
+    fv_status st;
+    ConvRun r;
+    // one refinegan.ResBlock (refinegan.py:87-100): in -> out; XT, XB scratch; leaky_relu fused into c1's staging and epilogue
+    auto resblock = [&](const RefineResBlock& rb, const float* in, float* out, float* XT, float* XB, int t,
+                        bool post_leaky) -> fv_status {
+        const float* src = in;
+        for (int n = 0; n < 3; ++n) {
+            ConvRun q;
+            q.batch = B;
+            q.t_in = t;
+            q.x = src;
+            q.y = XT;
+            q.pre_act = FV_ACT_LEAKY_RELU;
+            q.post_act = FV_ACT_LEAKY_RELU;
+            q.slope = slope;
+            fv_status e1 = conv_layer_run(rb.c1[n], q, s);
+            if (e1) return e1;
+            q = ConvRun();
+            q.batch = B;
+            q.t_in = t;
+            q.x = XT;
+            q.y = n == 2 ? out : XB;
+            q.res = (n != 0 || rb.cin == rb.cout) ? src : nullptr;   // refinegan.py:95-98
+            if (n == 2 && post_leaky) {
+                q.post_act = FV_ACT_LEAKY_RELU;
+                q.slope = slope;
+            }
+            fv_status e2 = conv_layer_run(rb.c2[n], q, s);
+            if (e2) return e2;
+            src = XB;
+        }
+        return FV_OK;
+    };
+
+    // ---- down path: x = template_conv(template); every leaky_relu_(x) of refinegan.py:305 is folded into its producer ----
+    int ch = m.cfg.start_channels;
+    r = ConvRun();
+    r.batch = B;
+    r.t_in = (int)down[0];
+    r.x = cur_template;
+    r.y = skip[0];
+    r.post_act = FV_ACT_LEAKY_RELU;
+    r.slope = slope;
+    if ((st = conv_layer_run(m.template_conv, r, s))) return st;
+    float* cat0 = P[5];   // cat([x, mel_conv(mel)]) : (2 * c_S, T)
+    int c_s = ch;
+    for (int i = 0; i < S; ++i) c_s *= 2;
+    for (int i = 0; i < S; ++i) {
+        const int rate = m.cfg.downsample_rates[i];
+        const float scale = (float)(1.0 / (1.0 / (double)rate));   // aten: static_cast<float>(1.0 / scale_factor)
+        FV_PROF(s, "linear_interp", 3.0 * B * ch * down[i + 1], 4.0 * B * ch * (down[i] + down[i + 1]),
+                launch_leaky_interp(skip[i], P[0], B, ch, (int)down[i], (int)down[i + 1], scale, 0, slope, ch, 0, s));
+        float* out = i + 1 < S ? skip[i + 1] : P[3];
+        if ((st = resblock(*m.downs[i], P[0], out, P[1], P[2], (int)down[i + 1], /*post_leaky=*/true))) return st;
+        ch *= 2;
+    }
+    FV_PROF(s, "copy_channels", 0.0, 8.0 * B * c_s * T, launch_copy_channels(P[3], cat0, B, c_s, T, 2 * c_s, 0, s));
+    r = ConvRun();
+    r.batch = B;
+    r.t_in = T;
+    r.x = d_mel;
+    r.y = P[4];
+    r.post_act = FV_ACT_LEAKY_RELU;   // the concatenated tensor is activated in place at the top of the up loop
+    r.slope = slope;
+    if ((st = conv_layer_run(m.mel_conv, r, s))) return st;
+    FV_PROF(s, "copy_channels", 0.0, 8.0 * B * c_s * T, launch_copy_channels(P[4], cat0, B, c_s, T, 2 * c_s, c_s, s));
+
+    // ---- up path ----
+    const float* xcur = cat0;
+    const float* noise = cur_noise;
+    for (int i = 0; i < S; ++i) {
+        const RefineUp& u = *m.ups[i];
+        const int t = (int)up[i + 1];
+        float* CAT = P[0];
+        float* XI = P[1];
+        float* XA = P[2];
+        float* XT = P[3];
+        float* XB = P[4];
+        float* Y = (xcur == P[5]) ? P[6] : P[5];
+        const float scale = (float)(1.0 / (double)u.rate);
+        // x = leaky_relu_(x) (already applied by the producers for i == 0), upsample, cat with the skip
+        FV_PROF(s, "linear_interp", 3.0 * B * u.cin * t, 4.0 * B * u.cin * (up[i] + t),
+                launch_leaky_interp(xcur, CAT, B, u.cin, (int)up[i], t, scale, i > 0, slope, u.cin + u.cskip, 0, s));
+        FV_PROF(s, "copy_channels", 0.0, 8.0 * B * u.cskip * t,
+                launch_copy_channels(skip[S - 1 - i], CAT, B, u.cskip, t, u.cin + u.cskip, u.cin, s));
+        r = ConvRun();
+        r.batch = B;
+        r.t_in = t;
+        r.x = CAT;
+        r.y = XI;
+        if ((st = conv_layer_run(u.input_conv, r, s))) return st;
+        const size_t nelem = (size_t)B * u.cout * t;
+        for (int j = 0; j < 3; ++j) {
+            FV_PROF(s, "adain", 3.0 * nelem, 12.0 * nelem, launch_adain(XI, noise, u.d_w1[j], XA, B, u.cout, t, slope, 0, 1.0f, s));
+            noise += nelem;
+            if ((st = resblock(u.rb[j], XA, CAT, XT, XB, t, /*post_leaky=*/false))) return st;   // CAT is free again: branch output
+            FV_PROF(s, "adain", 4.0 * nelem, 16.0 * nelem,
+                    launch_adain(CAT, noise, u.d_w2[j], Y, B, u.cout, t, slope, j > 0, j == 2 ? 1.0f / 3.0f : 1.0f, s));
+            noise += nelem;
+        }
+        xcur = Y;
+    }
+    // leaky_relu -> output_conv -> tanh (refinegan.py:319-321)
+    const int L = (int)up[S];
+    FV_PROF(s, "conv_post_narrow", 2.0 * B * m.out_cin * 7 * L, 4.0 * B * (m.out_cin + 1) * L,
+            launch_conv_narrow(xcur, m.d_wout, m.d_bout, d_out, B, m.out_cin, L, 1, 7, 3, FV_ACT_LEAKY_RELU, FV_ACT_TANH, slope, s));
+    return FV_OK;
+}
+
 fv_status fv_engine::run_model(const float* d_in, float* d_out, int batch, int t_in, float* ws, hipStream_t s) {
     fv_engine* e = this;
     switch (e->cfg.model) {
@@ -1344,6 +1701,7 @@ fv_status fv_engine::run_model(const float* d_in, float* d_out, int batch, int t
                 return FV_ERR_INVALID;
             }
             return e->run_logmel(d_in, d_out, batch, t_in, ws, s);
+        case FV_MODEL_REFINEGAN: return e->run_refinegan(d_in, d_out, batch, t_in, ws, s);
         case FV_MODEL_VOCOS: {
             const size_t mid = align_up((size_t)e->cnx.out_dim() * t_in * batch, 64);
             fv_status st = e->run_convnext(d_in, ws, batch, t_in, ws + mid, s);

@@ -205,4 +205,13 @@ fv_status launch_istft_spec(const float* h, float* spec, int B, int n_fft, int T
 fv_status launch_istft_ola(const float* frames, const float* inv_env, float* y, int B, int n_fft, int T, int hop, int pad,
                            hipStream_t s);
 
+
+// RefineGAN glue (small_kernels.hip): linear interpolation (nn.Upsample(mode="linear")) with optional leaky_relu, written into
+// a channel slice of a wider tensor; channel-slice copy; AdaIN with caller-supplied noise
+fv_status launch_leaky_interp(const float* x, float* y, int B, int C, int Lin, int Lout, float scale, int leaky, float slope,
+                              int ctot, int coff, hipStream_t s);
+fv_status launch_copy_channels(const float* x, float* y, int B, int C, int T, int ctot, int coff, hipStream_t s);
+fv_status launch_adain(const float* x, const float* noise, const float* w, float* y, int B, int C, int T, float slope,
+                       int accumulate, float scale, hipStream_t s);
+
 }  // namespace fv

@@ -680,4 +680,75 @@ fv_status launch_magnitude(const float* spec, float* mag, int B, int nb, int T, 
     return FV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// RefineGAN glue (fish_vocoder/modules/generators/refinegan.py)
+// ---------------------------------------------------------------------------------------------
+// nn.Upsample(scale_factor, mode="linear") = aten upsample_linear1d, align_corners=False (refinegan.py:229,262):
+//   src = max(scale * (t + 0.5) - 0.5, 0) in fp32 (scale = float(1 / scale_factor)), i0 = floor(src), i1 = min(i0 + 1, Lin - 1),
+//   y = (1 - frac) * x[i0] + frac * x[i1];  optionally leaky_relu first (the in-place activation of refinegan.py:311).
+// The result lands in channels [coff, coff + C) of a (B, ctot, Lout) tensor: the torch.cat of refinegan.py:314 for free.
+__global__ __launch_bounds__(256) void leaky_interp_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int Lin,
+                                                           int Lout, float scale, int leaky, float slope, int ctot, int coff) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (t >= Lout) return;
+    // no FMA contraction: the reference rounds the product and the difference separately
+    float src = __fsub_rn(__fmul_rn(scale, (float)t + 0.5f), 0.5f);
+    src = src < 0.f ? 0.f : src;
+    int i0 = (int)src;
+    i0 = i0 > Lin - 1 ? Lin - 1 : i0;
+    const int i1 = i0 + 1 > Lin - 1 ? Lin - 1 : i0 + 1;
+    const float w1 = src - (float)i0, w0 = 1.0f - w1;
+    const float* xr = x + ((long long)b * C + c) * Lin;
+    float a0 = xr[i0], a1 = xr[i1];
+    if (leaky) {
+        a0 = a0 >= 0.f ? a0 : a0 * slope;
+        a1 = a1 >= 0.f ? a1 : a1 * slope;
+    }
+    y[((long long)b * ctot + coff + c) * Lout + t] = __fadd_rn(__fmul_rn(w0, a0), __fmul_rn(w1, a1));
+}
+
+fv_status launch_leaky_interp(const float* x, float* y, int B, int C, int Lin, int Lout, float scale, int leaky, float slope,
+                              int ctot, int coff, hipStream_t s) {
+    hipLaunchKernelGGL(leaky_interp_kernel, dim3((Lout + 255) / 256, C, B), dim3(256), 0, s, x, y, C, Lin, Lout, scale, leaky,
+                       slope, ctot, coff);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
+// y[b][coff + c][t] = x[b][c][t]  (the skip half of torch.cat([x, down], dim=1), refinegan.py:314)
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T,
+                                                            int ctot, int coff) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (t < T) y[((long long)b * ctot + coff + c) * T + t] = x[((long long)b * C + c) * T + t];
+}
+
+fv_status launch_copy_channels(const float* x, float* y, int B, int C, int T, int ctot, int coff, hipStream_t s) {
+    hipLaunchKernelGGL(copy_channels_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, s, x, y, C, T, ctot, coff);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
+// AdaIN (refinegan.py:112-127): v = leaky_relu(x + noise * weight[c]);  y = v, or the running branch mean (y + v) * scale.
+// `noise` stands in for torch.randn_like: the caller supplies standard-normal samples.
+__global__ __launch_bounds__(256) void adain_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                    const float* __restrict__ w, float* __restrict__ y, int C, int T, float slope,
+                                                    int accumulate, float scale) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const long long i = ((long long)b * C + c) * T + t;
+    float v = __fadd_rn(x[i], __fmul_rn(noise[i], w[c]));
+    v = v >= 0.f ? v : v * slope;
+    y[i] = accumulate ? (y[i] + v) * scale : v;
+}
+
+fv_status launch_adain(const float* x, const float* noise, const float* w, float* y, int B, int C, int T, float slope,
+                       int accumulate, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(adain_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, s, x, noise, w, y, C, T, slope, accumulate, scale);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
 }  // namespace fv

@@ -84,10 +84,27 @@ def logmel_config(*, sample_rate=44100, n_fft=2048, win_length=2048, hop_length=
     return c
 
 
+def refinegan_config(*, hop_length=256, downsample_rates=(2, 2, 8, 8), upsample_rates=(8, 8, 2, 2), leaky_relu_slope=0.2,
+                     num_mels=128, start_channels=16, sampling_rate=44100, **_ignored) -> _lib.RefineGANConfig:
+    """RefineGANGenerator ctor kwargs (reference refinegan.py:183-193) -> fv_refinegan_config."""
+    if len(downsample_rates) != len(upsample_rates) or not 1 <= len(upsample_rates) <= _lib.FV_MAX_STAGES:
+        raise ValueError("downsample_rates and upsample_rates must have the same length (1..8)")
+    c = _lib.RefineGANConfig()
+    c.hop_length = int(hop_length)
+    c.num_stages = len(upsample_rates)
+    for i, (d, u) in enumerate(zip(downsample_rates, upsample_rates)):
+        c.downsample_rates[i] = int(d)
+        c.upsample_rates[i] = int(u)
+    c.num_mels = int(num_mels)
+    c.start_channels = int(start_channels)
+    c.leaky_relu_slope = float(leaky_relu_slope)
+    return c
+
+
 class Engine:
     """Owns one ``fv_engine`` on the current device.  ``state_dict`` uses the reference's key names."""
 
-    def __init__(self, model_kind: int, *, ups=None, backbone=None, head=None, mel=None,
+    def __init__(self, model_kind: int, *, ups=None, backbone=None, head=None, mel=None, refine=None,
                  state_dict: Mapping[str, "np.ndarray | torch.Tensor"], device=None, precision: str = "f32"):
         """``precision``: "f32" (exact-fp32 MFMA, the reference's arithmetic; default) or "f16x3" (opt-in split-fp16
         MFMA for the MFMA-bound convs, fp32-class accuracy, see include/fishvoc.h ``fv_precision``)."""
@@ -111,6 +128,8 @@ class Engine:
             cfg.head = head
         if mel is not None:
             cfg.mel = mel
+        if refine is not None:
+            cfg.refine = refine
         with torch.cuda.device(self.device):
             check(self._lib.fv_create(ctypes.byref(cfg), ctypes.byref(self._h)))
             try:
@@ -147,7 +166,14 @@ class Engine:
     def workspace_bytes(self, batch: int, t_in: int) -> int:
         return int(self._lib.fv_workspace_bytes(self._h, int(batch), int(t_in)))
 
-    def forward(self, x: torch.Tensor, out: torch.Tensor | None = None, template: torch.Tensor | None = None) -> torch.Tensor:
+    def noise_elems(self, batch: int, t_in: int) -> int:
+        """RefineGAN only: number of standard-normal samples one forward consumes (fv_refinegan_noise_elems)."""
+        return int(self._lib.fv_refinegan_noise_elems(self._h, int(batch), int(t_in)))
+
+    def forward(self, x: torch.Tensor, out: torch.Tensor | None = None, template: torch.Tensor | None = None,
+                noise: torch.Tensor | None = None) -> torch.Tensor:
+        """``noise`` (RefineGAN engines only): flat fp32 tensor of ``noise_elems(B, T)`` standard-normal samples standing in
+        for AdaIN's torch.randn_like draws (reference refinegan.py:125), in order of use."""
         _require_cuda(x, "Engine.forward")
         if x.dim() != 3 or x.shape[1] != self.in_channels:
             raise ValueError(f"expected input of shape (B, {self.in_channels}, T), got {tuple(x.shape)}")
@@ -165,6 +191,13 @@ class Engine:
             if tuple(template.shape) != (B, 1, L):
                 raise ValueError(f"expected template of shape {(B, 1, L)}, got {tuple(template.shape)}")
             tptr = template.data_ptr()
+        nptr = None
+        if noise is not None:
+            _require_cuda(noise, "Engine.forward noise")
+            noise = noise.contiguous()
+            if noise.dtype != torch.float32 or noise.numel() != self.noise_elems(B, T):
+                raise ValueError(f"expected {self.noise_elems(B, T)} fp32 noise samples, got {noise.numel()} ({noise.dtype})")
+            nptr = noise.data_ptr()
         need = self.workspace_bytes(B, T)
         if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != x.device:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
@@ -177,16 +210,21 @@ class Engine:
                     self._side = torch.cuda.Stream(x.device)
                 side = self._side
                 side.wait_stream(cur)
-                check(self._lib.fv_forward_template(self._h, x.data_ptr(), tptr, out.data_ptr(), B, T, self._ws.data_ptr(),
-                                                    self._ws.numel() * 4, int(side.cuda_stream)))
+                check(self._launch(x, tptr, nptr, out, B, T, int(side.cuda_stream)))
                 cur.wait_stream(side)
             else:
-                check(self._lib.fv_forward_template(self._h, x.data_ptr(), tptr, out.data_ptr(), B, T, self._ws.data_ptr(),
-                                                    self._ws.numel() * 4, int(cur.cuda_stream)))
+                check(self._launch(x, tptr, nptr, out, B, T, int(cur.cuda_stream)))
         return out
 
-    def __call__(self, x, out=None, template=None):
-        return self.forward(x, out, template)
+    def _launch(self, x, tptr, nptr, out, B, T, stream: int) -> int:
+        if nptr is not None:
+            return self._lib.fv_forward_refinegan(self._h, x.data_ptr(), tptr, nptr, out.data_ptr(), B, T, self._ws.data_ptr(),
+                                                  self._ws.numel() * 4, stream)
+        return self._lib.fv_forward_template(self._h, x.data_ptr(), tptr, out.data_ptr(), B, T, self._ws.data_ptr(),
+                                             self._ws.numel() * 4, stream)
+
+    def __call__(self, x, out=None, template=None, noise=None):
+        return self.forward(x, out, template, noise)
 
     def profile(self, x: torch.Tensor, repeats: int = 3) -> list[dict]:
         """Per-kernel hipEvent timings of `repeats` forwards (fv_profile_begin/end): a list of

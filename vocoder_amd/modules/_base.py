@@ -57,7 +57,7 @@ class EngineModule(nn.Module):
             object.__setattr__(self, "_engine", eng)
         return eng
 
-    def _run(self, x: torch.Tensor, template: torch.Tensor | None = None) -> torch.Tensor:
+    def _run(self, x: torch.Tensor, template: torch.Tensor | None = None, noise: torch.Tensor | None = None) -> torch.Tensor:
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
             raise RuntimeError(
                 f"{type(self).__name__}.forward needs a CUDA/HIP tensor (got "
@@ -67,7 +67,9 @@ class EngineModule(nn.Module):
         with torch.no_grad():
             if template is not None:
                 template = template.to(device=x.device, dtype=torch.float32)
-            return self.engine(x.device)(x.to(torch.float32), None, template)
+            if noise is not None:
+                noise = noise.to(device=x.device, dtype=torch.float32).reshape(-1)
+            return self.engine(x.device)(x.to(torch.float32), None, template, noise)
 
     def remove_parametrizations(self):
         """Kept for API compatibility (hifigan.py:251).  Weight-norm is folded inside the engine at load time, so this

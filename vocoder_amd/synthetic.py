@@ -197,3 +197,71 @@ VOCOS_24K = dict(
     backbone=dict(input_channels=80, depths=[3, 3, 27, 3], dims=[128, 256, 512, 1024],
                   drop_path_rate=0.4, kernel_size=7),
     head=dict(dim=1024, n_fft=1024, hop_length=256, win_length=1024, padding="same"))
+
+
+# RefineGANGenerator (/root/reference/fish_vocoder/modules/generators/refinegan.py:182-323) — no YAML in the reference; these
+# are its ctor defaults
+REFINEGAN_44K = dict(sampling_rate=44100, hop_length=256, downsample_rates=(2, 2, 8, 8), upsample_rates=(8, 8, 2, 2),
+                     leaky_relu_slope=0.2, num_mels=128, start_channels=16)
+
+
+def refinegan_stage_shapes(cfg: dict, frames: int):
+    """[(C, T)] of the AdaIN noise tensors: for every up-sampling stage, C = that stage's output channels and T = its length;
+    each stage consumes 3 branches x 2 AdaIN layers of them, in (stage, branch, layer) order."""
+    ch = cfg["start_channels"] * 2 ** len(cfg["downsample_rates"]) * 2
+    t = frames
+    out = []
+    for r in cfg["upsample_rates"]:
+        ch //= 2
+        t *= r
+        out.append((ch, t))
+    return out
+
+
+def refinegan_noise(cfg: dict, batch: int, frames: int, seed: int = 0) -> list:
+    """Standard-normal tensors standing in for AdaIN's torch.randn_like (refinegan.py:125), in order of use."""
+    rng = np.random.default_rng(seed)
+    return [rng.normal(size=(batch, c, t)).astype(np.float32)
+            for (c, t) in refinegan_stage_shapes(cfg, frames) for _ in range(6)]
+
+
+def refinegan_state_dict(cfg: dict, seed: int = 0) -> dict:
+    """State dict of RefineGANGenerator(**cfg), reference key order (refinegan.py:203-286)."""
+    rng = np.random.default_rng(seed)
+    sd: dict = {}
+    ch = cfg["start_channels"]
+    _put_wn(sd, "template_conv", rng, (ch, 1, 7), 7, 1.0, ch)
+
+    def resblock(prefix, cin, cout, k):
+        for n in range(3):
+            _put_wn(sd, f"{prefix}.convs1.{n}", rng, (cout, cin if n == 0 else cout, k), (cin if n == 0 else cout) * k, 1.3, cout)
+        for n in range(3):
+            _put_wn(sd, f"{prefix}.convs2.{n}", rng, (cout, cout, k), cout * k, 0.7, cout)
+
+    for i, _ in enumerate(cfg["downsample_rates"]):
+        resblock(f"downsample_blocks.{i}.1", ch, ch * 2, 7)
+        ch *= 2
+    _put_wn(sd, "mel_conv", rng, (ch, cfg["num_mels"], 7), cfg["num_mels"] * 7, 0.35, ch)
+    ch *= 2
+    for i, _ in enumerate(cfg["upsample_rates"]):
+        cin, cout = ch + ch // 4, ch // 2
+        p = f"upsample_conv_blocks.{i}"
+        sd[f"{p}.input_conv.weight"] = rng.normal(0.0, 1.0 / sqrt(cin * 7), size=(cout, cin, 7)).astype(np.float32)
+        sd[f"{p}.input_conv.bias"] = rng.normal(0.0, 0.05, size=cout).astype(np.float32)
+        for j, k in enumerate((3, 7, 11)):
+            sd[f"{p}.blocks.{j}.0.weight"] = rng.uniform(0.05, 0.3, size=cout).astype(np.float32)
+            resblock(f"{p}.blocks.{j}.1", cout, cout, k)
+            sd[f"{p}.blocks.{j}.2.weight"] = rng.uniform(0.05, 0.3, size=cout).astype(np.float32)
+        ch = cout
+    _put_wn(sd, "output_conv", rng, (1, ch, 7), ch * 7, 0.25, 1)
+    return sd
+
+
+def synthetic_template(batch: int, frames: int, hop: int, seed: int = 7) -> np.ndarray:
+    """A pitch-template-like signal (B, 1, frames * hop): a few harmonics of a slowly varying f0 plus a little noise."""
+    rng = np.random.default_rng(seed)
+    n = frames * hop
+    t = np.arange(n)[None, :]
+    f0 = rng.uniform(0.004, 0.02, size=(batch, 1))
+    x = sum(np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6.28, size=(batch, 1))) / h for h in (1, 2, 3))
+    return (0.3 * x + 0.02 * rng.normal(size=(batch, n)))[:, None, :].astype(np.float32)
