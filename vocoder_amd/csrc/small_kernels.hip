@@ -119,74 +119,93 @@ __device__ __forceinline__ float sin_squared(float z) {
     return sn * sn;
 }
 
-__global__ __launch_bounds__(256) void aa_snake_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                       const float* __restrict__ alpha_eff,
-                                                       const float* __restrict__ inv_beta,
-                                                       const float* __restrict__ up_taps,
-                                                       const float* __restrict__ down_taps, int C, int T, int n_tiles) {
-    // xs[m] = x[clamp(t0 - 6 + m)];  AE[m] / AO[m] = activated even / odd up-sampled sample of input position
-    // h = t0 - 3 + m (de-interleaved so that phase 3 reads consecutive addresses: no bank conflicts, no lane divergence)
+// Packed math: gfx950 issues a wave64 v_fma_f32 in ~4.4 cycles and a v_pk_fma_f32 (twice the work) in ~4.9
+// (tools/ubench/valu_rates.hip), and this kernel spends ~80 VALU instructions per element when written with scalar FMAs.
+// Both phases are arranged so that every FIR step is one packed FMA on a register PAIR that one ds_read2_b32 delivers:
+//   phase 2: (ue, uo)(h) += (up[2q+1], up[2q]) * (x[h+2-q], x[h+3-q])       -- consecutive inputs, taps as an SGPR pair
+//            snake on the pair, stored interleaved: A[2m] = even, A[2m+1] = odd sample of position h = t0 - 3 + m
+//   phase 3: (s0, s1) += (dn[2q], dn[2q+1]) * (A_odd(t+q-3), A_even(t+q-2))   -- A[2m'+1], A[2m'+2]: consecutive again
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 sin_squared2(f32x2 z) {
+    f32x2 k;
+    k.x = rintf(z.x * 0.318309886183790672f);
+    k.y = rintf(z.y * 0.318309886183790672f);
+    f32x2 r = __builtin_elementwise_fma(k, (f32x2)(-3.140625f), z);
+    r = __builtin_elementwise_fma(k, (f32x2)(-9.67502593994140625e-4f), r);
+    r = __builtin_elementwise_fma(k, (f32x2)(-1.509957990978376432e-7f), r);
+    const f32x2 r2 = r * r;
+    f32x2 p = __builtin_elementwise_fma(r2, (f32x2)(-2.50521083854417188e-8f), (f32x2)(2.75573192239858925e-6f));
+    p = __builtin_elementwise_fma(r2, p, (f32x2)(-1.98412698412698413e-4f));
+    p = __builtin_elementwise_fma(r2, p, (f32x2)(8.33333333333333322e-3f));
+    p = __builtin_elementwise_fma(r2, p, (f32x2)(-1.66666666666666657e-1f));
+    const f32x2 sn = __builtin_elementwise_fma(r * r2, p, r);
+    return sn * sn;
+}
+
+__global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const float* __restrict__ alpha_eff,
+                                                          const float* __restrict__ inv_beta,
+                                                          const float* __restrict__ up_taps,
+                                                          const float* __restrict__ down_taps, int C, int T, int n_tiles) {
     __shared__ float xs[AA_TT + 16];
-    __shared__ float AE[AA_TT + 8];
-    __shared__ float AO[AA_TT + 8];
-    __shared__ float tp[24];
+    __shared__ __attribute__((aligned(8))) float A[2 * (AA_TT + 8)];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x % n_tiles;
     const long long row = blockIdx.x / n_tiles;  // b * C + c
     const int c = (int)(row % C);
     const int t0 = tile * AA_TT;
     const float* xr = x + row * T;
-    if (tid < 12) tp[tid] = up_taps[tid];
-    else if (tid < 24) tp[tid] = down_taps[tid - 12];
     for (int e = tid; e < AA_TT + 13; e += 256) {
         int t = t0 - 6 + e;
         t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);   // replicate padding of the up-sampler input
         xs[e] = xr[t];
     }
-    __syncthreads();
+    // taps as uniform register pairs (the up-sampler's gain of 2 folded in)
+    f32x2 upp[6], dnp[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        upp[q] = f32x2{2.0f * up_taps[2 * q + 1], 2.0f * up_taps[2 * q]};
+        dnp[q] = f32x2{down_taps[2 * q], down_taps[2 * q + 1]};
+    }
     const float al = alpha_eff[c], ib = inv_beta[c];
-    // up-sample (polyphase: even output n = 2h uses odd taps at x[h+2 .. h-3], odd output uses even taps at x[h+3 .. h-2]),
-    // activate, for h = t0 - 3 .. t0 + AA_TT + 2
+    __syncthreads();
     for (int m = tid; m < AA_TT + 6; m += 256) {
         const int h = t0 - 3 + m;
         const int hc = h < 0 ? 0 : (h > T - 1 ? T - 1 : h);
         const int xi = hc - t0 + 6;   // position of x[hc] in xs
-        float ue = 0.f, uo = 0.f;
+        f32x2 u = {0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            ue = fmaf(tp[2 * q + 1], xs[xi + 2 - q], ue);
-            uo = fmaf(tp[2 * q], xs[xi + 3 - q], uo);
+            const f32x2 xp = {xs[xi + 2 - q], xs[xi + 3 - q]};
+            u = __builtin_elementwise_fma(upp[q], xp, u);
         }
-        ue *= 2.0f;
-        uo *= 2.0f;
-        float ae = fmaf(ib, sin_squared(ue * al), ue);
-        float ao = fmaf(ib, sin_squared(uo * al), uo);
+        f32x2 a = __builtin_elementwise_fma((f32x2)(ib), sin_squared2(u * al), u);
         // replicate padding of the down-sampler input: n < 0 -> a[0] (even sample of h = 0), n > 2T-1 -> a[2T-1]
-        if (h < 0) ao = ae;
-        if (h > T - 1) ae = ao;
-        AE[m] = ae;
-        AO[m] = ao;
+        if (h < 0) a.y = a.x;
+        if (h > T - 1) a.x = a.y;
+        *reinterpret_cast<f32x2*>(&A[2 * m]) = a;
     }
     __syncthreads();
-    // y[t0 + i] = sum_j down[j] * a[2(t0+i) + j - 5]:  j odd -> even sample of h = t0 + i + (j-5)/2,  j even -> odd sample
-    // of h = t0 + i + (j-6)/2
+    // y[t0 + i] = sum_q dn[2q] * odd(h = t0+i+q-3) + dn[2q+1] * even(h = t0+i+q-2);  position h -> m = h - (t0 - 3)
     for (int i = tid; i < AA_TT; i += 256) {
         const int t = t0 + i;
         if (t >= T) break;
-        float acc = 0.f;
+        f32x2 s2 = {0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            acc = fmaf(tp[12 + 2 * q + 1], AE[i + q + 1], acc);   // h - (t0-3) = i + q - 2 + 3
-            acc = fmaf(tp[12 + 2 * q], AO[i + q], acc);           // h - (t0-3) = i + q - 3 + 3
+            const int mo = i + q;   // odd sample of m = i + q, even sample of m + 1: A[2mo + 1], A[2mo + 2]
+            const f32x2 ap = {A[2 * mo + 1], A[2 * mo + 2]};
+            s2 = __builtin_elementwise_fma(dnp[q], ap, s2);
         }
-        y[row * T + t] = acc;
+        y[row * T + t] = s2.x + s2.y;
     }
 }
 
 fv_status launch_aa_snake(const float* x, float* y, const float* alpha_eff, const float* inv_beta, const float* up_taps,
                           const float* down_taps, int B, int C, int T, hipStream_t s) {
     const int n_tiles = (T + AA_TT - 1) / AA_TT;
-    hipLaunchKernelGGL(aa_snake_kernel, dim3((unsigned)((long long)B * C * n_tiles)), dim3(256), 0, s, x, y, alpha_eff,
+    hipLaunchKernelGGL(aa_snake_pk_kernel, dim3((unsigned)((long long)B * C * n_tiles)), dim3(256), 0, s, x, y, alpha_eff,
                        inv_beta, up_taps, down_taps, C, T, n_tiles);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
