@@ -105,20 +105,6 @@ constexpr int AA_TT = 1024;
 // sin(z)^2 with a three-constant Cody-Waite reduction to [-pi/2, pi/2] and an odd degree-11 polynomial: |error| < 2e-7 for
 // |z| < 1e3 (the snake argument alpha*u stays far below that).  libm's sinf costs ~4x more VALU work and made this
 // kernel compute- instead of bandwidth-bound.  The sign lost by the reduction does not matter for the square.
-__device__ __forceinline__ float sin_squared(float z) {
-    const float k = rintf(z * 0.318309886183790672f);
-    float r = fmaf(k, -3.140625f, z);                         // pi split in three short constants: k * c exact
-    r = fmaf(k, -9.67502593994140625e-4f, r);
-    r = fmaf(k, -1.509957990978376432e-7f, r);
-    const float r2 = r * r;
-    float p = fmaf(r2, -2.50521083854417188e-8f, 2.75573192239858925e-6f);
-    p = fmaf(r2, p, -1.98412698412698413e-4f);
-    p = fmaf(r2, p, 8.33333333333333322e-3f);
-    p = fmaf(r2, p, -1.66666666666666657e-1f);
-    const float sn = fmaf(r * r2, p, r);
-    return sn * sn;
-}
-
 // Packed math: gfx950 issues a wave64 v_fma_f32 in ~4.4 cycles and a v_pk_fma_f32 (twice the work) in ~4.9
 // (tools/ubench/valu_rates.hip), and this kernel spends ~80 VALU instructions per element when written with scalar FMAs.
 // Both phases are arranged so that every FIR step is one packed FMA on a register PAIR that one ds_read2_b32 delivers:
