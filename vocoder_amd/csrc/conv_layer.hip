@@ -9,7 +9,7 @@
 namespace fv {
 
 void tile_dims(int cfg, int* m_blk, int* n_blk) {
-    static const int dims[TILE_COUNT][2] = {{128, 128}, {64, 256}, {32, 512}, {128, 64}, {32, 128}, {64, 128}, {32, 64}};
+    static const int dims[TILE_COUNT][2] = {{128, 128}, {64, 256}, {32, 512}, {128, 64}, {32, 128}, {64, 128}, {32, 64}, {32, 32}};
     *m_blk = dims[cfg][0];
     *n_blk = dims[cfg][1];
 }
@@ -193,13 +193,17 @@ static int choose_tile(int M, long long N, int batch) {
     if (blocks_big < 512 || cols_small < cols_big) {
         // still fewer workgroups than CUs: 32 x 64 tiles with K split across the four waves (latency variant)
         const long long blocks_small = tiles_small * m_blks * batch;
-        if (blocks_small < 200) return TILE_SPLITK_32x64;
+        if (blocks_small < 200) {
+            // 32 x 64 tiles: 4x the workgroups of 128 x 64 / 2x those of 32 x 128; still under half the CUs -> 32 x 32
+            const long long blocks_sk = ((M + 31) / 32) * ((N + 63) / 64) * batch;
+            return blocks_sk < 128 ? TILE_SPLITK_32x32 : TILE_SPLITK_32x64;
+        }
         return small;
     }
     return big;
 }
 
-static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64"};
+static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64", "splitK32x32"};
 
 static const char* const kSplitNames[SPLIT_COUNT] = {"128x128", "64x256"};
 
@@ -313,7 +317,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     if (!L.transposed && L.ks == 1 && L.pad_l == 0 && r.batch > 1 &&
         (long long)r.batch * std::max<long long>((long long)L.c_in * r.t_in, (long long)L.c_out * tout) < (1LL << 30)) {
         const int cfg_flat = choose_tile(L.M, (long long)p.N * r.batch, 1);
-        if (cfg_flat != TILE_SPLITK_32x64) {
+        if (cfg_flat < TILE_SPLITK_32x64) {
             cfg = cfg_flat;
             p.flat = 1;
             p.n_total = p.N * r.batch;

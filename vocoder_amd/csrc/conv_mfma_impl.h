@@ -381,19 +381,22 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 }
 
 // Latency variant for launches that cannot fill the chip with regular tiles (small batch x short T): the workgroup
-// owns a 32 x 64 output tile and its four waves split K between them — wave w takes channel pair w of every
-// 8-channel chunk (k-steps stay whole, the staged window and the B-fragment reads are shared, each wave fetches only
+// owns a 32 x 64 (or 32 x 32) output tile and its four waves split K between them — wave w takes channel pair w of every
+// 8-channel chunk (an eight-wave version over 16-channel chunks spilled and measured slower) (k-steps stay whole, the staged window and the B-fragment reads are shared, each wave fetches only
 // its own dword of the packed weights).  Partial accumulators are reduced through LDS and wave 0 runs the epilogue.
 // 16x more workgroups than the 128 x 128 tile for the same problem.
-template <int KS, int DIL>
-__global__ __launch_bounds__(256, 4) void conv_mfma_splitk_kernel(const ConvParams p) {
-    constexpr int NT = 2, N_BLK = 64;
+template <int KS, int DIL, int NT, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void conv_mfma_splitk_kernel(const ConvParams p) {
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves split K");
+    constexpr int THREADS = NW * 64;
+    constexpr int CHW = 2 * NW;              // channels per LDS chunk: one channel pair (= one MFMA k-step per tap) per wave
+    constexpr int N_BLK = NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
     constexpr int W = N_BLK + SPAN;
-    constexpr int TOT = kChunk * W;
-    constexpr int NE = (TOT + 255) / 256;
+    constexpr int TOT = CHW * W;
+    constexpr int NE = (TOT + THREADS - 1) / THREADS;
     __shared__ float xs[2][TOT];
-    __shared__ float red[3][32][64];   // [wave-1][acc register][lane]
+    __shared__ float red[NW - 1][NT * 16][64];   // [wave-1][acc register][lane]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_splitk_kernel(const ConvPara
     const int tbase = n0 - p.pad_l;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        int e = tid + i * 256;
+        int e = tid + i * THREADS;
         const bool in_tile = e < TOT;
         e = in_tile ? e : TOT - 1;
         const int r = e / W;
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_splitk_kernel(const ConvPara
     }
     float stage[NE];
     auto load_chunk = [&](int c) {
-        const int cbase = c * kChunk;
+        const int cbase = c * CHW;
         const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)((p.Cin - cbase) * p.Tin) * 4u);
 #pragma unroll
         for (int i = 0; i < NE; ++i) stage[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_voff[i], 0, 0));
@@ -436,17 +439,18 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_splitk_kernel(const ConvPara
     auto store_chunk = [&](float* dst) {
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * THREADS;
             if (e < TOT) dst[e] = act_apply(stage[i], p.pre_act, p.slope);
         }
     };
 
-    // this wave's dword of the packed float4 (channel pair `wave`), by raw buffer loads (SGPR base + constant VGPR part)
+    // this wave's dword of the packed float4s: 8-channel sub-chunk (wave >> 2) of the LDS chunk, channel pair (wave & 3), by
+    // raw buffer loads (SGPR base + constant VGPR part).  The packed buffer is zero-padded to whole groups of four sub-chunks.
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
-    const int wvoff = lane * 16 + wave * 4;
+    const int wvoff = lane * 16 + (wave & 3) * 4;
     const int wtile_b = __builtin_amdgcn_readfirstlane(m_blk * p.nchunk * KS * 1024);
     auto load_a = [&](int c, int j) {
-        const int soff = __builtin_amdgcn_readfirstlane(wtile_b + (c * KS + j) * 1024);
+        const int soff = __builtin_amdgcn_readfirstlane(wtile_b + ((c * (NW / 4) + (wave >> 2)) * KS + j) * 1024);
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, wvoff, soff, 0));
     };
     const int b_lane = (2 * wave + (lane >> 5)) * W + (lane & 31);
@@ -459,14 +463,15 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_splitk_kernel(const ConvPara
     // prefetch distance would be far shorter than the L2 latency
     float a_cur[KS], a_nxt[KS];
     float b_cur[NT], b_nxt[NT];
+    const int nchunks = (p.Cin + CHW - 1) / CHW;
     load_chunk(0);
 #pragma unroll
     for (int j = 0; j < KS; ++j) a_cur[j] = load_a(0, j);
-    for (int c = 0; c < p.nchunk_real; ++c) {
+    for (int c = 0; c < nchunks; ++c) {
         float* xsb = xs[c & 1];
         store_chunk(xsb);
         __syncthreads();
-        const bool more = c + 1 < p.nchunk_real;
+        const bool more = c + 1 < nchunks;
         if (more) load_chunk(c + 1);
         const int cn = more ? c + 1 : c;
 #pragma unroll
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_splitk_kernel(const ConvPara
         for (int j = 0; j < KS; ++j) a_cur[j] = a_nxt[j];
     }
 
-    // reduce the four partial tiles
+    // reduce the partial tiles
     if (wave > 0) {
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn)
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_splitk_kernel(const ConvPara
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int w = 0; w < 3; ++w)
+        for (int w = 0; w < NW - 1; ++w)
 #pragma unroll
             for (int jn = 0; jn < NT; ++jn)
 #pragma unroll
@@ -525,7 +530,10 @@ inline bool launch_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
         case TILE_32x128: launch_one<KS, DIL, 1, 4, 1, 1>(p, batch, s); return true;
         case TILE_64x128: launch_one<KS, DIL, 1, 4, 2, 1>(p, batch, s); return true;
         case TILE_SPLITK_32x64:
-            hipLaunchKernelGGL((conv_mfma_splitk_kernel<KS, DIL>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((conv_mfma_splitk_kernel<KS, DIL, 2, 4>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
+            return true;
+        case TILE_SPLITK_32x32:
+            hipLaunchKernelGGL((conv_mfma_splitk_kernel<KS, DIL, 1, 4>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
             return true;
         default: return false;
     }
