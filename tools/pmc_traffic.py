@@ -13,9 +13,13 @@ def key_of(kernel_name: str, grid_threads: int):
     if m:
         ks, dil, wm, wn, mt, nt = map(int, m.groups())
         return f"conv_mfma k={ks} d={dil} tile={wm * mt * 32}x{wn * nt * 32} grid={blocks}"
-    m = re.search(r"conv_mfma_splitk_kernel<(\d+), (\d+)>", kernel_name)
+    m = re.search(r"conv_mfma_splitk_kernel<(\d+), (\d+), (\d+), (\d+)>", kernel_name)
     if m:
-        return f"conv_mfma k={m.group(1)} d={m.group(2)} tile=splitK32x64 grid={blocks}"
+        return f"conv_mfma k={m.group(1)} d={m.group(2)} tile=splitK32x{32 * int(m.group(3))} grid={blocks}"
+    m = re.search(r"conv_f16x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", kernel_name)
+    if m:
+        ks, dil, wm, wn, nt = map(int, m.groups())
+        return f"conv_f16x3 k={ks} d={dil} tile={wm * 32}x{wn * nt * 32} grid={blocks}"
     m = re.search(r"resblock_pair16_kernel<(\d+), (\d+)>", kernel_name)
     if m:
         return f"resblock_pair k={m.group(1)} d={m.group(2)} C=16 grid={blocks}"
@@ -30,6 +34,9 @@ def bench_key(label: str):
     m = re.search(r"conv_mfma<\w+ k=(\d+) d=(\d+) tile=(\w+)>.*grid=(\d+)", label)
     if m:
         return f"conv_mfma k={m.group(1)} d={m.group(2)} tile={m.group(3)} grid={m.group(4)}"
+    m = re.search(r"conv_f16x3<k=(\d+) d=(\d+) tile=(\w+)>.*grid=(\d+)", label)
+    if m:
+        return f"conv_f16x3 k={m.group(1)} d={m.group(2)} tile={m.group(3)} grid={m.group(4)}"
     m = re.search(r"resblock_pair<k=(\d+) d=(\d+) C=(\d+)> grid=(\d+)", label)
     if m:
         return f"resblock_pair k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={m.group(4)}"
@@ -57,5 +64,9 @@ if __name__ == "__main__":
         w = sum(write.get(k, [0.0])) / max(len(write.get(k, [])), 1) * 1024.0
         res[k] = {"hbm_bytes_per_launch": f + w, "read_bytes": f, "write_bytes": w, "launches_sampled": len(v)}
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(__file__), "..", "profiles", "traffic.json")
+    if os.path.exists(out) and "--merge" in sys.argv:   # add to an existing table (e.g. the f16x3 kernels to the fp32 ones)
+        old = json.load(open(out))
+        old.update(res)
+        res = old
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(f"{len(res)} kernels -> {out}")
