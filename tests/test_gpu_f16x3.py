@@ -165,3 +165,27 @@ def test_f16x3_vocos_and_convnext_match_oracle():
     assert np.abs(y - ref).max() <= 1e-4, np.abs(y - ref).max()
     prof = eng.profile(x)
     assert any(r["kernel"].startswith("conv_f16x3<k=1") for r in prof), [r["kernel"] for r in prof][:8]
+
+
+def test_f16x3_bigvgan_and_refinegan_goldens():
+    """The other generator families in f16x3 mode against the reference captures: BigVGAN (split kernels for the AMPBlock convs,
+    which see no pre-activation) and RefineGAN (leaky-ReLU pre-activations are not implemented by the split kernels, so those
+    layers must quietly stay on the fp32 kernels)."""
+    from conftest import load_golden
+    from vocoder_amd import _lib, synthetic as syn
+    from vocoder_amd.engine import Engine, refinegan_config, upsampler_config
+    dev = _dev()
+    g = load_golden("bigvgan_tiny.npz")
+    sd = syn.bigvgan_state_dict(g["cfg"], g["seed"])
+    eng = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**g["cfg"]), state_dict=sd, precision="f16x3")
+    y = eng(torch.from_numpy(g["mel"]).to(dev)).cpu().numpy()
+    assert np.abs(y - g["out"]).max() <= 1e-4, np.abs(y - g["out"]).max()
+    g = load_golden("refinegan_tiny.npz")
+    cfg = g["cfg"]
+    sd = syn.refinegan_state_dict(cfg, g["seed"])
+    B, _, T = g["mel"].shape
+    noise = np.concatenate([n.reshape(-1) for n in syn.refinegan_noise(cfg, B, T, seed=int(g["noise_seed"]))])
+    eng = Engine(_lib.FV_MODEL_REFINEGAN, refine=refinegan_config(**cfg), state_dict=sd, precision="f16x3")
+    y = eng(torch.from_numpy(g["mel"]).to(dev), None, torch.from_numpy(g["template"]).to(dev),
+            torch.from_numpy(noise).to(dev)).cpu().numpy()
+    assert np.abs(y - g["out"]).max() <= 1e-4, np.abs(y - g["out"]).max()
