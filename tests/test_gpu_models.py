@@ -285,3 +285,38 @@ def test_refinegan_default_config_vs_oracle():
     assert np.abs(y - ref).max() <= TOL, np.abs(y - ref).max()
     with pytest.raises(Exception):
         eng(torch.from_numpy(mel).to(dev))   # template + noise are mandatory
+
+
+@pytest.mark.parametrize("dims,T,B", [([24, 100], 3, 2), ([72, 200, 520], 33, 1), ([130], 1, 3)])
+def test_convnext_odd_widths_and_short_clips_vs_oracle(dims, T, B):
+    """Channel counts that are not multiples of the 64-row LDS chunks of the tiled dwconv+LN kernel, clips shorter than its
+    32-column tile (and than the 7-tap halo)."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, convnext_config
+    cfg = dict(input_channels=11, depths=[1] * len(dims), dims=dims, kernel_size=7)
+    sd = syn.convnext_state_dict(cfg, seed=21)
+    x = syn.synthetic_mel(B, 11, T, seed=4)
+    ref = orc.convnext_forward(sd, cfg, x)
+    eng = Engine(_lib.FV_MODEL_CONVNEXT, backbone=convnext_config(**cfg), state_dict=sd)
+    y = _fwd(eng, x)
+    err = np.abs(y - ref).max()
+    assert err <= 2e-5 * max(np.abs(ref).max(), 1.0), f"max|d| = {err:.3e}"
+
+
+def test_refinegan_single_frame_and_rejected_lengths():
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, refinegan_config
+    cfg = dict(sampling_rate=16000, hop_length=16, downsample_rates=(2, 2, 2, 2), upsample_rates=(2, 2, 2, 2),
+               leaky_relu_slope=0.2, num_mels=12, start_channels=4)
+    sd = syn.refinegan_state_dict(cfg, seed=2)
+    eng = Engine(_lib.FV_MODEL_REFINEGAN, refine=refinegan_config(**cfg), state_dict=sd)
+    dev = _dev()
+    mel = syn.synthetic_mel(1, 12, 1, seed=1)
+    tmpl = syn.synthetic_template(1, 1, 16, seed=2)
+    noise = syn.refinegan_noise(cfg, 1, 1, seed=3)
+    ref = orc.refinegan_forward(sd, cfg, mel, tmpl, noise)
+    y = eng(torch.from_numpy(mel).to(dev), None, torch.from_numpy(tmpl).to(dev),
+            torch.from_numpy(np.concatenate([n.reshape(-1) for n in noise])).to(dev)).cpu().numpy()
+    assert np.abs(y - ref).max() <= TOL
+    with pytest.raises(ValueError):   # wrong noise length
+        eng(torch.from_numpy(mel).to(dev), None, torch.from_numpy(tmpl).to(dev), torch.zeros(5, device=dev))
