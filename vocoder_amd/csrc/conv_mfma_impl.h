@@ -389,7 +389,10 @@ template <int KS, int DIL, int NT, int NW>
 __global__ __launch_bounds__(NW * 64, 4) void conv_mfma_splitk_kernel(const ConvParams p) {
     static_assert(NW == 4 || NW == 8, "4 or 8 waves split K");
     constexpr int THREADS = NW * 64;
-    constexpr int CHW = 2 * NW;              // channels per LDS chunk: one channel pair (= one MFMA k-step per tap) per wave
+    // 8-channel sub-chunks per LDS chunk (= per barrier): short kernels stage more channels at a time, otherwise a chunk is
+    // only KS * NT MFMAs per wave against a write -> barrier -> read round trip through LDS
+    constexpr int SUBK = KS <= 2 ? 4 : ((KS <= 4 || NT == 1) ? 2 : 1);   // (two sub-chunks spill the 32 x 64 tile at KS >= 7)
+    constexpr int CHW = 2 * NW * SUBK;       // channels per LDS chunk: one channel pair (= one MFMA k-step per tap) per wave and sub-chunk
     constexpr int N_BLK = NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
     constexpr int W = N_BLK + SPAN;
@@ -429,70 +432,88 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_mfma_splitk_kernel(const Conv
         const bool ok = in_tile && t >= 0 && t < p.Tin;
         st_voff[i] = ok ? (unsigned)(r * p.Tin + t) * 4u : 0xFFFFFFFFu;
     }
-    float stage[NE];
-    auto load_chunk = [&](int c) {
+    // Prefetch distance in LDS chunks for both operands: a chunk holds only KS * NT MFMAs per wave (256 cycles at KS = 2), far
+    // less than one L2 / HBM round trip, so short kernels keep several chunks of weights and window elements in flight
+    // (one chunk ahead left the transposed convs of a single-clip forward waiting ~1 us per chunk).
+    constexpr int PF = KS >= 8 ? 1 : 2;
+    float stage[PF][NE];
+    auto load_chunk = [&](float (&dst)[NE], int c) {
         const int cbase = c * CHW;
-        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)((p.Cin - cbase) * p.Tin) * 4u);
+        // chunks past the last one (prefetch overrun) get an empty descriptor: every load returns 0
+        const int rows = p.Cin - cbase > 0 ? p.Cin - cbase : 0;
+        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)(rows ? cbase : 0) * p.Tin, (unsigned)(rows * p.Tin) * 4u);
 #pragma unroll
-        for (int i = 0; i < NE; ++i) stage[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_voff[i], 0, 0));
+        for (int i = 0; i < NE; ++i) dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_voff[i], 0, 0));
     };
-    auto store_chunk = [&](float* dst) {
+    auto store_chunk = [&](float* dst, const float (&src)[NE]) {
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int e = tid + i * THREADS;
-            if (e < TOT) dst[e] = act_apply(stage[i], p.pre_act, p.slope);
+            if (e < TOT) dst[e] = act_apply(src[i], p.pre_act, p.slope);
         }
     };
 
     // this wave's dword of the packed float4s: 8-channel sub-chunk (wave >> 2) of the LDS chunk, channel pair (wave & 3), by
-    // raw buffer loads (SGPR base + constant VGPR part).  The packed buffer is zero-padded to whole groups of four sub-chunks.
+    // raw buffer loads (SGPR base + constant VGPR part).  The packed buffer is zero-padded to whole groups of four sub-chunks
+    // plus eight k-steps, and the descriptor is unbounded, so a prefetch past the last chunk reads harmless data.
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
     const int wvoff = lane * 16 + (wave & 3) * 4;
     const int wtile_b = __builtin_amdgcn_readfirstlane(m_blk * p.nchunk * KS * 1024);
-    auto load_a = [&](int c, int j) {
-        const int soff = __builtin_amdgcn_readfirstlane(wtile_b + ((c * (NW / 4) + (wave >> 2)) * KS + j) * 1024);
+    auto load_a = [&](int c, int sj) {   // sj = sub * KS + tap inside LDS chunk c
+        const int sub = sj / KS, j = sj - sub * KS;
+        const int soff = __builtin_amdgcn_readfirstlane(wtile_b + (((c * SUBK + sub) * (NW / 4) + (wave >> 2)) * KS + j) * 1024);
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, wvoff, soff, 0));
     };
     const int b_lane = (2 * wave + (lane >> 5)) * W + (lane & 31);
-    auto load_b = [&](float (&dst)[NT], const float* xsb, int j) {
+    auto load_b = [&](float (&dst)[NT], const float* xsb, int sj) {
+        const int sub = sj / KS, j = sj - sub * KS;
 #pragma unroll
-        for (int jn = 0; jn < NT; ++jn) dst[jn] = xsb[b_lane + jn * 32 + j * DIL];
+        for (int jn = 0; jn < NT; ++jn) dst[jn] = xsb[sub * (2 * NW) * W + b_lane + jn * 32 + j * DIL];
     };
 
-    // weights: a whole chunk's taps (KS dwords) are fetched one chunk ahead — with only NT MFMAs per tap a one-tap
-    // prefetch distance would be far shorter than the L2 latency
-    float a_cur[KS], a_nxt[KS];
+    constexpr int KSS = SUBK * KS;   // k-steps per wave and LDS chunk
+    float aq[PF + 1][KSS];
     float b_cur[NT], b_nxt[NT];
     const int nchunks = (p.Cin + CHW - 1) / CHW;
-    load_chunk(0);
+    const int last = nchunks - 1;
 #pragma unroll
-    for (int j = 0; j < KS; ++j) a_cur[j] = load_a(0, j);
+    for (int d = 0; d < PF; ++d) {
+        load_chunk(stage[d], d);
+#pragma unroll
+        for (int j = 0; j < KSS; ++j) aq[d][j] = load_a(d <= last ? d : last, j);
+    }
     for (int c = 0; c < nchunks; ++c) {
         float* xsb = xs[c & 1];
-        store_chunk(xsb);
+        store_chunk(xsb, stage[0]);
         __syncthreads();
-        const bool more = c + 1 < nchunks;
-        if (more) load_chunk(c + 1);
-        const int cn = more ? c + 1 : c;
+        // shift the window ring and request chunk c + PF
 #pragma unroll
-        for (int j = 0; j < KS; ++j) a_nxt[j] = load_a(cn, j);
+        for (int d = 0; d + 1 < PF; ++d)
+#pragma unroll
+            for (int i = 0; i < NE; ++i) stage[d][i] = stage[d + 1][i];
+        load_chunk(stage[PF - 1], c + PF);
+        const int cn = c + PF <= last ? c + PF : last;
+#pragma unroll
+        for (int j = 0; j < KSS; ++j) aq[PF][j] = load_a(cn, j);
         load_b(b_cur, xsb, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            if (j + 1 < KS) load_b(b_nxt, xsb, j + 1);
+        for (int j = 0; j < KSS; ++j) {
+            if (j + 1 < KSS) load_b(b_nxt, xsb, j + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jn = 0; jn < NT; ++jn)
-                acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], b_cur[jn], acc[0][jn], 0, 0, 0);
+                acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0][j], b_cur[jn], acc[0][jn], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (j + 1 < KS) {
+            if (j + 1 < KSS) {
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) b_cur[jn] = b_nxt[jn];
             }
         }
 #pragma unroll
-        for (int j = 0; j < KS; ++j) a_cur[j] = a_nxt[j];
+        for (int d = 0; d < PF; ++d)
+#pragma unroll
+            for (int j = 0; j < KSS; ++j) aq[d][j] = aq[d + 1][j];
     }
 
     // reduce the partial tiles

@@ -13,15 +13,16 @@ namespace fv {
 // One workgroup = 1024 consecutive t of one batch item; 8-channel slabs of pre-activated x go through LDS so the
 // activation is evaluated once per element instead of once per tap.
 // ---------------------------------------------------------------------------------------------
-constexpr int NARROW_TT = 1024;
 constexpr int NARROW_CH = 8;
 constexpr int NARROW_MAXCO = 4;
 
+template <int PER>   // output columns per thread: 4 (1024-column tiles) or 1 (256-column tiles when the batch is small)
 __global__ __launch_bounds__(256) void conv_narrow_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int Cin, int T, int Cout, int k, int pad, int pre_act,
                                                           int post_act, float slope, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NARROW_TT = 256 * PER;
     const int W = NARROW_TT + k - 1;
     float* xs = sm;                       // [NARROW_CH][W]
     float* ws = sm + NARROW_CH * W;       // [Cout][NARROW_CH][k] for the current slab
@@ -30,20 +31,21 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const float* __restric
     const int t0 = tile * NARROW_TT;
     const float* xb = x + (long long)b * Cin * T;
 
-    float acc[NARROW_MAXCO][4];
+    float acc[NARROW_MAXCO][PER];
 #pragma unroll
     for (int co = 0; co < NARROW_MAXCO; ++co)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[co][i] = 0.f;
+        for (int i = 0; i < PER; ++i) acc[co][i] = 0.f;
 
     for (int c0 = 0; c0 < Cin; c0 += NARROW_CH) {
         __syncthreads();
         for (int e = tid; e < NARROW_CH * W; e += 256) {
             const int r = e / W, col = e - r * W;
             const int ci = c0 + r, t = t0 - pad + col;
-            float v = 0.f;
-            if (ci < Cin && t >= 0 && t < T) v = act_apply(xb[(long long)ci * T + t], pre_act, slope);
-            xs[e] = v;
+            // unconditional load on a clamped address, mask applied to the value (a guarded load serialises)
+            const bool ok = ci < Cin && t >= 0 && t < T;
+            const float v = xb[(long long)(ci < Cin ? ci : Cin - 1) * T + (t < 0 ? 0 : (t < T ? t : T - 1))];
+            xs[e] = ok ? act_apply(v, pre_act, slope) : 0.f;
         }
         for (int e = tid; e < Cout * NARROW_CH * k; e += 256) {
             const int j = e % k, r = (e / k) % NARROW_CH, co = e / (k * NARROW_CH);
@@ -52,15 +54,15 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const float* __restric
         __syncthreads();
         for (int r = 0; r < NARROW_CH; ++r) {
             for (int j = 0; j < k; ++j) {
-                float xv[4];
+                float xv[PER];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xv[i] = xs[r * W + tid + i * 256 + j];
+                for (int i = 0; i < PER; ++i) xv[i] = xs[r * W + tid + i * 256 + j];
 #pragma unroll
                 for (int co = 0; co < NARROW_MAXCO; ++co) {
                     if (co < Cout) {
                         const float wv = ws[(co * NARROW_CH + r) * k + j];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[co][i] = fmaf(wv, xv[i], acc[co][i]);
+                        for (int i = 0; i < PER; ++i) acc[co][i] = fmaf(wv, xv[i], acc[co][i]);
                     }
                 }
             }
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const float* __restric
         if (co >= Cout) break;
         const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PER; ++i) {
             const int t = t0 + tid + i * 256;
             if (t < T) y[((long long)b * Cout + co) * T + t] = act_apply(acc[co][i] + bv, post_act, slope);
         }
@@ -84,10 +86,17 @@ fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, 
         set_error("conv_narrow: needs c_out <= %d and 'same' padding (c_out=%d k=%d pad=%d)", NARROW_MAXCO, Cout, k, pad);
         return FV_ERR_UNSUPPORTED;
     }
-    const int n_tiles = (T + NARROW_TT - 1) / NARROW_TT;
-    const size_t lds = ((size_t)NARROW_CH * (NARROW_TT + k - 1) + (size_t)Cout * NARROW_CH * k) * sizeof(float);
-    hipLaunchKernelGGL(conv_narrow_kernel, dim3(B * n_tiles), dim3(256), lds, s, x, w, bias, y, Cin, T, Cout, k, pad,
-                       pre_act, post_act, slope, n_tiles);
+    // 1024-column tiles unless they leave most CUs idle (single-clip latency): then 256-column tiles
+    const bool small = (long long)B * ((T + 1023) / 1024) < 2 * num_cus();
+    const int tt = small ? 256 : 1024;
+    const int n_tiles = (T + tt - 1) / tt;
+    const size_t lds = ((size_t)NARROW_CH * (tt + k - 1) + (size_t)Cout * NARROW_CH * k) * sizeof(float);
+    if (small)
+        hipLaunchKernelGGL(conv_narrow_kernel<1>, dim3(B * n_tiles), dim3(256), lds, s, x, w, bias, y, Cin, T, Cout, k, pad,
+                           pre_act, post_act, slope, n_tiles);
+    else
+        hipLaunchKernelGGL(conv_narrow_kernel<4>, dim3(B * n_tiles), dim3(256), lds, s, x, w, bias, y, Cin, T, Cout, k, pad,
+                           pre_act, post_act, slope, n_tiles);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
 }
