@@ -213,6 +213,14 @@ def main():
             "output_finite": ok,
             "roofline": roofline_from_profile(table, repeats),
         }
+        # whole-step view next to the dominant-kernel one: algorithmic flops of the forward (55.97 GFLOP per
+        # one-second clip at T_mel = 86; summed here from the profiler's per-launch figures) over the measured step time
+        step_flops = sum(r["flops_per_launch"] * (r["launches"] // repeats) for r in table)
+        peak_tf = PEAK_F16X3_TFLOPS if a.precision == "f16x3" else PEAK_MFMA_F32_TFLOPS
+        ach = step_flops / (elapsed / a.steps) / 1e12
+        result["roofline_step"] = {"flops_per_step": step_flops, "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s",
+                                   "frac": ach / peak_tf,
+                                   "note": "all kernels of one forward, measured step time (branch streams + graph replay)"}
         if world == 1 and a.precision == "f32" and not a.no_alt_precision:
             # the opt-in f16x3 mode on the same batch: throughput and its deviation from the exact-fp32 output above.
             # Auxiliary: a failure here must not cost the headline line.
