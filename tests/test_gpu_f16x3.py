@@ -189,3 +189,21 @@ def test_f16x3_bigvgan_and_refinegan_goldens():
     y = eng(torch.from_numpy(g["mel"]).to(dev), None, torch.from_numpy(g["template"]).to(dev),
             torch.from_numpy(noise).to(dev)).cpu().numpy()
     assert np.abs(y - g["out"]).max() <= 1e-4, np.abs(y - g["out"]).max()
+
+
+def test_f16x3_range_contract_is_loud():
+    """|activation| >= 65504 is outside the f16x3 contract (include/fishvoc.h fv_precision): the fp16 high plane becomes inf and
+    the affected outputs non-finite — never a silently wrong finite number; the fp32 mode handles the same input."""
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(1, 64, 300)).astype(np.float32)
+    x[0, 5, 100] = 1.0e5
+    w = (rng.normal(size=(64, 64, 3)) / 14.0).astype(np.float32)
+    y16, kern = _conv(w, None, x, None, "f16x3", padding=1)
+    assert kern.startswith("conv_f16x3"), kern
+    assert not np.isfinite(y16[0, :, 99:102]).all()
+    keep = np.ones(300, bool)
+    keep[99:102] = False
+    ref = orc.conv1d(x, w, None, padding=1)
+    assert np.isfinite(y16[0][:, keep]).all() and np.abs(y16[0][:, keep] - ref[0][:, keep]).max() <= 1e-4
+    y32, _ = _conv(w, None, x, None, "f32", padding=1)
+    assert np.isfinite(y32).all() and np.abs(y32 - ref).max() <= 1e-2   # 1e5-scale values: fp32 roundoff
