@@ -233,31 +233,38 @@ __global__ __launch_bounds__(256, FV_X_PAIRWAVES) void resblock_pair32_kernel(co
         gemm32_resident<KS, G::WB, 1, MT, NT, NCH>(p.w2, lane, Bs + krow * G::WB + ncol, acc);
         const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb, (unsigned)(C * p.T) * 4u);
         const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * C * p.T, (unsigned)(C * p.T) * 4u);
+        // residual operands of the whole register tile first, then combine and store: one HBM round trip instead of one per
+        // accumulator row (the loads of row r + 1 could not start before the stores of row r were issued)
+        auto off = [&](int i, int r, int jn) -> unsigned {   // byte offset inside this batch item, or 0xFFFFFFFF (masked)
+            const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
+            const int n = ncol + jn * 32;
+            const int t = t0 + n;
+            return (n < G::TT && t < p.T) ? (unsigned)(m * p.T + t) * 4u : 0xFFFFFFFFu;
+        };
+        float xr[MT][16][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn)
+                    xr[i][r][jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off(i, r, jn), 0, 0));
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
                 const float bias = p.b2[m];
-                // byte offset inside this batch item, or 0xFFFFFFFF (out of range: loads give 0, stores are dropped)
-                unsigned o[NT];
-                float xr[NT], yo[NT];
-#pragma unroll
-                for (int jn = 0; jn < NT; ++jn) {
-                    const int n = ncol + jn * 32;
-                    const int t = t0 + n;
-                    o[jn] = (n < G::TT && t < p.T) ? (unsigned)(m * p.T + t) * 4u : 0xFFFFFFFFu;
-                    xr[jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, o[jn], 0, 0));
-                }
+                float yo[NT];
                 if (p.out_mode == OUT_ACCUM) {
 #pragma unroll
-                    for (int jn = 0; jn < NT; ++jn) yo[jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, o[jn], 0, 0));
+                    for (int jn = 0; jn < NT; ++jn) yo[jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, off(i, r, jn), 0, 0));
                 }
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) {
-                    float v = acc[i][jn][r] + bias + xr[jn];
+                    float v = acc[i][jn][r] + bias + xr[i][r][jn];
                     if (p.out_mode == OUT_ACCUM) v = (yo[jn] + v) * p.out_scale;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, o[jn], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, off(i, r, jn), 0, 0);
                 }
             }
     }
@@ -314,28 +321,29 @@ __global__ __launch_bounds__(256, FV_X_PAIRWAVES) void resblock_pair16_kernel(co
         gemm16_resident<KS, G::WB, 1, NT>(p.w2, lane, Bs + krow * G::WB + ncol, acc);
         const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb, (unsigned)(C * p.T) * 4u);
         const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * C * p.T, (unsigned)(C * p.T) * 4u);
+        auto off = [&](int r, int jn) -> unsigned {   // byte offset inside this batch item, 0xFFFFFFFF = masked
+            const int n = ncol + jn * 16;
+            const int t = t0 + n;
+            return (n < G::TT && t < p.T) ? (unsigned)((4 * krow + r) * p.T + t) * 4u : 0xFFFFFFFFu;
+        };
+        float xr[4][NT];   // the whole tile's residual operands in one round trip (see resblock_pair32_kernel)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) xr[r][jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off(r, jn), 0, 0));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = 4 * krow + r;
-            const float bias = p.b2[m];
-            unsigned o[NT];   // byte offset inside this batch item, 0xFFFFFFFF = masked (see resblock_pair32_kernel)
-            float xr[NT], yo[NT];
-#pragma unroll
-            for (int jn = 0; jn < NT; ++jn) {
-                const int n = ncol + jn * 16;
-                const int t = t0 + n;
-                o[jn] = (n < G::TT && t < p.T) ? (unsigned)(m * p.T + t) * 4u : 0xFFFFFFFFu;
-                xr[jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, o[jn], 0, 0));
-            }
+            const float bias = p.b2[4 * krow + r];
+            float yo[NT];
             if (p.out_mode == OUT_ACCUM) {
 #pragma unroll
-                for (int jn = 0; jn < NT; ++jn) yo[jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, o[jn], 0, 0));
+                for (int jn = 0; jn < NT; ++jn) yo[jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, off(r, jn), 0, 0));
             }
 #pragma unroll
             for (int jn = 0; jn < NT; ++jn) {
-                float v = acc[jn][r] + bias + xr[jn];
+                float v = acc[jn][r] + bias + xr[r][jn];
                 if (p.out_mode == OUT_ACCUM) v = (yo[jn] + v) * p.out_scale;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, o[jn], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, off(r, jn), 0, 0);
             }
         }
     }
