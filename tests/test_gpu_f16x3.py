@@ -207,3 +207,31 @@ def test_f16x3_range_contract_is_loud():
     assert np.isfinite(y16[0][:, keep]).all() and np.abs(y16[0][:, keep] - ref[0][:, keep]).max() <= 1e-4
     y32, _ = _conv(w, None, x, None, "f32", padding=1)
     assert np.isfinite(y32).all() and np.abs(y32 - ref).max() <= 1e-2   # 1e5-scale values: fp32 roundoff
+
+
+PAIR_CASES = [(128, 11, 1, 2, 300), (128, 11, 5, 1, 517), (128, 7, 3, 2, 200), (128, 3, 1, 1, 1000), (128, 3, 5, 3, 97),
+              (64, 11, 3, 2, 700), (64, 7, 1, 1, 255), (64, 3, 3, 2, 129), (64, 11, 5, 1, 40), (128, 7, 5, 1, 5)]
+
+
+@pytest.mark.parametrize("C,k,d,B,T", PAIR_CASES)
+def test_f16x3_wide_fused_pair_matches_oracle(C, k, d, B, T):
+    """y = x + c2(silu(c1(silu(x)))) in one launch on the split-fp16 path (fv_conv_pair_forward, pair_f16x3_impl.h):
+    ragged tile edges, clips shorter than a tile, every (k, dilation) the ResBlocks use."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import FusedConv
+    rng = np.random.default_rng(C + 13 * k + d)
+    x = (rng.normal(size=(B, C, T)) * 2.0).astype(np.float32)
+    w1 = (rng.normal(size=(C, C, k)) / np.sqrt(C * k) * 1.3).astype(np.float32)
+    w2 = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    b1 = rng.normal(size=C).astype(np.float32) * 0.1
+    b2 = rng.normal(size=C).astype(np.float32) * 0.1
+    h = orc.conv1d(orc.silu(x), w1, b1, dilation=d, padding=(k * d - d) // 2)
+    ref = x + orc.conv1d(orc.silu(h), w2, b2, dilation=1, padding=(k - 1) // 2)
+    c1 = FusedConv(w1, b1, dilation=d, padding=(k * d - d) // 2).set_precision("f16x3")
+    c2 = FusedConv(w2, b2, padding=(k - 1) // 2).set_precision("f16x3")
+    y = c1.pair(c2, torch.from_numpy(x).to(_dev()))
+    torch.cuda.synchronize()
+    assert _lib.last_kernel().startswith("pair_f16x3"), _lib.last_kernel()
+    err = np.abs(y.cpu().numpy() - ref).max()
+    scale = max(np.abs(ref).max(), 1.0)
+    assert err <= 1e-4 and err <= 2e-5 * scale, f"max|d|={err:.3e} scale={scale:.2f}"

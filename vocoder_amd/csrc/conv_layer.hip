@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "fv_internal.h"
+#include "pair_f16x3_params.h"
 
 namespace fv {
 
@@ -378,9 +379,71 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     return FV_OK;
 }
 
+// f16x3 precision mode: wide (C = 128 / 64) SiLU pairs on the fused split-fp16 kernel (pair_f16x3_impl.h)
+bool pair_f16x3_supported(const ConvLayer& c1, const ConvLayer& c2) {
+    const int C = c1.c_in;
+    return c1.precision == FV_PRECISION_F16X3 && c2.precision == FV_PRECISION_F16X3 && c1.d_wph && c2.d_wph &&
+           !c1.transposed && !c2.transposed && (C == 128 || C == 64) && c1.c_out == C && c2.c_in == C && c2.c_out == C &&
+           c1.k == c2.k && (c1.k == 3 || c1.k == 7 || c1.k == 11) && (c1.dil == 1 || c1.dil == 3 || c1.dil == 5) && c2.dil == 1 &&
+           c1.padding == (c1.k - 1) / 2 * c1.dil && c2.padding == (c2.k - 1) / 2 && getenv("FV_NO_F16X3_PAIRS") == nullptr;
+}
+
+static fv_status conv_pair_run_f16x3(const ConvLayer& c1, const ConvLayer& c2, const float* x, float* y, int batch, int t,
+                                     int out_mode, float out_scale, hipStream_t stream) {
+    if (x == y) {
+        set_error("conv_pair_run: output must not alias the input (halo reads)");
+        return FV_ERR_INVALID;
+    }
+    const int C = c1.c_in;
+    if ((long long)C * t >= (1LL << 30)) {
+        set_error("conv_pair_run: a batch item of %lld elements exceeds the 4 GiB buffer-addressing span", (long long)C * t);
+        return FV_ERR_UNSUPPORTED;
+    }
+    PairF16Params p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = x;
+    p.y = y;
+    p.w1h = c1.d_wph;
+    p.w2h = c2.d_wph;
+    p.b1 = c1.d_bias;
+    p.b2 = c2.d_bias;
+    p.s1 = 1.0f / c1.w_scale;
+    p.s2 = 1.0f / c2.w_scale;
+    p.T = t;
+    p.nch16 = C / 16;
+    p.out_mode = out_mode;
+    p.out_scale = out_scale;
+    const int prof_idx = prof_begin(stream);
+    bool ok = false;
+    switch (c1.k) {
+        case 3: ok = launch_pair_f16x3_k3(p, C, c1.dil, batch, stream); break;
+        case 7: ok = launch_pair_f16x3_k7(p, C, c1.dil, batch, stream); break;
+        case 11: ok = launch_pair_f16x3_k11(p, C, c1.dil, batch, stream); break;
+        default: break;
+    }
+    if (!ok) {
+        set_error("conv_pair_run: no f16x3 pair kernel for (C=%d k=%d d=%d)", C, c1.k, c1.dil);
+        return FV_ERR_UNSUPPORTED;
+    }
+    static thread_local char name[96];
+    std::snprintf(name, sizeof(name), "pair_f16x3<k=%d d=%d C=%d>", c1.k, c1.dil, C);
+    set_last_kernel(name);
+    if (prof_idx >= 0) {
+        const int tt = (C == 128 ? 96 : 128) - (c1.k - 1);
+        char lbl[128];
+        std::snprintf(lbl, sizeof(lbl), "%s grid=%d", name, batch * ((t + tt - 1) / tt));
+        const double macs = 2.0 * C * C * c1.k * (double)t * batch;
+        const double elems = (out_mode == OUT_ACCUM ? 4.0 : 3.0) * C * (double)t * batch;   // x, residual, y (+ accumulate)
+        prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * 4.0 + 2.0 * C * C * c1.k * 4.0);
+    }
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
 fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x, float* y, int batch, int t, int out_mode,
                         float out_scale, hipStream_t stream) {
     const int C = c1.c_in;
+    if (pair_f16x3_supported(c1, c2)) return conv_pair_run_f16x3(c1, c2, x, y, batch, t, out_mode, out_scale, stream);
     const bool shape_ok = !c1.transposed && !c2.transposed && c1.c_out == C && c2.c_in == C && c2.c_out == C &&
                           c1.k == c2.k && c2.dil == 1 && c1.padding == (c1.k - 1) / 2 * c1.dil && c2.padding == (c2.k - 1) / 2;
     if (!shape_ok || !pair_supported(C, c1.k, c1.dil)) {

@@ -776,8 +776,12 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
             }
             // HiFiGAN narrow stages: the whole (c1, c2) pair in one kernel, intermediate kept in LDS.  Not in place
             // (workgroups read their neighbours' halo), so the branch ping-pongs S -> XB -> XT -> Y.
-            const bool fuse = !ups.bigvgan && pair_supported(ch, br.k, br.dil[0]) && pair_supported(ch, br.k, br.dil[1]) &&
-                              pair_supported(ch, br.k, br.dil[2]) && fuse_pairs;
+            const bool fuse_narrow = pair_supported(ch, br.k, br.dil[0]) && pair_supported(ch, br.k, br.dil[1]) &&
+                                     pair_supported(ch, br.k, br.dil[2]);
+            // f16x3 precision mode: the wide stages (C = 128 / 64) fuse too (pair_f16x3_impl.h)
+            const bool fuse_wide = pair_f16x3_supported(br.c1[0], br.c2[0]) && pair_f16x3_supported(br.c1[1], br.c2[1]) &&
+                                   pair_f16x3_supported(br.c1[2], br.c2[2]);
+            const bool fuse = !ups.bigvgan && (fuse_narrow || fuse_wide) && fuse_pairs;
             if (fuse) {
                 const float* src = S;
                 for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
