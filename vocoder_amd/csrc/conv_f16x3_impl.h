@@ -18,7 +18,7 @@
 //   * K runs over 16-channel chunks; lane l of a wave supplies k = 8 * (l >> 5) .. +7 (8 consecutive channels).
 //   * LDS window: [plane][k-half][column] x 16 B (8 channels of one column), so a B fragment is one ds_read_b128 per
 //     lane at lane-consecutive 16-byte slots (conflict-free) and taps are immediate-offset shifts, as before.
-//   * Weights: host-packed [m_tile][chunk16][tap][plane (wh, wl, wh*2^-11)][lane] x 16 B, fetched from L2 with
+//   * Weights: host-packed [m_tile][chunk16][tap][plane (wh, wl)][lane] x 16 B (the third operand wh*2^-11 is derived in registers), fetched from L2 with
 //     SGPR-addressed raw buffer loads, prefetched DA k-blocks ahead.
 //   * Wave tile 32 x (NT*32): waves are stacked along M so no two waves of a workgroup fetch the same weights.
 #pragma once
@@ -212,14 +212,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
         }
     };
 
-    // ---- weights: k-block g = chunk16 * KS + tap of m-tile mt starts at byte ((mt * nch16 * KS) + g) * 3072 ----
+    // ---- weights: k-block g = chunk16 * KS + tap of m-tile mt starts at byte ((mt * nch16 * KS) + g) * 2048 ----
     const int mt0 = m_blk * WM + wm;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wph, 0, 0x7fffffff, 0x00020000);
     const int wvoff = lane * 16;
-    const int wbase = __builtin_amdgcn_readfirstlane(mt0 * p.nch16 * KS * 3072);
-    auto load_a = [&](h8 (&dst)[3], int goff_b) {   // goff_b = g * 3072, wave-uniform
+    const int wbase = __builtin_amdgcn_readfirstlane(mt0 * p.nch16 * KS * 2048);
+    auto load_a = [&](h8 (&dst)[2], int goff_b) {   // goff_b = g * 2048, wave-uniform
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < 2; ++q) {
             // voffset carries the constant plane offset so that it folds into the instruction's immediate field: one
             // SALU add per k-block instead of three
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + q * 1024, wbase + goff_b, 0);
@@ -244,14 +244,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
     constexpr int NG = NT / 2;
     constexpr int G = KB * NG;            // fragment groups per chunk
     constexpr int RA = DA + 1;            // weight-fragment ring: k-block kb of a chunk lives in slot kb % RA
-    h8 aq[RA][3];
+    h8 aq[RA][2];   // (wh, wl); the third operand wh * 2^-11 is derived in registers right before its MFMAs
     h8 bq[2][2][2];
     const int nch = (p.nch16_real + SUBS - 1) / SUBS;   // LDS chunks; the packed planes are padded to whole chunks
     chunk_rsrc(0);
 #pragma unroll
     for (int i = 0; i < NE; ++i) load_item(i);
 #pragma unroll
-    for (int d = 0; d < DA; ++d) load_a(aq[d], d * 3072);
+    for (int d = 0; d < DA; ++d) load_a(aq[d], d * 2048);
     for (int c = 0; c < nch; ++c) {
         h8* xsb = xs[c & 1];
         store_chunk(xsb);
@@ -262,11 +262,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
 #pragma unroll
             for (int i = 0; i < NE; ++i) load_item(i);
         }
-        const int gchunk_b = __builtin_amdgcn_readfirstlane((c * KB + DA) * 3072);
+        const int gchunk_b = __builtin_amdgcn_readfirstlane((c * KB + DA) * 2048);
         load_bgrp(bq[0], xsb, 0, 0);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-            load_a(aq[(kb + DA) % RA], gchunk_b + kb * 3072);
+            load_a(aq[(kb + DA) % RA], gchunk_b + kb * 2048);
 #pragma unroll
             for (int grp = 0; grp < NG; ++grp) {
                 const int sidx = kb * NG + grp;            // compile-time after unrolling
@@ -274,12 +274,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
                 if (sidx + 1 < G) load_bgrp(bq[cur ^ 1], xsb, (sidx + 1) / NG, (sidx + 1) % NG);
                 __builtin_amdgcn_sched_barrier(0);
                 // product-major order: consecutive MFMAs never share an accumulator
+                const h8 a_sc = aq[kb % RA][0] * (_Float16)(1.0f / 2048.0f);   // exact (power of two): 4 v_pk_mul_f16
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int jn = grp * 2 + u;
-                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[kb % RA][q], bq[cur][u][q == 2 ? 1 : 0], acc[0][jn], 0, 0, 0);
+                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q == 2 ? a_sc : aq[kb % RA][q], bq[cur][u][q == 2 ? 1 : 0], acc[0][jn], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -287,15 +288,15 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
         // the DA fragments in flight for the next chunk sit in slots (KB + d) % RA: move them to slots d (once per chunk;
         // a per-tap rotation cost 2 v_mov per MFMA)
         if (KB % RA != 0) {
-            h8 t[DA][3];
+            h8 t[DA][2];
 #pragma unroll
             for (int d = 0; d < DA; ++d)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) t[d][q] = aq[(KB + d) % RA][q];
+                for (int q = 0; q < 2; ++q) t[d][q] = aq[(KB + d) % RA][q];
 #pragma unroll
             for (int d = 0; d < DA; ++d)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) aq[d][q] = t[d][q];
+                for (int q = 0; q < 2; ++q) aq[d][q] = t[d][q];
         }
     }
 

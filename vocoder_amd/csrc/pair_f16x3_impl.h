@@ -108,26 +108,27 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairF16Params 
         }
     };
     const int wvoff = lane * 16;
-    const int wtile_b = __builtin_amdgcn_readfirstlane(wm * p.nch16 * KS * 3072);   // this wave's m-tile in either layer
-    auto load_a = [&](const __amdgpu_buffer_rsrc_t& rs, h8 (&dst)[3], int goff_b) {
+    const int wtile_b = __builtin_amdgcn_readfirstlane(wm * p.nch16 * KS * 2048);   // this wave's m-tile in either layer
+    auto load_a = [&](const __amdgpu_buffer_rsrc_t& rs, h8 (&dst)[2], int goff_b) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < 2; ++q) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, wvoff + q * 1024, wtile_b + goff_b, 0);
             dst[q] = __builtin_bit_cast(h8, v);
         }
     };
     constexpr int DA = kF16WeightPrefetch;
     constexpr int RA = DA + 1;
-    h8 aq[RA][3];
+    h8 aq[RA][2];   // (wh, wl); wh * 2^-11 derived in registers
     h8 bq[2][NT][2];                                    // B fragments of the current and the next k-block
     const int nch = p.nch16;
     // nine (NT = 3) MFMAs per k-block, product-major so that consecutive MFMAs never share an accumulator
-    auto mfma_block = [&](const h8 (&a)[3], const h8 (&bf)[NT][2]) {
+    auto mfma_block = [&](const h8 (&a)[2], const h8 (&bf)[NT][2]) {
+        const h8 a_sc = a[0] * (_Float16)(1.0f / 2048.0f);   // exact (power of two): 4 v_pk_mul_f16
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int jn = 0; jn < NT; ++jn)
-                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q], bf[jn][q == 2 ? 1 : 0], acc[jn], 0, 0, 0);
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q == 2 ? a_sc : a[q], bf[jn][q == 2 ? 1 : 0], acc[jn], 0, 0, 0);
     };
     {
         const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1h, 0, 0x7fffffff, 0x00020000);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairF16Params 
 #pragma unroll
         for (int i = 0; i < NE; ++i) load_item(i);
 #pragma unroll
-        for (int d = 0; d < DA; ++d) load_a(w1rs, aq[d], d * 3072);
+        for (int d = 0; d < DA; ++d) load_a(w1rs, aq[d], d * 2048);
         for (int c = 0; c < nch; ++c) {
             h8* xsb = xs0 + (c & 1) * (2 * PLANE);
             store_chunk(xsb);
@@ -152,26 +153,26 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairF16Params 
 #pragma unroll
                 for (int i = 0; i < NE; ++i) load_item(i);
             }
-            const int gchunk_b = __builtin_amdgcn_readfirstlane((c * KS + DA) * 3072);
+            const int gchunk_b = __builtin_amdgcn_readfirstlane((c * KS + DA) * 2048);
             load_b(bq[0], xsb, 0);
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
-                load_a(w1rs, aq[(j + DA) % RA], gchunk_b + j * 3072);
+                load_a(w1rs, aq[(j + DA) % RA], gchunk_b + j * 2048);
                 if (j + 1 < KS) load_b(bq[(j + 1) & 1], xsb, j + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_block(aq[j % RA], bq[j & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (KS % RA != 0) {
-                h8 t[DA][3];
+                h8 t[DA][2];
 #pragma unroll
                 for (int d = 0; d < DA; ++d)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) t[d][q] = aq[(KS + d) % RA][q];
+                    for (int q = 0; q < 2; ++q) t[d][q] = aq[(KS + d) % RA][q];
 #pragma unroll
                 for (int d = 0; d < DA; ++d)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) aq[d][q] = t[d][q];
+                    for (int q = 0; q < 2; ++q) aq[d][q] = t[d][q];
             }
         }
     }
@@ -225,13 +226,13 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairF16Params 
                 for (int jn = NT - 1; jn >= 0; --jn) dst[jn][q] = hk[q * HPLANE + jn * 32];
         };
 #pragma unroll
-        for (int d = 0; d < DA; ++d) load_a(w2rs, aq[d], d * 3072);
+        for (int d = 0; d < DA; ++d) load_a(w2rs, aq[d], d * 2048);
         load_b2(bq[0], 0, 0);
         for (int kb = 0; kb < nch; ++kb) {
-            const int gchunk_b = __builtin_amdgcn_readfirstlane((kb * KS + DA) * 3072);
+            const int gchunk_b = __builtin_amdgcn_readfirstlane((kb * KS + DA) * 2048);
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
-                load_a(w2rs, aq[(j + DA) % RA], gchunk_b + j * 3072);
+                load_a(w2rs, aq[(j + DA) % RA], gchunk_b + j * 2048);
                 // no barriers in this phase: the fragment prefetch runs across channel-group boundaries too
                 const int cur = j & 1;   // every channel group starts in bq[0] (see the copy below)
                 if (j + 1 < KS) load_b2(bq[cur ^ 1], kb, j + 1);
@@ -247,15 +248,15 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairF16Params 
                     for (int q = 0; q < 2; ++q) bq[0][jn][q] = bq[1][jn][q];
             }
             if (KS % RA != 0) {
-                h8 t[DA][3];
+                h8 t[DA][2];
 #pragma unroll
                 for (int d = 0; d < DA; ++d)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) t[d][q] = aq[(KS + d) % RA][q];
+                    for (int q = 0; q < 2; ++q) t[d][q] = aq[(KS + d) % RA][q];
 #pragma unroll
                 for (int d = 0; d < DA; ++d)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) aq[d][q] = t[d][q];
+                    for (int q = 0; q < 2; ++q) aq[d][q] = t[d][q];
             }
         }
     }
