@@ -20,6 +20,9 @@ def key_of(kernel_name: str, grid_threads: int):
     if m:
         ks, dil, wm, wn, nt = map(int, m.groups())
         return f"conv_f16x3 k={ks} d={dil} tile={wm * 32}x{wn * nt * 32} grid={blocks}"
+    m = re.search(r"pair_f16x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", kernel_name)
+    if m:
+        return f"pair_f16x3 k={m.group(1)} d={m.group(2)} C={32 * int(m.group(3))} grid={blocks}"
     m = re.search(r"resblock_pair16_kernel<(\d+), (\d+)>", kernel_name)
     if m:
         return f"resblock_pair k={m.group(1)} d={m.group(2)} C=16 grid={blocks}"
@@ -37,6 +40,9 @@ def bench_key(label: str):
     m = re.search(r"conv_f16x3<k=(\d+) d=(\d+) tile=(\w+)>.*grid=(\d+)", label)
     if m:
         return f"conv_f16x3 k={m.group(1)} d={m.group(2)} tile={m.group(3)} grid={m.group(4)}"
+    m = re.search(r"pair_f16x3<k=(\d+) d=(\d+) C=(\d+)> grid=(\d+)", label)
+    if m:
+        return f"pair_f16x3 k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={m.group(4)}"
     m = re.search(r"resblock_pair<k=(\d+) d=(\d+) C=(\d+)> grid=(\d+)", label)
     if m:
         return f"resblock_pair k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={m.group(4)}"

@@ -300,11 +300,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
         }
     }
 
-    // epilogue in groups of four n-tiles (64 accumulator registers; bounds the live registers)
+    // epilogue in groups of four n-tiles (two for the 128-accumulator tile: bounds the live registers)
+    constexpr int EG = NT >= 8 ? 2 : 4;
 #pragma unroll
-    for (int hf = 0; hf < NT / 4; ++hf) {
-        f32x16(&sub)[4] = reinterpret_cast<f32x16(&)[4]>(acc[0][hf * 4]);
-        conv_epilogue_bulk<4>(p, sub, b, mt0, n0 + wn * (NT * 32) + hf * 128 + (lane & 31), lane);
+    for (int hf = 0; hf < NT / EG; ++hf) {
+        f32x16(&sub)[EG] = reinterpret_cast<f32x16(&)[EG]>(acc[0][hf * EG]);
+        conv_epilogue_bulk<EG>(p, sub, b, mt0, n0 + wn * (NT * 32) + hf * EG * 32 + (lane & 31), lane);
     }
 }
 
