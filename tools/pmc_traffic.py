@@ -50,7 +50,7 @@ def bench_key(label: str):
 
 
 def collect(d, counter):
-    path = glob.glob(os.path.join(d, "*counter_collection.csv"))[0]
+    path = max(glob.glob(os.path.join(d, "*counter_collection.csv")), key=os.path.getmtime)   # newest pass in the directory
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
