@@ -12,7 +12,8 @@
 //   phase 2  c1 as implicit GEMM on fp32 MFMA over W1 = TT + KS-1 columns, epilogue bias + silu (+ zero outside [0, T):
 //            c2's zero padding) written to LDS buffer Bf
 //   phase 3  c2 as implicit GEMM reading Bf, epilogue bias + residual x (+ MRF accumulate) to HBM
-// All K = C*KS is resident, so there are only two barriers per workgroup and every LDS address is an immediate.
+// All K = C*KS is resident, so there are only three barriers per workgroup and every LDS address is an immediate; Bf
+// overlays A (written after a barrier once c1 has consumed it).
 // C = 32 / 64 use v_mfma_f32_32x32x2_f32; C = 16 uses v_mfma_f32_16x16x4_f32 (no padded rows).
 #include "conv_mfma_impl.h"
 
@@ -26,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int KS, int DIL, int C>
 struct PairGeom {
-    static constexpr int W1 = kPairCols / C;            // c1 output columns per workgroup (256 at C=16, 128 at C=32: ~40 KB of LDS, 4 workgroups per CU)
+    static constexpr int W1 = kPairCols / C;            // c1 output columns per workgroup (256 at C=16, 128 at C=32: 18-27 KB of LDS)
     static constexpr int TT = W1 - (KS - 1);            // final output columns per workgroup
     static constexpr int H1 = (KS - 1) / 2 * DIL, H2 = (KS - 1) / 2, HP = H1 + H2;
     static constexpr int WA_RAW = W1 + (KS - 1) * DIL;  // staged x columns
@@ -34,7 +35,8 @@ struct PairGeom {
     // row strides == 16 (mod 32): the 16x16x4 B-fragment read puts lanes 0-15 / 16-31 on adjacent channel rows
     static constexpr int WA = (WA_RAW - 16 + 31) / 32 * 32 + 16;
     static constexpr int WB = (WB_RAW - 16 + 31) / 32 * 32 + 16;
-    static constexpr int LDS_FLOATS = C * (WA + WB);
+    // the intermediate overlays the input window (one extra barrier): half the LDS, up to 8 workgroups per CU (-4 %)
+    static constexpr int LDS_FLOATS = C * (WA > WB ? WA : WB);
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256, FV_X_PAIRWAVES) void resblock_pair32_kernel(co
     constexpr int NCH = C / 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;
-    float* Bs = lds + C * G::WA;
+    float* Bs = lds;   // overlays As once every wave has finished c1
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256, FV_X_PAIRWAVES) void resblock_pair32_kernel(co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         gemm32_resident<KS, G::WA, DIL, MT, NT, NCH>(p.w1, lane, As + krow * G::WA + ncol, acc);
+        __syncthreads();   // every wave is done reading the window before the intermediate overwrites it
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256, FV_X_PAIRWAVES) void resblock_pair16_kernel(co
     constexpr int NT = G::W1 / 16 / 4;   // 8 n-tiles of 16 columns per wave
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;
-    float* Bs = lds + C * G::WA;
+    float* Bs = lds;   // overlays As once every wave has finished c1
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(256, FV_X_PAIRWAVES) void resblock_pair16_kernel(co
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         gemm16_resident<KS, G::WA, DIL, NT>(p.w1, lane, As + krow * G::WA + ncol, acc);
+        __syncthreads();   // (see resblock_pair32_kernel)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = 4 * krow + r;
