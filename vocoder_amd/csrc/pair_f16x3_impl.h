@@ -13,7 +13,7 @@
 // the last KS - 1 would need intermediate columns of the next tile and are dropped: tiles advance by TT = N_H - (KS - 1)
 // (8 - 10 % redundant MFMA work at k = 11, 2 % at k = 3).
 // LDS (dynamic): x window (two 16-channel chunks in flight, as in the per-layer kernel) + the intermediate planes
-// [plane][channel group of 8][column] x 16 B = 4 * C * N_H bytes: 68 / 56 KB at k = 11, d = 5 -> two workgroups per CU.
+// [plane][channel group of 8][column] x 16 B = 4 * C * N_H bytes (49 / 33 KB), the latter overlaying the former once c1 is done.
 #pragma once
 
 #include "conv_f16x3_impl.h"
@@ -29,7 +29,8 @@ struct PairF16Geom {
     static constexpr int W1 = N_H + (KS - 1) * DIL1;
     static constexpr int XS_SLOTS = 2 * 4 * W1;              // two buffers x (2 planes x 2 k-halves x W1)
     static constexpr int HS_SLOTS = 2 * KG * N_H + KS;       // two planes (+ read overhang of the dropped columns)
-    static constexpr size_t LDS_BYTES = (size_t)(XS_SLOTS + HS_SLOTS) * 16;
+    // the intermediate planes overlay the x window (written after a barrier once c1 has consumed it)
+    static constexpr size_t LDS_BYTES = (size_t)(XS_SLOTS > HS_SLOTS ? XS_SLOTS : HS_SLOTS) * 16;
 };
 
 template <int KS, int DIL1, int WM, int WN, int NT>
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairF16Params 
     constexpr int HPLANE = KG * N_H;                    // slots per intermediate plane
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     h8* xs0 = reinterpret_cast<h8*>(lds_raw);           // c1 input window: [buffer][plane][k-half][column]
-    h8* hs = xs0 + 2 * 2 * PLANE;                       // intermediate: [plane][channel group][column] (+ read overhang)
+    h8* hs = xs0;                                       // intermediate: [plane][channel group][column] (+ read overhang); overlays xs
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairF16Params 
             }
         }
     }
+    __syncthreads();   // every wave is done reading the x window: the intermediate planes may overwrite it
     // c1 epilogue: bias, SiLU, zero outside [0, T) (= c2's zero padding), split, into the intermediate planes.
     // Lane (half hh, column n) holds rows 8*rq + 4*hh + (0..3) of its m-tile for rq = 0..3: four consecutive channels of
     // channel group wm*4 + rq -> one 8-byte store per (n-tile, rq, plane).
