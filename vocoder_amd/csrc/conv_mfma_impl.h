@@ -148,13 +148,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
 }
 
-#ifndef FV_X_DA
-#define FV_X_DA 3
-#endif
-#ifndef FV_X_ABLATE
-#define FV_X_ABLATE 0   // experiments only: bit 0 no weight loads, 1 no LDS fragment reads, 2 no staging, 3 no barrier
-#endif
-constexpr int kWeightPrefetch = FV_X_DA;   // weight-fragment prefetch distance in k-steps (taps)
+constexpr int kWeightPrefetch = 3;   // weight-fragment prefetch distance in k-steps (taps)
 
 // 8-channel sub-chunks staged per barrier (LDS budget 2 * 8*SUBS * W floats, <= 36 KiB)
 constexpr int subs_for(int ks, int w) {
@@ -166,11 +160,7 @@ constexpr int subs_for(int ks, int w) {
 // min 3 waves per SIMD for the 64-accumulator tiles, 4 for the smaller ones: caps VGPR+AGPR so that several workgroups
 // stay resident per CU (their MFMA phases cover each other's staging / barrier phases)
 template <int KS, int DIL, int WM, int WN, int MT, int NT>
-#ifdef FV_X_WAVES4
-__global__ __launch_bounds__(256, (NT >= 4 ? 2 : 4)) void conv_mfma_kernel(const ConvParams p) {
-#else
 __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void conv_mfma_kernel(const ConvParams p) {
-#endif
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int N_BLK = WN * NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
@@ -179,17 +169,12 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     // barrier so that the MFMA run between two barriers stays long
     constexpr int SUBS = subs_for(KS, W);
     constexpr int CH = kChunk * SUBS;
-#ifdef FV_X_PRIVATE
-    // experiment: every wave stages its own (NT*32 + SPAN)-column window -> no workgroup barrier in the main loop
-    constexpr bool PRIV = (KS >= 3);
-#else
-    constexpr bool PRIV = false;
-#endif
-    constexpr int WL = PRIV ? NT * 32 + SPAN : W;      // window width staged by one staging group
+    // (a wave-private window variant without workgroup barriers measured 17 % slower: extra halo traffic)
+    constexpr int WL = W;                              // window width staged by the workgroup
     constexpr int TOT = CH * WL;
-    constexpr int NTHR = PRIV ? 64 : 256;              // threads per staging group
+    constexpr int NTHR = 256;                          // threads staging the window
     constexpr int NE = (TOT + NTHR - 1) / NTHR;        // staged elements per thread
-    __shared__ float xs[PRIV ? 4 : 1][2][TOT];
+    __shared__ float xs[2][TOT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -219,8 +204,8 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     // zero-padded channels past C_in — come back as 0 from the hardware bounds check (no clamp / select / 64-bit VALU).
     unsigned st_voff[NE];
     int st_row[KS == 1 ? NE : 1];   // flat mode only: the descriptor spans every batch item, rows are checked explicitly
-    const int sid = PRIV ? lane : tid;
-    const int tbase = n0 - p.pad_l + (PRIV ? wn * (NT * 32) : 0);
+    const int sid = tid;
+    const int tbase = n0 - p.pad_l;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         int e = sid + i * NTHR;
@@ -291,7 +276,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
             dst[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
     };
-    const int b_lane = (lane >> 5) * WL + (PRIV ? 0 : wn * (NT * 32)) + (lane & 31);
+    const int b_lane = (lane >> 5) * WL + wn * (NT * 32) + (lane & 31);
 
     auto load_b = [&](float (&dst)[4][NT], const float* xsb, int sub, int j) {
 #pragma unroll
@@ -314,42 +299,19 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 #pragma unroll
     for (int d = 0; d < DA; ++d) load_a(aq[d], d * 1024);
     for (int c = 0; c < nch; ++c) {
-        float* xsb = xs[PRIV ? wave : 0][c & 1];
-#if !(FV_X_ABLATE & 4)
+        float* xsb = xs[c & 1];
         store_chunk(xsb, c);
-#endif
-#if !(FV_X_ABLATE & 8)
-        if (!PRIV) __syncthreads();   // PRIV: a wave's LDS ops execute in order and nothing is shared across waves
-#endif
-#if !(FV_X_ABLATE & 4)
+        __syncthreads();
         if (c + 1 < nch) load_chunk(c + 1);
-#endif
         // readfirstlane: c is wave-uniform, this makes the weight offsets provably so (else hipcc wraps every buffer
         // load in a waterfall loop)
         const int gchunk_b = __builtin_amdgcn_readfirstlane((c * STEPS + DA) * 1024);
         load_b(b_cur, xsb, 0, 0);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
-#if (FV_X_ABLATE & 1)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) aq[DA][i] = make_float4(0.5f, 0.25f, -0.5f, 0.125f);   // ablation: no weight loads
-#else
             load_a(aq[DA], gchunk_b + st * 1024);
-#endif
-#if (FV_X_ABLATE & 2)
-            if (st + 1 < STEPS) {
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-                    for (int jn = 0; jn < NT; ++jn) b_nxt[pp][jn] = (float)(lane + pp);   // ablation: no LDS fragment reads
-            }
-#else
             if (st + 1 < STEPS) load_b(b_nxt, xsb, (st + 1) / KS, (st + 1) % KS);
-#endif
             __builtin_amdgcn_sched_barrier(0);
-#ifdef FV_X_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
 #pragma unroll
@@ -360,9 +322,6 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[pp][jn], acc[i][jn], 0, 0, 0);
                 }
             }
-#ifdef FV_X_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int d = 0; d < DA; ++d)
