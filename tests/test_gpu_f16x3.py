@@ -235,3 +235,22 @@ def test_f16x3_wide_fused_pair_matches_oracle(C, k, d, B, T):
     err = np.abs(y.cpu().numpy() - ref).max()
     scale = max(np.abs(ref).max(), 1.0)
     assert err <= 1e-4 and err <= 2e-5 * scale, f"max|d|={err:.3e} scale={scale:.2f}"
+
+
+CONVT = [(512, 256, 16, 8, 2, 86), (256, 128, 16, 8, 1, 300), (128, 64, 8, 2, 2, 500), (64, 64, 4, 2, 1, 333), (128, 64, 16, 8, 1, 1)]
+
+
+@pytest.mark.parametrize("cin,cout,k,u,B,T", CONVT)
+def test_f16x3_conv_transpose_matches_oracle(cin, cout, k, u, B, T):
+    """The up-sampling ConvTranspose1d (polyphase form: rows = (c_out, phase), scatter store) on the split-fp16 path."""
+    from vocoder_amd import _lib
+    rng = np.random.default_rng(cin + cout + k + u)
+    x = (rng.normal(size=(B, cin, T)) * 2.0).astype(np.float32)
+    w = (rng.normal(size=(cin, cout, k)) / np.sqrt(cin * k / u)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    ref = orc.conv_transpose1d(orc.silu(x), w, b, stride=u, padding=(k - u) // 2)
+    y, kern = _conv(w, b, x, None, "f16x3", transposed=True, stride=u, padding=(k - u) // 2, pre_act=_lib.FV_ACT_SILU)
+    assert kern.startswith("conv_f16x3"), kern
+    assert y.shape == ref.shape
+    err = np.abs(y - ref).max()
+    assert err <= 1e-4 and err <= 2e-5 * max(np.abs(ref).max(), 1.0), f"max|d|={err:.3e} ({kern})"

@@ -24,6 +24,7 @@
 #pragma once
 
 #include <algorithm>
+#include <climits>
 #include <cstdlib>
 #include <type_traits>
 
@@ -46,20 +47,27 @@ __device__ __forceinline__ void conv_epilogue_bulk(const ConvParams& p, f32x16 (
     const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
     const bool has_res = p.res != nullptr;
     const bool accum = p.out_mode == OUT_ACCUM;
-    int coff[NTE];   // element offset of the column (row part excluded), -1 when the column does not exist
+    int coff[NTE];   // element offset of the column (row part excluded), INT_MIN when the column does not exist
 #pragma unroll
     for (int jn = 0; jn < NTE; ++jn) {
         const int n = ncol0 + jn * 32;
-        if (p.flat) {
+        if (p.convt) {
+            coff[jn] = n < p.N ? n * p.u - p.pad_t : INT_MIN;   // polyphase: column q lands at t = q*u - padding + phase
+        } else if (p.flat) {
             const int bb = n / p.N;
-            coff[jn] = n < p.n_total ? bb * (int)p.y_bstride + (n - bb * p.N) : -1;
+            coff[jn] = n < p.n_total ? bb * (int)p.y_bstride + (n - bb * p.N) : INT_MIN;
         } else {
-            coff[jn] = n < p.N ? n : -1;
+            coff[jn] = n < p.N ? n : INT_MIN;
         }
     }
     auto offset = [&](int r, int jn) -> unsigned {   // byte offset of accumulator register r of n-tile jn, or the OOB marker
         const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        return (m < p.M && coff[jn] >= 0) ? (unsigned)(m * p.N + coff[jn]) * 4u : 0xFFFFFFFFu;
+        if (p.convt) {   // row m = (c_out, phase)
+            const int co = m / p.u, ph = m - co * p.u;
+            const int t = coff[jn] + ph;
+            return (m < p.M && coff[jn] != INT_MIN && t >= 0 && t < p.Tout) ? (unsigned)(co * p.Tout + t) * 4u : 0xFFFFFFFFu;
+        }
+        return (m < p.M && coff[jn] != INT_MIN) ? (unsigned)(m * p.N + coff[jn]) * 4u : 0xFFFFFFFFu;
     };
     float rv[NTE][16];
     if (has_res) {
@@ -106,7 +114,7 @@ __device__ __forceinline__ void conv_epilogue_bulk(const ConvParams& p, f32x16 (
 constexpr int kChunk16 = 16;
 constexpr int kF16WeightPrefetch = 2;   // weight prefetch distance in k-blocks (one block = 16 channels x 1 tap = 3*NT MFMAs)
 // 16-channel sub-chunks staged per barrier: pointwise convs have one k-block per sub-chunk, so they stage four
-constexpr int f16_subs_for(int ks) { return ks == 1 ? 4 : 1; }
+constexpr int f16_subs_for(int ks) { return ks == 1 ? 4 : ((ks == 2 || ks == 4) ? 2 : 1); }
 
 template <int KS, int DIL, int WM, int WN, int NT>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) {
@@ -315,7 +323,7 @@ inline bool launch_f16x3_cfg(const ConvParams& p, int cfg, int batch, hipStream_
     switch (cfg) {
         case SPLIT_128x128: hipLaunchKernelGGL((conv_f16x3_kernel<KS, DIL, 4, 1, 4>), dim3(grid), dim3(256), 0, s, p); return true;
         case SPLIT_64x256:
-            if constexpr (KS != 1) {   // (a 256-column window of four sub-chunks would not fit the static LDS limit)
+            if constexpr (KS == 3 || KS >= 5) {   // (a 256-column window of several sub-chunks would not fit the static LDS limit)
                 hipLaunchKernelGGL((conv_f16x3_kernel<KS, DIL, 2, 2, 4>), dim3(grid), dim3(256), 0, s, p);
                 return true;
             }

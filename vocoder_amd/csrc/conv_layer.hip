@@ -78,7 +78,8 @@ static float pack_conv_weights_f16x3(const std::vector<float>& wc, int M, int Ci
 
 // layers the split-fp16 kernels cover: MFMA-bound stride-1 convs with the ResBlock kernel sizes
 static bool f16x3_eligible(bool transposed, int c_in, int M, int ks, int dil) {
-    if (transposed) return false;
+    // polyphase transposed convs: 1, 2 or 4 taps per phase, M = C_out * stride rows
+    if (transposed) return c_in >= 32 && c_in % 16 == 0 && M >= 128 && (ks == 1 || ks == 2 || ks == 4);
     // pointwise convs (ConvNeXt GEMMs): whole 64-channel LDS chunks, 128-row tiles
     if (ks == 1) return dil == 1 && c_in >= 64 && c_in % 64 == 0 && M >= 128;
     return c_in >= 32 && M >= 64 && (ks == 3 || ks == 7 || ks == 11) && (dil == 1 || dil == 3 || dil == 5);
@@ -140,7 +141,7 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
     FV_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
     if (with_f16x3 && f16x3_eligible(transposed, c_in, L.M, L.ks, L.dil)) {
         L.nch16 = (c_in + 15) / 16;
-        if (L.ks == 1) L.nch16 = (L.nch16 + 3) / 4 * 4;   // whole LDS chunks of four sub-chunks
+        if (L.ks <= 4) L.nch16 = (L.nch16 + 3) / 4 * 4;   // whole LDS chunks of two / four sub-chunks
         std::vector<_Float16> ph;
         L.w_scale = pack_conv_weights_f16x3(wc, L.M, c_in, L.ks, L.m_pad, L.nch16, ph);
         FV_HIP_CHECK(hipMalloc(&L.d_wph, ph.size() * sizeof(_Float16)));
@@ -218,7 +219,7 @@ static fv_status conv_layer_run_f16x3(const ConvLayer& L, const ConvRun& r, Conv
     const int mb = cfg == SPLIT_64x256 ? 64 : 128, nb = cfg == SPLIT_64x256 ? 256 : 128;
     // pointwise convs have no halo: batch and time flatten into one column axis (no per-item partial tiles)
     int launch_batch = r.batch;
-    if (L.ks == 1 && L.pad_l == 0 && r.batch > 1 &&
+    if (!L.transposed && L.ks == 1 && L.pad_l == 0 && r.batch > 1 &&
         (long long)r.batch * std::max<long long>((long long)L.c_in * r.t_in, (long long)L.c_out * p.N) < (1LL << 30)) {
         p.flat = 1;
         p.n_total = p.N * r.batch;
@@ -230,6 +231,8 @@ static fv_status conv_layer_run_f16x3(const ConvLayer& L, const ConvRun& r, Conv
     bool ok = false;
     switch (L.ks) {
         case 1: ok = launch_conv_f16x3_k1(p, cfg, launch_batch, stream); break;
+        case 2:
+        case 4: ok = launch_conv_f16x3_misc(p, cfg, r.batch, stream); break;
         case 3: ok = launch_conv_f16x3_k3(p, cfg, r.batch, stream); break;
         case 7: ok = launch_conv_f16x3_k7(p, cfg, r.batch, stream); break;
         case 11: ok = launch_conv_f16x3_k11(p, cfg, r.batch, stream); break;
@@ -244,12 +247,13 @@ static fv_status conv_layer_run_f16x3(const ConvLayer& L, const ConvRun& r, Conv
     set_last_kernel(name);
     if (prof_idx >= 0) {
         const long long tout = L.out_len(r.t_in);
-        const double macs = (double)L.c_in * L.c_out * L.k * (double)tout * r.batch;
+        const double macs = (double)L.c_in * L.c_out * L.k * (L.transposed ? (double)r.t_in : (double)tout) * r.batch;
         double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
         if (r.res) elems += (double)L.c_out * tout;
         if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
         char lbl[160];
-        std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d grid=%d", name, L.c_in, L.c_out, launch_batch * p.m_blks * p.n_tiles);
+        std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d%s grid=%d", name, L.c_in, L.c_out, L.transposed ? " convT" : "",
+                      launch_batch * p.m_blks * p.n_tiles);
         prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
     }
     FV_HIP_CHECK(hipGetLastError());

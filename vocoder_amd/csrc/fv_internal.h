@@ -141,6 +141,7 @@ bool launch_conv_generic(const ConvParams& p, int cfg, int batch, hipStream_t s,
 enum SplitCfg : int { SPLIT_128x128 = 0, SPLIT_64x256 = 1, SPLIT_COUNT };
 bool launch_conv_f16x3_k1(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_f16x3_k3(const ConvParams& p, int cfg, int batch, hipStream_t s);
+bool launch_conv_f16x3_misc(const ConvParams& p, int cfg, int batch, hipStream_t s);   // k = 2, 4 (polyphase transposed convs)
 bool launch_conv_f16x3_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_f16x3_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
 
