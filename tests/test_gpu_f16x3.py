@@ -209,7 +209,7 @@ def test_f16x3_range_contract_is_loud():
     assert np.isfinite(y32).all() and np.abs(y32 - ref).max() <= 1e-2   # 1e5-scale values: fp32 roundoff
 
 
-PAIR_CASES = [(128, 11, 1, 2, 300), (128, 11, 5, 1, 517), (128, 7, 3, 2, 200), (128, 3, 1, 1, 1000), (128, 3, 5, 3, 97),
+PAIR_CASES = [(256, 11, 5, 1, 688), (256, 3, 1, 2, 100), (256, 7, 3, 1, 87), (128, 11, 1, 2, 300), (128, 11, 5, 1, 517), (128, 7, 3, 2, 200), (128, 3, 1, 1, 1000), (128, 3, 5, 3, 97),
               (64, 11, 3, 2, 700), (64, 7, 1, 1, 255), (64, 3, 3, 2, 129), (64, 11, 5, 1, 40), (128, 7, 5, 1, 5)]
 
 

@@ -386,7 +386,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
 bool pair_f16x3_supported(const ConvLayer& c1, const ConvLayer& c2) {
     const int C = c1.c_in;
     return c1.precision == FV_PRECISION_F16X3 && c2.precision == FV_PRECISION_F16X3 && c1.d_wph && c2.d_wph &&
-           !c1.transposed && !c2.transposed && (C == 128 || C == 64) && c1.c_out == C && c2.c_in == C && c2.c_out == C &&
+           !c1.transposed && !c2.transposed && (C == 256 || C == 128 || C == 64) && c1.c_out == C && c2.c_in == C && c2.c_out == C &&
            c1.k == c2.k && (c1.k == 3 || c1.k == 7 || c1.k == 11) && (c1.dil == 1 || c1.dil == 3 || c1.dil == 5) && c2.dil == 1 &&
            c1.padding == (c1.k - 1) / 2 * c1.dil && c2.padding == (c2.k - 1) / 2 && getenv("FV_NO_F16X3_PAIRS") == nullptr;
 }
@@ -432,7 +432,7 @@ static fv_status conv_pair_run_f16x3(const ConvLayer& c1, const ConvLayer& c2, c
     std::snprintf(name, sizeof(name), "pair_f16x3<k=%d d=%d C=%d>", c1.k, c1.dil, C);
     set_last_kernel(name);
     if (prof_idx >= 0) {
-        const int tt = (C == 128 ? 96 : 128) - (c1.k - 1);
+        const int tt = (C == 64 ? 128 : 96) - (c1.k - 1);
         char lbl[128];
         std::snprintf(lbl, sizeof(lbl), "%s grid=%d", name, batch * ((t + tt - 1) / tt));
         const double macs = 2.0 * C * C * c1.k * (double)t * batch;

@@ -8,8 +8,8 @@
 // straight into LDS, in the very layout c2 reads its B fragments from — so the pair moves ~3.5 tensor passes instead of
 // ~5.5, c2 needs no staging and no barriers at all, and one prologue / epilogue serves two convs.
 //
-// Workgroup = 4 waves, C rows (WM m-tiles of 32) x N_H = WN * NT * 32 intermediate columns; each wave owns 32 rows x NT
-// n-tiles (C = 128: 4 x 1 waves, NT = 3, N_H = 96; C = 64: 2 x 2 waves, NT = 2, N_H = 128).  Of the N_H columns c2 produces,
+// Workgroup = 4 (8) waves, C rows (WM m-tiles of 32) x N_H = WN * NT * 32 intermediate columns; each wave owns 32 rows x NT
+// n-tiles (C = 128: 4 x 1 waves, NT = 3, N_H = 96; C = 64: 2 x 2 waves, NT = 2, N_H = 128; C = 256: 8 x 1 waves, NT = 3).  Of the N_H columns c2 produces,
 // the last KS - 1 would need intermediate columns of the next tile and are dropped: tiles advance by TT = N_H - (KS - 1)
 // (8 - 10 % redundant MFMA work at k = 11, 2 % at k = 3).
 // LDS (dynamic): x window (two 16-channel chunks in flight, as in the per-layer kernel) + the intermediate planes
@@ -34,8 +34,9 @@ struct PairF16Geom {
 };
 
 template <int KS, int DIL1, int WM, int WN, int NT>
-__global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairF16Params p) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(WM * WN * 64, 2) void pair_f16x3_kernel(const PairF16Params p) {
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+    constexpr int THREADS = WM * WN * 64;
     constexpr int C = WM * 32;
     constexpr int KG = C / 8;                           // channel groups of 8 (one 16-byte LDS slot per column)
     constexpr int N_H = WN * NT * 32;                   // intermediate columns per workgroup
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairF16Params 
     constexpr int H2 = (KS - 1) / 2, H1 = H2 * DIL1;
     constexpr int W1 = N_H + (KS - 1) * DIL1;           // staged x columns per channel row
     constexpr int ITEMS = 2 * W1;
-    constexpr int NE = (ITEMS + 255) / 256;
+    constexpr int NE = (ITEMS + THREADS - 1) / THREADS;
     constexpr int PLANE = 2 * W1;
     constexpr int HPLANE = KG * N_H;                    // slots per intermediate plane
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairF16Params 
     const unsigned row_b = (unsigned)p.T * 4u;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        int e = tid + i * 256;
+        int e = tid + i * THREADS;
         const bool in_tile = e < ITEMS;
         e = in_tile ? e : ITEMS - 1;
         const int h = e / W1;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairF16Params 
     auto store_chunk = [&](h8* dst) {   // silu, split, pack (element-wise on purpose, see conv_f16x3_impl.h)
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * THREADS;
             h8 hi, lo;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -309,11 +310,11 @@ inline void launch_pair_f16x3_one(PairF16Params q, int batch, hipStream_t s) {
                                   (int)G::LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL((pair_f16x3_kernel<KS, DIL1, WM, WN, NT>), dim3(batch * q.n_tiles), dim3(256), G::LDS_BYTES, s, q);
+    hipLaunchKernelGGL((pair_f16x3_kernel<KS, DIL1, WM, WN, NT>), dim3(batch * q.n_tiles), dim3(WM * WN * 64), G::LDS_BYTES, s, q);
 }
 
-// C = 128: 128 rows x 96 intermediate columns (68 KB of LDS at k = 11, d = 5); C = 64: 64 rows x 128 columns (56 KB): two
-// workgroups per CU either way
+// C = 128: 128 rows x 96 intermediate columns; C = 64: 64 rows x 128 columns (49 / 33 KB of LDS, two workgroups per CU);
+// C = 256: 256 rows x 96 columns on eight waves (98 KB, one workgroup per CU)
 template <int KS, int DIL1>
 inline bool launch_pair_f16x3_cfg(const PairF16Params& p, int C, int batch, hipStream_t s) {
     if (C == 128) {
@@ -322,6 +323,10 @@ inline bool launch_pair_f16x3_cfg(const PairF16Params& p, int C, int batch, hipS
     }
     if (C == 64) {
         launch_pair_f16x3_one<KS, DIL1, 2, 2, 2>(p, batch, s);
+        return true;
+    }
+    if (C == 256) {   // eight waves (one m-tile each), 98 KB of intermediate planes: one workgroup per CU, two waves per SIMD
+        launch_pair_f16x3_one<KS, DIL1, 8, 1, 3>(p, batch, s);
         return true;
     }
     return false;
