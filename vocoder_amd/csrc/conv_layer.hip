@@ -477,7 +477,7 @@ fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x
     std::snprintf(name, sizeof(name), "resblock_pair<k=%d d=%d C=%d>", c1.k, c1.dil, C);
     set_last_kernel(name);
     if (prof_idx >= 0) {
-        const int tt = kPairCols / C - (c1.k - 1);   // PairGeom::TT
+        const int tt = std::max(128, kPairCols / C) - (c1.k - 1);   // PairGeom::TT
         char lbl[128];
         std::snprintf(lbl, sizeof(lbl), "%s grid=%d", name, batch * ((t + tt - 1) / tt));
         // algorithmic work: the two convs' MACs; bytes: x once + output once (+ accumulate operand)

@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int KS, int DIL, int C>
 struct PairGeom {
-    static constexpr int W1 = kPairCols / C;            // c1 output columns per workgroup (256 at C=16, 128 at C=32: 18-27 KB of LDS)
+    static constexpr int W1 = kPairCols / C < 128 ? 128 : kPairCols / C;   // c1 output columns per workgroup (256 at C=16, 128 at C=32 / 64)
     static constexpr int TT = W1 - (KS - 1);            // final output columns per workgroup
     static constexpr int H1 = (KS - 1) / 2 * DIL, H2 = (KS - 1) / 2, HP = H1 + H2;
     static constexpr int WA_RAW = W1 + (KS - 1) * DIL;  // staged x columns
@@ -381,11 +381,26 @@ static bool launch_pair_c(const PairParams& p, int C, int batch, hipStream_t s) 
         hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 32>), dim3(batch * q.n_tiles), dim3(256), lds, s, q);
         return true;
     }
+    if (C == 64) {
+        using G = PairGeom<KS, DIL, 64>;
+        PairParams q = p;
+        q.n_tiles = (p.T + G::TT - 1) / G::TT;
+        const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)resblock_pair32_kernel<KS, DIL, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 64>), dim3(batch * q.n_tiles), dim3(256), lds, s, q);
+        return true;
+    }
     return false;
 }
 
+// C = 64 fuses only at k = 3 (measured per stage: k = 3 -20 %, k = 7 +42 %, k = 11 worse still: with two m-tiles per wave and a
+// single n-tile the resident-K kernel re-fetches every weight fragment per wave, which only the short kernel can afford)
 bool pair_supported(int C, int ks, int dil) {
-    if (C != 16 && C != 32) return false;
+    if (C != 16 && C != 32 && !(C == 64 && ks == 3)) return false;
     if (ks != 3 && ks != 7 && ks != 11) return false;
     return dil == 1 || dil == 3 || dil == 5;
 }
