@@ -152,7 +152,7 @@ constexpr int kWeightPrefetch = 3;   // weight-fragment prefetch distance in k-s
 
 // 8-channel sub-chunks staged per barrier (LDS budget 2 * 8*SUBS * W floats, <= 36 KiB)
 constexpr int subs_for(int ks, int w) {
-    int s = ks <= 2 ? 4 : (ks <= 4 ? 2 : 1);   // measured: 16-channel chunks +4 % for k=3, -3 % for k >= 7
+    int s = ks <= 3 ? 4 : (ks <= 4 ? 2 : 1);   // measured: k=3 +4 % with 16-channel chunks, +2 % more with 32; -3 % for k >= 7
     while (s > 1 && s * kChunk * w > 4608) s /= 2;
     return s;
 }
