@@ -210,7 +210,8 @@ def test_f16x3_range_contract_is_loud():
 
 
 PAIR_CASES = [(256, 11, 5, 1, 688), (256, 3, 1, 2, 100), (256, 7, 3, 1, 87), (128, 11, 1, 2, 300), (128, 11, 5, 1, 517), (128, 7, 3, 2, 200), (128, 3, 1, 1, 1000), (128, 3, 5, 3, 97),
-              (64, 11, 3, 2, 700), (64, 7, 1, 1, 255), (64, 3, 3, 2, 129), (64, 11, 5, 1, 40), (128, 7, 5, 1, 5)]
+              (64, 11, 3, 2, 700), (64, 7, 1, 1, 255), (64, 3, 3, 2, 129), (64, 11, 5, 1, 40), (128, 7, 5, 1, 5),
+              (32, 11, 5, 2, 1000), (32, 7, 3, 1, 374), (32, 3, 1, 3, 383), (32, 11, 1, 1, 9), (32, 7, 5, 2, 2049)]
 
 
 @pytest.mark.parametrize("C,k,d,B,T", PAIR_CASES)

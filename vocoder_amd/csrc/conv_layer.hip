@@ -82,8 +82,12 @@ static bool f16x3_eligible(bool transposed, int c_in, int M, int ks, int dil) {
     if (transposed) return c_in >= 32 && c_in % 16 == 0 && M >= 128 && (ks == 1 || ks == 2 || ks == 4);
     // pointwise convs (ConvNeXt GEMMs): whole 64-channel LDS chunks, 128-row tiles
     if (ks == 1) return dil == 1 && c_in >= 64 && c_in % 64 == 0 && M >= 128;
-    return c_in >= 32 && M >= 64 && (ks == 3 || ks == 7 || ks == 11) && (dil == 1 || dil == 3 || dil == 5);
+    // M = 32 (the C = 32 ResBlock convs): planes are packed for the fused pair kernel only, see f16x3_per_layer_ok()
+    return c_in >= 32 && M >= 32 && (ks == 3 || ks == 7 || ks == 11) && (dil == 1 || dil == 3 || dil == 5);
 }
+
+// the per-layer split-fp16 kernel tiles 64 or 128 rows; narrower layers keep the fp32 kernel unless a fused pair takes them
+static bool f16x3_per_layer_ok(const ConvLayer& L) { return L.M >= 64; }
 
 fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, int k, int dil, int padding,
                             int stride, const float* host_w, const float* host_bias, bool with_f16x3) {
@@ -311,7 +315,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     p.acc_scale = 1.0f;
 
     // the split kernels implement the pre-activations of the MFMA-bound layers only (none / SiLU)
-    if (L.precision == FV_PRECISION_F16X3 && L.d_wph && (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU))
+    if (L.precision == FV_PRECISION_F16X3 && L.d_wph && f16x3_per_layer_ok(L) && (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU))
         return conv_layer_run_f16x3(L, r, p, stream);
 
     int cfg = choose_tile(L.M, p.N, r.batch);
@@ -386,7 +390,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
 bool pair_f16x3_supported(const ConvLayer& c1, const ConvLayer& c2) {
     const int C = c1.c_in;
     return c1.precision == FV_PRECISION_F16X3 && c2.precision == FV_PRECISION_F16X3 && c1.d_wph && c2.d_wph &&
-           !c1.transposed && !c2.transposed && (C == 256 || C == 128 || C == 64) && c1.c_out == C && c2.c_in == C && c2.c_out == C &&
+           !c1.transposed && !c2.transposed && (C == 256 || C == 128 || C == 64 || C == 32) && c1.c_out == C && c2.c_in == C && c2.c_out == C &&
            c1.k == c2.k && (c1.k == 3 || c1.k == 7 || c1.k == 11) && (c1.dil == 1 || c1.dil == 3 || c1.dil == 5) && c2.dil == 1 &&
            c1.padding == (c1.k - 1) / 2 * c1.dil && c2.padding == (c2.k - 1) / 2 && getenv("FV_NO_F16X3_PAIRS") == nullptr;
 }
@@ -432,7 +436,7 @@ static fv_status conv_pair_run_f16x3(const ConvLayer& c1, const ConvLayer& c2, c
     std::snprintf(name, sizeof(name), "pair_f16x3<k=%d d=%d C=%d>", c1.k, c1.dil, C);
     set_last_kernel(name);
     if (prof_idx >= 0) {
-        const int tt = (C == 64 ? 128 : 96) - (c1.k - 1);
+        const int tt = (C == 32 ? kPairF16ColsC32 : C == 64 ? 128 : 96) - (c1.k - 1);
         char lbl[128];
         std::snprintf(lbl, sizeof(lbl), "%s grid=%d", name, batch * ((t + tt - 1) / tt));
         const double macs = 2.0 * C * C * c1.k * (double)t * batch;

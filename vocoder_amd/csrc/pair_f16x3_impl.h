@@ -329,6 +329,10 @@ inline bool launch_pair_f16x3_cfg(const PairF16Params& p, int C, int batch, hipS
         launch_pair_f16x3_one<KS, DIL1, 8, 1, 3>(p, batch, s);
         return true;
     }
+    if (C == 32) {    // a single m-tile: the four waves split the columns (A fragments reused across NT n-tiles only)
+        launch_pair_f16x3_one<KS, DIL1, 1, 4, kPairF16NtC32>(p, batch, s);
+        return true;
+    }
     return false;
 }
 
