@@ -97,7 +97,7 @@ def roofline_from_profile(table: list[dict], repeats: int) -> dict:
     t_s = top["avg_ms"] * 1e-3
     tf = top["flops_per_launch"] / t_s / 1e12
     gbs = top["bytes_per_launch"] / t_s / 1e9
-    peak_tf = PEAK_F16X3_TFLOPS if top["kernel"].startswith("conv_f16x3") else PEAK_MFMA_F32_TFLOPS
+    peak_tf = PEAK_F16X3_TFLOPS if top["kernel"].startswith(("conv_f16x3", "pair_f16x3")) else PEAK_MFMA_F32_TFLOPS
     t_mfma = top["flops_per_launch"] / (peak_tf * 1e12)
     t_hbm = top["bytes_per_launch"] / (PEAK_HBM_GBS * 1e9)
     # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.py);
