@@ -45,6 +45,9 @@ CONV_CASES = [
     (6, 4, 5, 2, 2, 61), (2, 2, 3, 2, 1, 9), (1, 3, 13, 1, 1, 40),
     (512, 512, 13, 1, 1, 50),        # firefly pre conv
     (128, 512, 1, 1, 2, 94), (512, 128, 1, 1, 2, 94),   # ConvNeXt pointwise
+    # enough columns for the flattened (batch, time) tiles: even T stages column pairs, odd T single columns;
+    # C_in = 100 ends in a partial 32-channel chunk
+    (100, 512, 1, 1, 40, 94), (512, 128, 1, 1, 70, 47), (128, 256, 1, 1, 64, 50), (64, 1026, 1, 1, 33, 98),
 ]
 
 

@@ -327,7 +327,8 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         const int cfg_flat = choose_tile(L.M, (long long)p.N * r.batch, 1);
         if (cfg_flat < TILE_SPLITK_32x64) {
             cfg = cfg_flat;
-            p.flat = 1;
+            // 2: even T and 8-byte aligned rows -> the kernel stages column pairs (conv_mfma_impl.h)
+            p.flat = (p.N % 2 == 0 && ((uintptr_t)r.x & 7) == 0) ? 2 : 1;
             p.n_total = p.N * r.batch;
             launch_batch = 1;
         }

@@ -27,6 +27,7 @@ namespace fv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
@@ -206,25 +207,47 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     int st_row[KS == 1 ? NE : 1];   // flat mode only: the descriptor spans every batch item, rows are checked explicitly
     const int sid = tid;
     const int tbase = n0 - p.pad_l;
+    // Pointwise convs over flattened columns with an even T (p.flat == 2): columns (2q, 2q + 1) are adjacent in memory,
+    // 8-byte aligned and never straddle two batch items, so the window is staged as pairs — half the vector-memory and
+    // LDS-write instructions (staging is 15 - 25 % of a k = 1 launch: one chunk feeds only 4 k-steps, not 4 * KS).
+    // Pair q of the chunk window is elements (2q, 2q + 1) of the same linear [CH][WL] layout; the plan of the NE2 pairs
+    // lives in the first half of the same arrays.
+    constexpr int NE2 = KS == 1 ? (TOT / 2 + NTHR - 1) / NTHR : 1;
+    static_assert(KS != 1 || (TOT % (2 * NTHR) == 0 && NE == 2 * NE2), "pair staging covers the window exactly");
+    const bool pair2 = KS == 1 && p.flat == 2;
+    if (KS == 1 && pair2) {
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        int e = sid + i * NTHR;
-        const bool in_tile = e < TOT;
-        e = in_tile ? e : TOT - 1;
-        const int r = e / WL;
-        const int col = e - r * WL;
-        int t = tbase + col;
-        int boff = 0;
-        bool ok = in_tile;
-        if (flat) {   // column = (batch item, t)
-            ok = ok && t < p.n_total;
+        for (int i = 0; i < NE2; ++i) {
+            const int q = sid + i * NTHR;
+            const int r = q / (WL / 2);
+            int t = tbase + 2 * (q - r * (WL / 2));
+            const bool ok = t < p.n_total;
             const int bb = t / p.N;
             t -= bb * p.N;
-            boff = bb * (int)p.x_bstride;
+            st_voff[i] = ok ? (unsigned)(bb * (int)p.x_bstride + r * p.Tin + t) * 4u : 0xFFFFFFF8u;
+            st_row[KS == 1 ? i : 0] = r;
         }
-        ok = ok && t >= 0 && t < p.Tin;
-        st_voff[i] = ok ? (unsigned)(boff + r * p.Tin + t) * 4u : 0xFFFFFFFFu;
-        if (KS == 1) st_row[i < NE ? i : 0] = r;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            int e = sid + i * NTHR;
+            const bool in_tile = e < TOT;
+            e = in_tile ? e : TOT - 1;
+            const int r = e / WL;
+            const int col = e - r * WL;
+            int t = tbase + col;
+            int boff = 0;
+            bool ok = in_tile;
+            if (flat) {   // column = (batch item, t)
+                ok = ok && t < p.n_total;
+                const int bb = t / p.N;
+                t -= bb * p.N;
+                boff = bb * (int)p.x_bstride;
+            }
+            ok = ok && t >= 0 && t < p.Tin;
+            st_voff[i] = ok ? (unsigned)(boff + r * p.Tin + t) * 4u : 0xFFFFFFFFu;
+            if (KS == 1) st_row[i < NE ? i : 0] = r;
+        }
     }
     // Staging is split in two halves one chunk apart: load_chunk only ISSUES the loads (no dependent ALU, so no wait),
     // store_chunk — one chunk of MFMAs later — applies the activation and writes LDS (act(0) == 0 keeps the padding).
@@ -236,6 +259,16 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
         const long long rows = (long long)(p.Cin - cbase) * p.Tin;
         const __amdgpu_buffer_rsrc_t xrs =
             uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)((flat ? span : (rows < span ? rows : span)) * 4));
+        if (KS == 1 && pair2) {
+#pragma unroll
+            for (int i = 0; i < NE2; ++i) {
+                const unsigned off = st_row[KS == 1 ? i : 0] < p.Cin - cbase ? st_voff[i] : 0xFFFFFFF8u;
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, 0, 0);
+                stage[(2 * i) % NE] = __uint_as_float(v.x);
+                stage[(2 * i + 1) % NE] = __uint_as_float(v.y);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             unsigned off = st_voff[i];
@@ -243,17 +276,24 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
             stage[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
         }
     };
+    auto act_in = [&](float v) {
+        if (p.pre_act == FV_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        if (p.pre_act != FV_ACT_NONE) return act_apply(v, p.pre_act, p.slope);
+        return v;
+    };
     auto store_chunk = [&](float* dst, int c) {
         (void)c;
+        if (KS == 1 && pair2) {
+#pragma unroll
+            for (int i = 0; i < NE2; ++i)
+                reinterpret_cast<float2*>(dst)[sid + i * NTHR] =
+                    make_float2(act_in(stage[(2 * i) % NE]), act_in(stage[(2 * i + 1) % NE]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int e = sid + i * NTHR;
-            float v = stage[i];
-            if (p.pre_act == FV_ACT_SILU) {
-                v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-            } else if (p.pre_act != FV_ACT_NONE) {
-                v = act_apply(v, p.pre_act, p.slope);
-            }
+            const float v = act_in(stage[i]);
             if (e < TOT) dst[e] = v;
         }
     };
