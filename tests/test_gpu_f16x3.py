@@ -34,6 +34,7 @@ CASES = [
     (64, 64, 11, 3, 2, 700), (64, 64, 7, 5, 1, 1025), (64, 64, 3, 1, 3, 259),
     (48, 96, 7, 1, 2, 200),      # C_in not a multiple of 16 chunks? 48 = 3 chunks; M = 96 -> partial m-block
     (40, 64, 3, 3, 1, 77),       # C_in = 40 -> zero-padded half chunk
+    (32, 32, 11, 1, 2, 1500), (32, 32, 7, 5, 1, 255), (32, 32, 3, 3, 3, 513), (64, 32, 11, 3, 1, 300), (32, 48, 7, 1, 2, 90),   # 32 x 256 tiles
 ]
 
 

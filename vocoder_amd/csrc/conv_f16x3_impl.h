@@ -119,7 +119,7 @@ constexpr int f16_subs_for(int ks) { return ks == 1 ? 4 : ((ks == 2 || ks == 4) 
 template <int KS, int DIL, int WM, int WN, int NT>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(NT % 4 == 0, "B fragments are loaded two n-tiles at a time, the epilogue handles four");
+    static_assert(NT % 2 == 0, "B fragments are loaded two n-tiles at a time");
     constexpr int N_BLK = WN * NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
     constexpr int W = N_BLK + SPAN;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) 
     }
 
     // epilogue in groups of four n-tiles (two for the 128-accumulator tile: bounds the live registers)
-    constexpr int EG = NT >= 8 ? 2 : 4;
+    constexpr int EG = (NT >= 8 || NT < 4) ? 2 : 4;
 #pragma unroll
     for (int hf = 0; hf < NT / EG; ++hf) {
         f32x16(&sub)[EG] = reinterpret_cast<f32x16(&)[EG]>(acc[0][hf * EG]);
@@ -325,6 +325,12 @@ inline bool launch_f16x3_cfg(const ConvParams& p, int cfg, int batch, hipStream_
         case SPLIT_64x256:
             if constexpr (KS == 3 || KS >= 5) {   // (a 256-column window of several sub-chunks would not fit the static LDS limit)
                 hipLaunchKernelGGL((conv_f16x3_kernel<KS, DIL, 2, 2, 4>), dim3(grid), dim3(256), 0, s, p);
+                return true;
+            }
+            return false;
+        case SPLIT_32x256:   // a single m-tile of rows (C_out = 32): the four waves split the columns, two n-tiles each
+            if constexpr (KS == 3 || KS >= 5) {
+                hipLaunchKernelGGL((conv_f16x3_kernel<KS, DIL, 1, 4, 2>), dim3(grid), dim3(256), 0, s, p);
                 return true;
             }
             return false;

@@ -82,12 +82,11 @@ static bool f16x3_eligible(bool transposed, int c_in, int M, int ks, int dil) {
     if (transposed) return c_in >= 32 && c_in % 16 == 0 && M >= 128 && (ks == 1 || ks == 2 || ks == 4);
     // pointwise convs (ConvNeXt GEMMs): whole 64-channel LDS chunks, 128-row tiles
     if (ks == 1) return dil == 1 && c_in >= 64 && c_in % 64 == 0 && M >= 128;
-    // M = 32 (the C = 32 ResBlock convs): planes are packed for the fused pair kernel only, see f16x3_per_layer_ok()
     return c_in >= 32 && M >= 32 && (ks == 3 || ks == 7 || ks == 11) && (dil == 1 || dil == 3 || dil == 5);
 }
 
-// the per-layer split-fp16 kernel tiles 64 or 128 rows; narrower layers keep the fp32 kernel unless a fused pair takes them
-static bool f16x3_per_layer_ok(const ConvLayer& L) { return L.M >= 64; }
+// the per-layer split-fp16 kernel tiles 32, 64 or 128 rows (f16x3_eligible() keeps narrower layers out)
+static bool f16x3_per_layer_ok(const ConvLayer& L) { return L.M >= 32; }
 
 fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, int k, int dil, int padding,
                             int stride, const float* host_w, const float* host_bias, bool with_f16x3) {
@@ -210,7 +209,7 @@ static int choose_tile(int M, long long N, int batch) {
 
 static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64", "splitK32x32"};
 
-static const char* const kSplitNames[SPLIT_COUNT] = {"128x128", "64x256"};
+static const char* const kSplitNames[SPLIT_COUNT] = {"128x128", "64x256", "32x256"};
 
 // f16x3 precision mode: tile choice + dispatch of the split-fp16 kernel (p already describes the layer call)
 static fv_status conv_layer_run_f16x3(const ConvLayer& L, const ConvRun& r, ConvParams& p, hipStream_t stream) {
@@ -219,8 +218,8 @@ static fv_status conv_layer_run_f16x3(const ConvLayer& L, const ConvRun& r, Conv
     p.nch16_real = (L.c_in + 15) / 16;
     p.acc_scale = 1.0f / L.w_scale;
     // wave tile 32 x 128 either way (64 accumulator registers); waves stacked along M when there are >= 128 rows
-    const int cfg = L.M <= 64 ? SPLIT_64x256 : SPLIT_128x128;
-    const int mb = cfg == SPLIT_64x256 ? 64 : 128, nb = cfg == SPLIT_64x256 ? 256 : 128;
+    const int cfg = L.M <= 32 ? SPLIT_32x256 : L.M <= 64 ? SPLIT_64x256 : SPLIT_128x128;
+    const int mb = cfg == SPLIT_32x256 ? 32 : cfg == SPLIT_64x256 ? 64 : 128, nb = cfg == SPLIT_128x128 ? 128 : 256;
     // pointwise convs have no halo: batch and time flatten into one column axis (no per-item partial tiles)
     int launch_batch = r.batch;
     if (!L.transposed && L.ks == 1 && L.pad_l == 0 && r.batch > 1 &&

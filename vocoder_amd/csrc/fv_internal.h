@@ -138,7 +138,7 @@ bool launch_conv_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_misc(const ConvParams& p, int cfg, int batch, hipStream_t s);   // k=2, 4, 5, 13 ...
 bool launch_conv_generic(const ConvParams& p, int cfg, int batch, hipStream_t s, size_t* lds_bytes);
 // f16x3 precision mode: tiles of the split-fp16 kernel (rows x columns per workgroup)
-enum SplitCfg : int { SPLIT_128x128 = 0, SPLIT_64x256 = 1, SPLIT_COUNT };
+enum SplitCfg : int { SPLIT_128x128 = 0, SPLIT_64x256 = 1, SPLIT_32x256 = 2, SPLIT_COUNT };
 bool launch_conv_f16x3_k1(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_f16x3_k3(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_f16x3_misc(const ConvParams& p, int cfg, int batch, hipStream_t s);   // k = 2, 4 (polyphase transposed convs)
