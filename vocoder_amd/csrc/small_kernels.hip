@@ -138,24 +138,21 @@ __device__ __forceinline__ f32x2 sin_squared2(f32x2 z) {
     return sn * sn;
 }
 
-__global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                          const float* __restrict__ alpha_eff,
-                                                          const float* __restrict__ inv_beta,
-                                                          const float* __restrict__ up_taps,
-                                                          const float* __restrict__ down_taps, int C, int T, int n_tiles) {
-    __shared__ float xs[AA_TT + 16];
-    __shared__ __attribute__((aligned(8))) float A[2 * (AA_TT + 8)];
+// EDGE = false: the tile and its 6-sample halo lie inside [0, T) — no clamps, no bounds tests, fixed trip counts (the
+// clamp / compare / loop-carried VALU work was about a quarter of the kernel's instructions).  Same arithmetic order either way.
+template <bool EDGE>
+__device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, float* __restrict__ yr, float* __restrict__ xs,
+                                              float* __restrict__ A, const float* __restrict__ up_taps,
+                                              const float* __restrict__ down_taps, float al, float ib, int t0, int T) {
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x % n_tiles;
-    const long long row = blockIdx.x / n_tiles;  // b * C + c
-    const int c = (int)(row % C);
-    const int t0 = tile * AA_TT;
-    const float* xr = x + row * T;
-    for (int e = tid; e < AA_TT + 13; e += 256) {
+    auto load_x = [&](int e) {
         int t = t0 - 6 + e;
-        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);   // replicate padding of the up-sampler input
+        if (EDGE) t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);   // replicate padding of the up-sampler input
         xs[e] = xr[t];
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < AA_TT / 256; ++i) load_x(tid + i * 256);
+    if (tid < 13) load_x(AA_TT + tid);
     // taps as uniform register pairs (the up-sampler's gain of 2 folded in)
     f32x2 upp[6], dnp[6];
 #pragma unroll
@@ -163,12 +160,14 @@ __global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restric
         upp[q] = f32x2{2.0f * up_taps[2 * q + 1], 2.0f * up_taps[2 * q]};
         dnp[q] = f32x2{down_taps[2 * q], down_taps[2 * q + 1]};
     }
-    const float al = alpha_eff[c], ib = inv_beta[c];
     __syncthreads();
-    for (int m = tid; m < AA_TT + 6; m += 256) {
+    auto up_snake = [&](int m) {
         const int h = t0 - 3 + m;
-        const int hc = h < 0 ? 0 : (h > T - 1 ? T - 1 : h);
-        const int xi = hc - t0 + 6;   // position of x[hc] in xs
+        int xi = m + 3;   // position of x[h] in xs
+        if (EDGE) {
+            const int hc = h < 0 ? 0 : (h > T - 1 ? T - 1 : h);
+            xi = hc - t0 + 6;
+        }
         f32x2 u = {0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
@@ -176,16 +175,22 @@ __global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restric
             u = __builtin_elementwise_fma(upp[q], xp, u);
         }
         f32x2 a = __builtin_elementwise_fma((f32x2)(ib), sin_squared2(u * al), u);
-        // replicate padding of the down-sampler input: n < 0 -> a[0] (even sample of h = 0), n > 2T-1 -> a[2T-1]
-        if (h < 0) a.y = a.x;
-        if (h > T - 1) a.x = a.y;
+        if (EDGE) {   // replicate padding of the down-sampler input: n < 0 -> a[0] (even sample of h = 0), n > 2T-1 -> a[2T-1]
+            if (h < 0) a.y = a.x;
+            if (h > T - 1) a.x = a.y;
+        }
         *reinterpret_cast<f32x2*>(&A[2 * m]) = a;
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < AA_TT / 256; ++i) up_snake(tid + i * 256);
+    if (tid < 6) up_snake(AA_TT + tid);
     __syncthreads();
     // y[t0 + i] = sum_q dn[2q] * odd(h = t0+i+q-3) + dn[2q+1] * even(h = t0+i+q-2);  position h -> m = h - (t0 - 3)
-    for (int i = tid; i < AA_TT; i += 256) {
-        const int t = t0 + i;
-        if (t >= T) break;
+    // (raw buffer ops for the row traffic and one opaque LDS base per position — immediate ds_read2 offsets — were tried:
+    //  fewer VALU instructions, 4 % slower)
+#pragma unroll
+    for (int k = 0; k < AA_TT / 256; ++k) {
+        const int i = tid + k * 256;
         f32x2 s2 = {0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
@@ -193,8 +198,26 @@ __global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restric
             const f32x2 ap = {A[2 * mo + 1], A[2 * mo + 2]};
             s2 = __builtin_elementwise_fma(dnp[q], ap, s2);
         }
-        y[row * T + t] = s2.x + s2.y;
+        if (!EDGE || t0 + i < T) yr[t0 + i] = s2.x + s2.y;
     }
+}
+
+__global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const float* __restrict__ alpha_eff,
+                                                          const float* __restrict__ inv_beta,
+                                                          const float* __restrict__ up_taps,
+                                                          const float* __restrict__ down_taps, int C, int T, int n_tiles) {
+    __shared__ float xs[AA_TT + 16];
+    __shared__ __attribute__((aligned(8))) float A[2 * (AA_TT + 8)];
+    const int tile = blockIdx.x % n_tiles;
+    const long long row = blockIdx.x / n_tiles;  // b * C + c
+    const int c = (int)(row % C);
+    const int t0 = tile * AA_TT;
+    const float al = alpha_eff[c], ib = inv_beta[c];
+    if (t0 >= 6 && t0 + AA_TT + 6 < T)
+        aa_snake_tile<false>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T);
+    else
+        aa_snake_tile<true>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T);
 }
 
 fv_status launch_aa_snake(const float* x, float* y, const float* alpha_eff, const float* inv_beta, const float* up_taps,
