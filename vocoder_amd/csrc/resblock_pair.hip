@@ -21,9 +21,7 @@ namespace fv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef FV_X_PAIRWAVES
-#define FV_X_PAIRWAVES 2   // min waves per SIMD the register allocator must leave room for
-#endif
+constexpr int kPairMinWaves = 2;   // min waves per SIMD the register allocator must leave room for
 
 template <int KS, int DIL, int C>
 struct PairGeom {
@@ -173,7 +171,7 @@ __device__ __forceinline__ void gemm16_resident(const float4* __restrict__ w, in
 // C = 32 (MT = 1) and C = 64 (MT = 2): 32x32x2 MFMA.  Each wave owns NT n-tiles of 32 columns and all m-tiles.
 // ---------------------------------------------------------------------------------------------------------------
 template <int KS, int DIL, int C>
-__global__ __launch_bounds__(256, FV_X_PAIRWAVES) void resblock_pair32_kernel(const PairParams p) {
+__global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair32_kernel(const PairParams p) {
     using G = PairGeom<KS, DIL, C>;
     constexpr int MT = C / 32;
     constexpr int NT = G::W1 / 32 / 4;   // n-tiles per wave
@@ -278,7 +276,7 @@ __global__ __launch_bounds__(256, FV_X_PAIRWAVES) void resblock_pair32_kernel(co
 // Weights packed as [tap][lane] float4 = the four channel quads of that tap.
 // ---------------------------------------------------------------------------------------------------------------
 template <int KS, int DIL>
-__global__ __launch_bounds__(256, FV_X_PAIRWAVES) void resblock_pair16_kernel(const PairParams p) {
+__global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair16_kernel(const PairParams p) {
     constexpr int C = 16;
     using G = PairGeom<KS, DIL, C>;
     constexpr int NT = G::W1 / 16 / 4;   // 8 n-tiles of 16 columns per wave
