@@ -212,7 +212,10 @@ def test_f16x3_range_contract_is_loud():
 
 PAIR_CASES = [(256, 11, 5, 1, 688), (256, 3, 1, 2, 100), (256, 7, 3, 1, 87), (128, 11, 1, 2, 300), (128, 11, 5, 1, 517), (128, 7, 3, 2, 200), (128, 3, 1, 1, 1000), (128, 3, 5, 3, 97),
               (64, 11, 3, 2, 700), (64, 7, 1, 1, 255), (64, 3, 3, 2, 129), (64, 11, 5, 1, 40), (128, 7, 5, 1, 5),
-              (32, 11, 5, 2, 1000), (32, 7, 3, 1, 374), (32, 3, 1, 3, 383), (32, 11, 1, 1, 9), (32, 7, 5, 2, 2049)]
+              (32, 11, 5, 2, 1000), (32, 7, 3, 1, 374), (32, 3, 1, 3, 383), (32, 11, 1, 1, 9), (32, 7, 5, 2, 2049),
+              # C = 16: two output samples per MFMA row (pair16_f16x3.hip); every (k, d), tile edges, tiny clips
+              (16, 11, 1, 2, 2000), (16, 11, 3, 1, 1504), (16, 11, 5, 2, 500), (16, 7, 1, 1, 506), (16, 7, 3, 2, 1018),
+              (16, 7, 5, 1, 2), (16, 3, 1, 3, 510), (16, 3, 3, 1, 4096), (16, 3, 5, 2, 38)]
 
 
 @pytest.mark.parametrize("C,k,d,B,T", PAIR_CASES)
@@ -237,6 +240,23 @@ def test_f16x3_wide_fused_pair_matches_oracle(C, k, d, B, T):
     err = np.abs(y.cpu().numpy() - ref).max()
     scale = max(np.abs(ref).max(), 1.0)
     assert err <= 1e-4 and err <= 2e-5 * scale, f"max|d|={err:.3e} scale={scale:.2f}"
+
+
+def test_f16x3_pair16_needs_an_even_length_and_falls_back_to_fp32_otherwise():
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import FusedConv
+    rng = np.random.default_rng(5)
+    w = (rng.normal(size=(16, 16, 7)) / 10.0).astype(np.float32)
+    c1 = FusedConv(w, None, dilation=3, padding=9).set_precision("f16x3")
+    c2 = FusedConv(w, None, padding=3).set_precision("f16x3")
+    for T, want in ((300, "pair_f16x3"), (301, "resblock_pair")):
+        x = rng.normal(size=(2, 16, T)).astype(np.float32)
+        y = c1.pair(c2, torch.from_numpy(x).to(_dev()))
+        torch.cuda.synchronize()
+        assert _lib.last_kernel().startswith(want), (T, _lib.last_kernel())
+        h = orc.conv1d(orc.silu(x), w, None, dilation=3, padding=9)
+        ref = x + orc.conv1d(orc.silu(h), w, None, dilation=1, padding=3)
+        assert np.abs(y.cpu().numpy() - ref).max() <= 1e-5
 
 
 CONVT = [(512, 256, 16, 8, 2, 86), (256, 128, 16, 8, 1, 300), (128, 64, 8, 2, 2, 500), (64, 64, 4, 2, 1, 333), (128, 64, 16, 8, 1, 1)]

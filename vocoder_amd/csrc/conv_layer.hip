@@ -150,6 +150,33 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
         FV_HIP_CHECK(hipMalloc(&L.d_wph, ph.size() * sizeof(_Float16)));
         FV_HIP_CHECK(hipMemcpy(L.d_wph, ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     }
+    if (with_f16x3 && !transposed && c_in == 16 && c_out == 16 && (k == 3 || k == 7 || k == 11)) {
+        // pair16_f16x3.hip: row (s, co) of tap block jj in [0, k] holds w[co][:, jj - s] (two output samples per channel
+        // share one activation fragment); 32x32x16 A-fragment order, (wh, wl) planes, + 4 zero blocks of prefetch overrun
+        float wmax = 0.f;
+        for (size_t i = 0; i < (size_t)16 * 16 * k; ++i) wmax = std::max(wmax, std::fabs(host_w[i]));
+        int e = 0;
+        if (wmax > 0.f && std::isfinite(wmax)) {
+            (void)std::frexp(wmax, &e);
+            e = 14 - e;   // wmax * 2^e in [2^13, 2^14), as in pack_conv_weights_f16x3
+        }
+        L.w_scale = std::ldexp(1.0f, e);
+        std::vector<_Float16> ph((size_t)(k + 1 + 4) * 2 * 64 * 8, (_Float16)0.f);
+        for (int jj = 0; jj <= k; ++jj)
+            for (int l = 0; l < 64; ++l) {
+                const int s = (l & 31) >> 4, co = l & 15, j = jj - s;
+                if (j < 0 || j >= k) continue;
+                for (int i = 0; i < 8; ++i) {
+                    const int ci = 8 * (l >> 5) + i;
+                    const float w = host_w[((size_t)co * 16 + ci) * k + j] * L.w_scale;   // exact: power-of-two scale
+                    const _Float16 wh = (_Float16)w;
+                    ph[(((size_t)jj * 2 + 0) * 64 + l) * 8 + i] = wh;
+                    ph[(((size_t)jj * 2 + 1) * 64 + l) * 8 + i] = (_Float16)(w - (float)wh);
+                }
+            }
+        FV_HIP_CHECK(hipMalloc(&L.d_wph16, ph.size() * sizeof(_Float16)));
+        FV_HIP_CHECK(hipMemcpy(L.d_wph16, ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    }
     if (!transposed && c_in == 16 && c_out == 16) {
         // v_mfma_f32_16x16x4_f32 A fragments: [tap][lane] float4, .q = W[lane & 15][4q + (lane >> 4)][tap]
         std::vector<float> p16((size_t)k * 64 * 4);
@@ -168,6 +195,8 @@ void conv_layer_destroy(ConvLayer& L) {
     if (L.d_bias) (void)hipFree(L.d_bias);
     if (L.d_wp16) (void)hipFree(L.d_wp16);
     if (L.d_wph) (void)hipFree(L.d_wph);
+    if (L.d_wph16) (void)hipFree(L.d_wph16);
+    L.d_wph16 = nullptr;
     L.d_wph = nullptr;
     L.d_wp16 = nullptr;
     L.d_wp = nullptr;
@@ -447,10 +476,57 @@ static fv_status conv_pair_run_f16x3(const ConvLayer& c1, const ConvLayer& c2, c
     return FV_OK;
 }
 
+// C = 16 in f16x3 mode (pair16_f16x3.hip): needs an even T and 8-byte aligned tensors (paired loads / stores); anything else
+// keeps the exact-fp32 pair kernel
+static bool pair16_f16x3_usable(const ConvLayer& c1, const ConvLayer& c2, const float* x, const float* y, int t) {
+    return c1.precision == FV_PRECISION_F16X3 && c2.precision == FV_PRECISION_F16X3 && c1.d_wph16 && c2.d_wph16 &&
+           c1.k == c2.k && (c1.dil == 1 || c1.dil == 3 || c1.dil == 5) && c2.dil == 1 &&
+           c1.padding == (c1.k - 1) / 2 * c1.dil && c2.padding == (c2.k - 1) / 2 && t % 2 == 0 &&
+           (((uintptr_t)x | (uintptr_t)y) & 7) == 0 && x != y && (long long)16 * t < (1LL << 30) &&
+           getenv("FV_NO_F16X3_PAIRS") == nullptr;
+}
+
+static fv_status conv_pair16_run_f16x3(const ConvLayer& c1, const ConvLayer& c2, const float* x, float* y, int batch, int t,
+                                       int out_mode, float out_scale, hipStream_t stream) {
+    PairF16Params p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = x;
+    p.y = y;
+    p.w1h = c1.d_wph16;
+    p.w2h = c2.d_wph16;
+    p.b1 = c1.d_bias;
+    p.b2 = c2.d_bias;
+    p.s1 = 1.0f / c1.w_scale;
+    p.s2 = 1.0f / c2.w_scale;
+    p.T = t;
+    p.nch16 = 1;
+    p.out_mode = out_mode;
+    p.out_scale = out_scale;
+    const int prof_idx = prof_begin(stream);
+    if (!launch_pair16_f16x3(p, c1.k, c1.dil, batch, stream)) {
+        set_error("conv_pair_run: no f16x3 pair kernel for (C=16 k=%d d=%d)", c1.k, c1.dil);
+        return FV_ERR_UNSUPPORTED;
+    }
+    static thread_local char name[96];
+    std::snprintf(name, sizeof(name), "pair_f16x3<k=%d d=%d C=16>", c1.k, c1.dil);
+    set_last_kernel(name);
+    if (prof_idx >= 0) {
+        const int tt = pair16_f16x3_tile(c1.k, c1.dil);
+        char lbl[128];
+        std::snprintf(lbl, sizeof(lbl), "%s grid=%d", name, batch * ((t + tt - 1) / tt));
+        const double macs = 2.0 * 16 * 16 * c1.k * (double)t * batch;
+        const double elems = (out_mode == OUT_ACCUM ? 4.0 : 3.0) * 16 * (double)t * batch;
+        prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * 4.0 + 2.0 * 16 * 16 * c1.k * 4.0);
+    }
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
 fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x, float* y, int batch, int t, int out_mode,
                         float out_scale, hipStream_t stream) {
     const int C = c1.c_in;
     if (pair_f16x3_supported(c1, c2)) return conv_pair_run_f16x3(c1, c2, x, y, batch, t, out_mode, out_scale, stream);
+    if (pair16_f16x3_usable(c1, c2, x, y, t)) return conv_pair16_run_f16x3(c1, c2, x, y, batch, t, out_mode, out_scale, stream);
     const bool shape_ok = !c1.transposed && !c2.transposed && c1.c_out == C && c2.c_in == C && c2.c_out == C &&
                           c1.k == c2.k && c2.dil == 1 && c1.padding == (c1.k - 1) / 2 * c1.dil && c2.padding == (c2.k - 1) / 2;
     if (!shape_ok || !pair_supported(C, c1.k, c1.dil)) {

@@ -92,6 +92,7 @@ struct ConvLayer {
     int M = 0, ks = 0, pad_l = 0, nchunk = 0, nchunk_real = 0, m_pad = 0;
     float4* d_wp = nullptr;
     float4* d_wp16 = nullptr;  // 16x16x4-fragment layout, only for 16 -> 16 channel Conv1d (fused pair kernel)
+    void* d_wph16 = nullptr;   // f16x3 mode, 16 -> 16 channel Conv1d: (wh, wl) planes of the two-samples-per-row layout (pair16_f16x3.hip)
     void* d_wph = nullptr;     // f16x3 mode: (wh, wl, wh * 2^-11) fp16 planes in 32x32x16 fragment order (optional)
     float w_scale = 1.f;       // s_w: power of two folded into those planes
     int nch16 = 0;

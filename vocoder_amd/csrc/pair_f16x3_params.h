@@ -25,5 +25,8 @@ struct PairF16Params {
 bool launch_pair_f16x3_k3(const PairF16Params& p, int C, int dil1, int batch, hipStream_t s);
 bool launch_pair_f16x3_k7(const PairF16Params& p, int C, int dil1, int batch, hipStream_t s);
 bool launch_pair_f16x3_k11(const PairF16Params& p, int C, int dil1, int batch, hipStream_t s);
+// C = 16 (pair16_f16x3.hip): w1h / w2h are ConvLayer::d_wph16 planes; T must be even, x / y 8-byte aligned
+bool launch_pair16_f16x3(const PairF16Params& p, int ks, int dil1, int batch, hipStream_t s);
+int pair16_f16x3_tile(int ks, int dil1);
 
 }  // namespace fv
