@@ -234,7 +234,8 @@ FV_API fv_status fv_conv_forward(fv_conv* c, const float* d_x, float* d_y, const
                           int32_t t_in, void* stream);
 /* One ResBlock1 iteration in a single launch: y = x + c2(silu(c1(silu(x)))) (hifigan.py:102-107).  c1 is the dilated
  * conv, c2 the dilation-1 conv; both C -> C with the same odd kernel size and 'same' padding; exact-fp32 kernels for C in {16, 32},
- * k in {3, 7, 11} and (C, k) = (64, 3); split-fp16 kernels for C in {64, 128, 256} when both layers are set to FV_PRECISION_F16X3;
+ * k in {3, 7, 11} and (C, k) = (64, 3); split-fp16 kernels for C in {16, 32, 64, 128, 256} when both layers are set to FV_PRECISION_F16X3 (C = 16: even t and
+ * 8-byte aligned tensors, otherwise the fp32 kernel runs);
  * dilation in {1, 3, 5} (else FV_ERR_UNSUPPORTED).  d_y must not alias d_x. */
 FV_API fv_status fv_conv_pair_forward(fv_conv* c1, fv_conv* c2, const float* d_x, float* d_y, int32_t batch, int32_t t,
                                       void* stream);
