@@ -24,6 +24,9 @@ def key_of(kernel_name: str, grid_threads: int):
     if m:
         wg = 64 * int(m.group(3)) * int(m.group(4))   # C = 256 runs eight waves
         return f"pair_f16x3 k={m.group(1)} d={m.group(2)} C={32 * int(m.group(3))} grid={grid_threads // wg}"
+    m = re.search(r"pair16_f16x3_kernel<(\d+), (\d+)>", kernel_name)
+    if m:
+        return f"pair_f16x3 k={m.group(1)} d={m.group(2)} C=16 grid={blocks}"
     m = re.search(r"resblock_pair16_kernel<(\d+), (\d+)>", kernel_name)
     if m:
         return f"resblock_pair k={m.group(1)} d={m.group(2)} C=16 grid={blocks}"
