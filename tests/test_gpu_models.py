@@ -287,7 +287,10 @@ def test_refinegan_default_config_vs_oracle():
         eng(torch.from_numpy(mel).to(dev))   # template + noise are mandatory
 
 
-@pytest.mark.parametrize("dims,T,B", [([24, 100], 3, 2), ([72, 200, 520], 33, 1), ([130], 1, 3)])
+@pytest.mark.parametrize("dims,T,B", [([24, 100], 3, 2), ([72, 200, 520], 33, 1), ([130], 1, 3),
+                                      # widths that leave whole 64-channel chunks of the kernel's 256 / 512 / 1024 register
+                                      # budget unused (Firefly's 384 did: uninitialised registers reached the variance)
+                                      ([320], 12, 2), ([384], 40, 3), ([640, 192], 64, 4), ([448, 896], 5, 1)])
 def test_convnext_odd_widths_and_short_clips_vs_oracle(dims, T, B):
     """Channel counts that are not multiples of the 64-row LDS chunks of the tiled dwconv+LN kernel, clips shorter than its
     32-column tile (and than the 7-tap halo)."""

@@ -113,3 +113,27 @@ def test_logmel_frontend_module_and_wav_to_wav():
     assert out.shape == (3, 1, 40 * 512) and torch.isfinite(out).all()
     with pytest.raises(Exception):
         m(torch.zeros(1, 1, 100, device="cuda"))     # shorter than the reflect padding
+
+
+def test_firefly_gan_base_full_size_runs_and_f16x3_agrees():
+    """The shipped Firefly composition (firefly-gan-base.yaml: ConvNeXt 128..512 -> HiFiGAN head, num_mels 512, k = 13
+    pre / post convs) at full size: too big for the CPU oracle in a test, so check the size-independent properties —
+    finite, bounded by the tanh, batch items independent — and that the opt-in f16x3 engine lands on the same waveform."""
+    from vocoder_amd import _lib, synthetic as syn
+    from vocoder_amd.engine import Engine, convnext_config, upsampler_config
+    cfg = dict(syn.FIREFLY_BASE_44K)
+    sd = syn.firefly_state_dict(cfg, 0)
+    mel = torch.from_numpy(syn.synthetic_mel(3, 128, 40, 7)).cuda()
+    outs = {}
+    for prec in ("f32", "f16x3"):
+        eng = Engine(_lib.FV_MODEL_FIREFLY, backbone=convnext_config(**cfg["backbone"]), ups=upsampler_config(**cfg["head"]),
+                     state_dict=sd, precision=prec)
+        y = eng(mel)
+        torch.cuda.synchronize()
+        assert tuple(y.shape) == (3, 1, 40 * 512) and bool(torch.isfinite(y).all()) and float(y.abs().max()) <= 1.0
+        y1 = eng(mel[1:2].contiguous())
+        torch.cuda.synchronize()
+        assert float((y1 - y[1:2]).abs().max()) <= 2e-6     # same clip alone: tile choice may differ, values may not
+        outs[prec] = y.clone()
+        eng.close()
+    assert float((outs["f32"] - outs["f16x3"]).abs().max()) <= 1e-4

@@ -37,6 +37,11 @@ eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), h
              state_dict=syn.vocos_state_dict(cfg, 0), precision=PREC)
 run("vocos-24k", eng, torch.from_numpy(syn.synthetic_mel(128, 80, 94, 2)).cuda(), 24000)
 del eng
+cfg = dict(syn.FIREFLY_BASE_44K)   # the composition the reference ships scripts for (firefly-gan-base.yaml), 32 one-second clips
+eng = Engine(_lib.FV_MODEL_FIREFLY, backbone=convnext_config(**cfg["backbone"]), ups=upsampler_config(**cfg["head"]),
+             state_dict=syn.firefly_state_dict(cfg, 0), precision=PREC)
+run("firefly-gan-base-44k", eng, torch.from_numpy(syn.synthetic_mel(32, 128, 86, 5)).cuda(), 44100)
+del eng
 # RefineGAN (reference ctor defaults: 44.1 kHz, hop 256, start_channels 16): 16 one-second clips
 cfg = dict(syn.REFINEGAN_44K)
 eng = Engine(_lib.FV_MODEL_REFINEGAN, refine=refinegan_config(**cfg), state_dict=syn.refinegan_state_dict(cfg, 0), precision=PREC)

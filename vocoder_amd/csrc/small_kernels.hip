@@ -435,6 +435,8 @@ __global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __rest
     };
 
     float h[CMAX / 8];
+#pragma unroll
+    for (int i = 0; i < CMAX / 8; ++i) h[i] = 0.f;
     float s = 0.f;
     issue(0);
     commit(0);
@@ -475,8 +477,10 @@ __global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __rest
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
             const int c = ch * DWT_CH + cg + 8 * qq;
-            const float d = h[ch * 8 + qq] - mean;
-            qv = fmaf(d, d, c < C ? qv : qv - d * d);
+            // chunks past ceil(C / 64) were never computed (h holds whatever the registers held): they must not enter
+            // the sum in any form — a "subtract it back out" formulation turned such garbage into NaN for C = 320 / 384 / 640
+            const float d = c < C ? h[ch * 8 + qq] - mean : 0.f;
+            qv = fmaf(d, d, qv);
         }
     red[cg][col] = qv;
     __syncthreads();

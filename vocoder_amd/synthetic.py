@@ -198,6 +198,15 @@ VOCOS_24K = dict(
                   drop_path_rate=0.4, kernel_size=7),
     head=dict(dim=1024, n_fft=1024, hop_length=256, win_length=1024, padding="same"))
 
+# Firefly-GAN base (reference configs/model/generator/firefly-gan-base.yaml:1-20 with resolution/44100_512_2048.yaml: 128 mels,
+# hop 512): ConvNeXt backbone (128 mel bins -> 512 features) feeding a HiFiGAN head with k = 13 pre / post convs
+FIREFLY_BASE_44K = dict(
+    backbone=dict(input_channels=128, depths=[3, 3, 9, 3], dims=[128, 256, 384, 512], drop_path_rate=0.2, kernel_size=7),
+    head=dict(hop_length=512, upsample_rates=[8, 8, 2, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4, 4],
+              resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+              num_mels=512, upsample_initial_channel=512, use_template=False,
+              pre_conv_kernel_size=13, post_conv_kernel_size=13))
+
 
 # RefineGANGenerator (/root/reference/fish_vocoder/modules/generators/refinegan.py:182-323) — no YAML in the reference; these
 # are its ctor defaults
