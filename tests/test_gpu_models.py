@@ -386,3 +386,63 @@ def test_two_engines_on_two_host_threads_match_single_threaded_results():
     assert not errs, errs
     for g, w in zip(got, want):
         assert torch.equal(g, w)
+
+
+_RES = {"24000_256_1024": dict(num_mels=100, n_fft=1024, hop_length=256, win_length=1024),
+        "44100_512_2048": dict(num_mels=128, n_fft=2048, hop_length=512, win_length=2048)}
+
+
+@pytest.mark.parametrize("name,depths,dims,res", [
+    ("vocos-small", [8], [512], "24000_256_1024"),                              # configs/model/generator/vocos-small.yaml
+    ("vocos-small", [8], [512], "44100_512_2048"),
+    ("vocos", [1, 1, 2, 1], [128, 256, 512, 1024], "44100_512_2048"),            # vocos.yaml widths at the 44.1 kHz resolution
+    ("vocos-huge", [1, 1, 1, 1], [352, 704, 1408, 2816], "24000_256_1024"),      # vocos-huge.yaml widths (depths cut for the oracle)
+    ("vocos-small-vae decoder", [2, 1], [512, 1024], "24000_256_1024"),
+])
+def test_shipped_vocos_configs_vs_oracle(name, depths, dims, res):
+    """The widths / resolutions the reference ships YAMLs for (not only the benchmark config) against the CPU oracle."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config
+    r = _RES[res]
+    cfg = dict(backbone=dict(input_channels=r["num_mels"], depths=depths, dims=dims, kernel_size=7),
+               head=dict(dim=dims[-1], n_fft=r["n_fft"], hop_length=r["hop_length"], win_length=r["win_length"], padding="same"))
+    sd = syn.vocos_state_dict(cfg, seed=len(name))
+    mel = syn.synthetic_mel(2, r["num_mels"], 9, seed=2)
+    ref = orc.vocos_forward(sd, cfg, mel)
+    eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), head=istft_head_config(**cfg["head"]),
+                 state_dict=sd)
+    y = _fwd(eng, mel)
+    assert y.shape == ref.shape == (2, 1, 9 * r["hop_length"])
+    err = np.abs(y - ref).max()
+    assert err <= TOL, f"{name} @ {res}: max|d| = {err:.3e} (ref max {np.abs(ref).max():.3f})"
+
+
+def test_shipped_hifigan_vae_decoder_config_vs_oracle():
+    """configs/model/generator/hifigan-vae.yaml decoder: hop 640 = 8 * 5 * 4 * 2 * 2 (a stride-5 and a stride-4 stage),
+    512 input features."""
+    cfg = dict(hop_length=640, upsample_rates=[8, 5, 4, 2, 2], upsample_kernel_sizes=[16, 10, 8, 4, 4],
+               resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=512,
+               upsample_initial_channel=512, use_template=False, pre_conv_kernel_size=7, post_conv_kernel_size=7)
+    sd = syn.hifigan_state_dict(cfg, 2)
+    mel = syn.synthetic_mel(2, 512, 3, seed=8) * 0.2
+    ref = orc.hifigan_forward(sd, cfg, mel)
+    y = _fwd(_hifigan_engine(cfg, sd), mel)
+    # k - stride is odd at the stride-5 stage (padding (10 - 5) // 2 = 2): the reference emits 5 T + 1 samples there, so
+    # 640 T + 16 in total (checked against the reference itself: 1936 for T = 3, oracle within 6e-8 of it)
+    assert y.shape == ref.shape == (2, 1, 3 * 640 + 16)
+    assert np.abs(y - ref).max() <= TOL, np.abs(y - ref).max()
+
+
+def test_istft_head_with_a_hop_that_does_not_divide_n_fft_vs_oracle():
+    """resolution/24000_2048_3072.yaml: hop 2048, n_fft = win = 3072 (1.5 hops per frame)."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, istft_head_config
+    cfg = dict(dim=64, n_fft=3072, hop_length=2048, win_length=3072, padding="same")
+    sd = syn.istft_head_state_dict(cfg, 1)
+    x = (np.random.default_rng(3).normal(size=(2, 64, 5)) * 0.5).astype(np.float32)
+    ref = orc.istft_head_forward(sd, cfg, x)
+    eng = Engine(_lib.FV_MODEL_ISTFT_HEAD, head=istft_head_config(**cfg), state_dict=sd)
+    y = _fwd(eng, x)
+    assert y.shape == (2, 1, 5 * 2048) and ref.shape == (2, 5 * 2048)   # ISTFTHead returns (B, T); the engine adds the channel axis (unify.py:30-31)
+    err = np.abs(y[:, 0] - ref).max()
+    assert err <= TOL * max(1.0, np.abs(ref).max()), f"max|d| = {err:.3e} (ref max {np.abs(ref).max():.3f})"
