@@ -120,7 +120,7 @@ typedef struct fv_istft_head_config {
 } fv_istft_head_config;
 
 /* LogMelSpectrogram ctor kwargs (spectrogram.py:60-70); center must be 0 (the reference default), win_length == n_fft,
- * n_fft a multiple of hop_length. */
+ * hop_length <= n_fft (hop need not divide n_fft: resolution/24000_2048_3072.yaml). */
 typedef struct fv_logmel_config {
     int32_t sample_rate;
     int32_t n_fft;

@@ -137,3 +137,17 @@ def test_firefly_gan_base_full_size_runs_and_f16x3_agrees():
         outs[prec] = y.clone()
         eng.close()
     assert float((outs["f32"] - outs["f16x3"]).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("sr,n_fft,hop,n_mels", [(44100, 2048, 512, 128), (24000, 1024, 256, 100), (24000, 3072, 2048, 100)])
+def test_logmel_frontend_at_every_shipped_resolution_vs_oracle(sr, n_fft, hop, n_mels):
+    """configs/model/resolution/*.yaml through the log-mel front-end (f1), including hop 2048 with n_fft 3072."""
+    from vocoder_amd.data.transforms import LogMelSpectrogram
+    from oracle import oracle as orc
+    cfg = dict(sample_rate=sr, n_fft=n_fft, win_length=n_fft, hop_length=hop, n_mels=n_mels, f_min=0.0, f_max=sr // 2)
+    wave = (0.1 * np.random.default_rng(n_fft).normal(size=(2, hop * 7))).astype(np.float32)
+    m = LogMelSpectrogram(**cfg).eval().cuda()
+    mel = m(torch.from_numpy(wave).cuda()[:, None, :])
+    ref = orc.logmel_forward(wave, cfg)
+    assert mel.shape == ref.shape == (2, n_mels, 7)
+    assert np.abs(mel.cpu().numpy() - ref).max() <= 2e-4

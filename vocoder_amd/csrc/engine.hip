@@ -964,7 +964,10 @@ static double mel_to_hz_slaney(double m) {
 fv_status fv_engine::build_logmel(const std::string& pfx) {
     const fv_logmel_config& c = cfg.mel;
     mel.cfg = c;
-    const int N = c.n_fft, hop = c.hop_length, nb = N / 2 + 1, taps = N / hop;
+    const int N = c.n_fft, hop = c.hop_length, nb = N / 2 + 1;
+    // frames are cut into ceil(N / hop) hop-sized pieces; when hop does not divide N (resolution/24000_2048_3072.yaml) the
+    // last piece is only partly covered by the window and the rest of its DFT weights stay zero
+    const int taps = (N + hop - 1) / hop;
     mel.nb = nb;
     mel.taps = taps;
     mel.pad_l = (c.win_length - hop) / 2;        // spectrogram.py:30-33
@@ -980,11 +983,12 @@ fv_status fv_engine::build_logmel(const std::string& pfx) {
         for (int n = 0; n < N; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / N));   // hann, periodic
     }
     // STFT as a stride-1 conv over the polyphase signal: X_k[t] = sum_{r<hop} sum_{q<taps} w[qh+r] e^{-2 pi i k (qh+r)/N} yp[r][t+q]
-    std::vector<float> wst((size_t)2 * nb * hop * taps);
+    std::vector<float> wst((size_t)2 * nb * hop * taps, 0.f);
     for (int k = 0; k < nb; ++k)
         for (int r = 0; r < hop; ++r)
             for (int q = 0; q < taps; ++q) {
                 const int n = q * hop + r;
+                if (n >= N) continue;
                 const double ang = 2.0 * M_PI * (double)(((int64_t)k * n) % N) / N;
                 wst[((size_t)k * hop + r) * taps + q] = (float)(win[n] * std::cos(ang));
                 wst[((size_t)(nb + k) * hop + r) * taps + q] = (float)(-(double)win[n] * std::sin(ang));
@@ -1148,9 +1152,9 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
         }
         case FV_MODEL_LOGMEL: {
             const fv_logmel_config& m = cfg->mel;
-            if (m.n_fft < 2 || m.n_fft % 2 || m.hop_length < 1 || m.win_length != m.n_fft || m.n_fft % m.hop_length ||
+            if (m.n_fft < 2 || m.n_fft % 2 || m.hop_length < 1 || m.win_length != m.n_fft || m.hop_length > m.n_fft ||
                 m.n_mels < 1 || m.sample_rate < 2 || m.f_min < 0) {
-                set_error("logmel: need even n_fft == win_length, n_fft a multiple of hop_length, n_mels >= 1");
+                set_error("logmel: need even n_fft == win_length, hop_length <= n_fft, n_mels >= 1");
                 st = FV_ERR_INVALID;
             }
             break;
