@@ -65,6 +65,14 @@ def test_config_compose_and_instantiate():
     assert type(v.backbone).__name__ == "ConvNeXtEncoder" and v.head.n_fft == 1024
     with pytest.raises(AssertionError, match="hop_length must be 512"):
         config.build_generator("hifigan", overrides={"hop_length": 256})
+    # every generator YAML of the reference that builds a network on this path: in-group ``defaults`` (vocos-huge = vocos + own keys)
+    small, _ = config.build_generator("vocos-small", "24000_256_1024")
+    assert len(small.backbone.stages) == 1 and len(small.backbone.stages[0]) == 8 and small.head.n_fft == 1024
+    huge_cfg = config.compose_model("vocos-huge", "24000_256_1024")["model"]["generator"]
+    assert huge_cfg["backbone"]["dims"] == [352, 704, 1408, 2816] and huge_cfg["head"]["dim"] == 2816
+    assert huge_cfg["head"]["padding"] == "same" and huge_cfg["backbone"]["input_channels"] == 100 and "defaults" not in huge_cfg
+    ff, _ = config.build_generator("firefly-gan-base", "44100_512_2048")
+    assert type(ff.head).__name__ == "HiFiGANGenerator" and type(ff.backbone).__name__ == "ConvNeXtEncoder"
 
 
 def test_reference_target_strings_resolve_to_dropins():

@@ -89,6 +89,35 @@ def load_yaml(path: str) -> dict:
         return yaml.safe_load(f) or {}
 
 
+def _deep_merge(base: dict, over: dict) -> dict:
+    out = dict(base)
+    for k, v in over.items():
+        out[k] = _deep_merge(out[k], v) if isinstance(v, dict) and isinstance(out.get(k), dict) else v
+    return out
+
+
+def _load_generator(root: str, name: str, _depth: int = 0) -> dict:
+    """``model/generator/<name>.yaml`` with Hydra's in-group ``defaults`` list (vocos-huge.yaml: ``[vocos, _self_]``): the
+    named siblings are merged in order, ``_self_`` marks where this file's own keys go (last when absent)."""
+    if _depth > 8:
+        raise RecursionError(f"generator config '{name}': defaults chain too deep")
+    node = dict(load_yaml(os.path.join(root, "model", "generator", f"{name}.yaml")))
+    defaults = node.pop("defaults", None)
+    if not defaults:
+        return node
+    merged: dict = {}
+    seen_self = False
+    for d in defaults:
+        if d == "_self_":
+            merged = _deep_merge(merged, node)
+            seen_self = True
+        elif isinstance(d, str):
+            merged = _deep_merge(merged, _load_generator(root, d, _depth + 1))
+        else:
+            raise ValueError(f"generator config '{name}': unsupported defaults entry {d!r}")
+    return merged if seen_self else _deep_merge(merged, node)
+
+
 def compose_model(generator: str = "hifigan", resolution: str = "44100_512_2048", overrides: dict | None = None,
                   config_root: str | None = None) -> dict:
     """Equivalent of ``model/gan.yaml``'s defaults for inference: resolution keys merged at ``model`` level
@@ -97,7 +126,7 @@ def compose_model(generator: str = "hifigan", resolution: str = "44100_512_2048"
     Returns the fully interpolated ``{"model": {...}}`` dict."""
     root = config_root or CONFIG_ROOT
     model = dict(load_yaml(os.path.join(root, "model", "resolution", f"{resolution}.yaml")))
-    model["generator"] = load_yaml(os.path.join(root, "model", "generator", f"{generator}.yaml"))
+    model["generator"] = _load_generator(root, generator)
     for key, val in (overrides or {}).items():
         cur = model
         parts = key.split(".")
