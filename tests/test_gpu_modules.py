@@ -151,3 +151,28 @@ def test_logmel_frontend_at_every_shipped_resolution_vs_oracle(sr, n_fft, hop, n
     ref = orc.logmel_forward(wave, cfg)
     assert mel.shape == ref.shape == (2, n_mels, 7)
     assert np.abs(mel.cpu().numpy() - ref).max() <= 2e-4
+
+
+def test_cli_wav_branch_matches_the_direct_pipeline(tmp_path):
+    """inference.main on a stereo .wav (test.py:50-71: channels -> batch items, log-mel on the GPU, generator) writes what
+    LogMelSpectrogram -> generator produce directly; a wrong sampling rate is refused (no resampler here)."""
+    from vocoder_amd import inference
+    gen, cfg = config.build_generator("hifigan", overrides={"num_mels": 80})
+    sd = syn.hifigan_state_dict(dict(syn.HIFIGAN_V1_44K), 3)
+    torch.save({"state_dict": {f"generator.{k}": torch.from_numpy(v) for k, v in sd.items()}}, tmp_path / "g.ckpt")
+    rng = np.random.default_rng(1)
+    wav = (0.3 * rng.normal(size=(512 * 9, 2))).astype(np.float32).clip(-1, 1)
+    (tmp_path / "in").mkdir()
+    inference.write_wav(tmp_path / "in" / "a.wav", wav, 44100)
+    inference.main(["--generator", "hifigan", "--num-mels", "80", "--ckpt-path", str(tmp_path / "g.ckpt"),
+                    "--input-path", str(tmp_path / "in"), "--output-path", str(tmp_path / "out")])
+    got, sr = inference.read_wav(tmp_path / "out" / "a.wav")
+    assert sr == 44100 and got.shape == (2, 512 * 9)
+    model = inference.build_model("hifigan", overrides={"num_mels": 80}, ckpt_path=tmp_path / "g.ckpt")
+    y, _ = inference.read_wav(tmp_path / "in" / "a.wav")
+    want = model(torch.from_numpy(y)[:, None].cuda())[0].squeeze(1).cpu().numpy()
+    assert np.abs(got - np.clip(want, -1, 1)).max() <= 2.0 / 32767
+    inference.write_wav(tmp_path / "in" / "b.wav", wav, 22050)
+    with pytest.raises(ValueError, match="does not resample"):
+        inference.main(["--generator", "hifigan", "--num-mels", "80", "--ckpt-path", str(tmp_path / "g.ckpt"),
+                        "--input-path", str(tmp_path / "in" / "b.wav"), "--output-path", str(tmp_path / "out")])

@@ -116,6 +116,11 @@ def test_lightning_checkpoint_prefix_and_mel_preparation(tmp_path):
     assert prepare_mel(torch.zeros(2, 80, 50), 80).shape == (2, 80, 50)
     write_wav(tmp_path / "a.wav", np.zeros((100, 1), np.float32), 44100)
     assert (tmp_path / "a.wav").stat().st_size == 44 + 200
+    from vocoder_amd.inference import read_wav
+    sig = np.stack([np.sin(np.arange(300) * 0.05), np.cos(np.arange(300) * 0.03)], 1).astype(np.float32) * 0.7
+    write_wav(tmp_path / "s.wav", sig, 24000)
+    back, sr = read_wav(tmp_path / "s.wav")
+    assert sr == 24000 and back.shape == (2, 300) and np.abs(back.T - sig).max() <= 2.0 / 32767   # write scales by 32767, read by 1 / 32768 (librosa)
     with pytest.raises(NotImplementedError):
         InferenceModel(torch.nn.Identity())(torch.zeros(1, 1, 8))
 
