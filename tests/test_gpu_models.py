@@ -409,12 +409,13 @@ def test_shipped_vocos_configs_vs_oracle(name, depths, dims, res):
     sd = syn.vocos_state_dict(cfg, seed=len(name))
     mel = syn.synthetic_mel(2, r["num_mels"], 9, seed=2)
     ref = orc.vocos_forward(sd, cfg, mel)
-    eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), head=istft_head_config(**cfg["head"]),
-                 state_dict=sd)
-    y = _fwd(eng, mel)
-    assert y.shape == ref.shape == (2, 1, 9 * r["hop_length"])
-    err = np.abs(y - ref).max()
-    assert err <= TOL, f"{name} @ {res}: max|d| = {err:.3e} (ref max {np.abs(ref).max():.3f})"
+    for prec in ("f32", "f16x3"):
+        eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), head=istft_head_config(**cfg["head"]),
+                     state_dict=sd, precision=prec)
+        y = _fwd(eng, mel)
+        assert y.shape == ref.shape == (2, 1, 9 * r["hop_length"])
+        err = np.abs(y - ref).max()
+        assert err <= TOL, f"{name} @ {res} ({prec}): max|d| = {err:.3e} (ref max {np.abs(ref).max():.3f})"
 
 
 def test_shipped_hifigan_vae_decoder_config_vs_oracle():
