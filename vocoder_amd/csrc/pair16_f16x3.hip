@@ -49,7 +49,7 @@ template <int KS, int DIL1>
 __global__ __launch_bounds__(256, 2) void pair16_f16x3_kernel(const PairF16Params p) {
     using G = Pair16Geom<KS, DIL1>;
     constexpr int C = 16, NT = G::NT, D = DIL1;
-    constexpr int TT = G::TT, TH = G::TH, W1 = G::W1, HW1 = G::HW1, HW2 = G::HW2;
+    constexpr int TT = G::TT, W1 = G::W1, HW1 = G::HW1, HW2 = G::HW2;
     constexpr int ITEMS = 2 * W1;                       // (channel half, sample) staging items of 8 channels each
     constexpr int NE = (ITEMS + 255) / 256;
     constexpr int KB = KS + 1;                          // tap blocks per conv
