@@ -80,6 +80,75 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const float* __restric
     }
 }
 
+// C_in -> 1 with a compile-time tap count (the generators' conv_post at full batch): the generic kernel above pays an
+// integer division per staged element, one LDS read per FMA and runtime tap loops (1 TB/s on a 90 MB input).  Here a
+// thread owns four consecutive outputs: per channel it reads its 4 + K - 1 window values with aligned ds_read_b128s and
+// runs the 4 * K FMAs against taps held in SGPRs; the slab is staged row by row (no division) with raw buffer loads whose
+// bounds check supplies the zero padding.
+constexpr int POST_TT = 1024;
+template <int K>
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int Cin, int T,
+                                                        int pre_act, int post_act, float slope, int n_tiles) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int LEAD = (PAD + 3) / 4 * 4;            // staged columns before the tile, whole float4s
+    constexpr int NV = (LEAD - PAD + 4 + K - 1 + 3) / 4;   // float4s covering a thread's window
+    constexpr int PITCH = POST_TT + LEAD + 8;          // row pitch in floats (multiple of 4)
+    __shared__ __attribute__((aligned(16))) float xs[NARROW_CH][PITCH];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
+    const int t0 = tile * POST_TT;
+    const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(x + (long long)b * Cin * T, (unsigned)((long long)Cin * T * 4));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < Cin; c0 += NARROW_CH) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NARROW_CH; ++r) {
+            const int ci = c0 + r;
+#pragma unroll
+            for (int i = 0; i < (PITCH + 255) / 256; ++i) {
+                const int col = tid + i * 256;
+                const int t = t0 - LEAD + col;
+                const bool ok = ci < Cin && t >= 0 && t < T;
+                const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? (unsigned)(ci * T + t) * 4u : 0xFFFFFFFFu, 0, 0));
+                if (col < PITCH) xs[r][col] = pre_act == FV_ACT_SILU ? v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) : act_apply(v, pre_act, slope);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NARROW_CH; ++r) {
+            if (c0 + r < Cin) {   // wave-uniform
+                float win[4 * NV];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(&xs[r][4 * tid + 4 * q]);
+                    win[4 * q] = v.x, win[4 * q + 1] = v.y, win[4 * q + 2] = v.z, win[4 * q + 3] = v.w;
+                }
+                const float* wr = w + (long long)(c0 + r) * K;   // uniform address: scalar loads
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float wv = wr[j];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(wv, win[LEAD - PAD + i + j], acc[i]);
+                }
+            }
+        }
+    }
+    const float bv = bias ? bias[0] : 0.f;
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = act_apply(acc[i] + bv, post_act, slope);
+    const int t = t0 + 4 * tid;
+    float* yb = y + (long long)b * T;
+    if (t + 3 < T && (T & 3) == 0) {
+        *reinterpret_cast<float4*>(yb + t) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (t + i < T) yb[t + i] = o[i];
+    }
+}
+
 fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int T,
                              int Cout, int k, int pad, int pre_act, int post_act, float slope, hipStream_t s) {
     if (Cout > NARROW_MAXCO || 2 * pad != k - 1) {
@@ -88,6 +157,15 @@ fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, 
     }
     // 1024-column tiles unless they leave most CUs idle (single-clip latency): then 256-column tiles
     const bool small = (long long)B * ((T + 1023) / 1024) < 2 * num_cus();
+    if (!small && Cout == 1 && (k == 7 || k == 13) && (long long)Cin * T < (1LL << 30)) {
+        const int nt = (T + POST_TT - 1) / POST_TT;
+        if (k == 7)
+            hipLaunchKernelGGL(conv_post_kernel<7>, dim3(B * nt), dim3(256), 0, s, x, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
+        else
+            hipLaunchKernelGGL(conv_post_kernel<13>, dim3(B * nt), dim3(256), 0, s, x, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
+        FV_HIP_CHECK(hipGetLastError());
+        return FV_OK;
+    }
     const int tt = small ? 256 : 1024;
     const int n_tiles = (T + tt - 1) / tt;
     const size_t lds = ((size_t)NARROW_CH * (tt + k - 1) + (size_t)Cout * NARROW_CH * k) * sizeof(float);
