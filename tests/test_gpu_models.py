@@ -447,3 +447,34 @@ def test_istft_head_with_a_hop_that_does_not_divide_n_fft_vs_oracle():
     assert y.shape == (2, 1, 5 * 2048) and ref.shape == (2, 5 * 2048)   # ISTFTHead returns (B, T); the engine adds the channel axis (unify.py:30-31)
     err = np.abs(y[:, 0] - ref).max()
     assert err <= TOL * max(1.0, np.abs(ref).max()), f"max|d| = {err:.3e} (ref max {np.abs(ref).max():.3f})"
+
+
+def test_bigvgan_long_clip_covers_the_interior_snake_tiles_vs_oracle():
+    """The anti-aliased snake takes a clamp-free path for tiles whose 1024 samples + halo lie inside the clip: stages of
+    3000 and 6000 samples have both kinds (the goldens and the 7-frame BigVGAN-24k case above only have edge tiles)."""
+    from vocoder_amd import _lib
+    cfg = dict(hop_length=4, upsample_rates=[2, 2], upsample_kernel_sizes=[4, 4], resblock_kernel_sizes=[3, 7],
+               resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5]], num_mels=12, upsample_initial_channel=32, use_template=False,
+               pre_conv_kernel_size=7, post_conv_kernel_size=7)
+    sd = syn.bigvgan_state_dict(cfg, seed=11)
+    mel = syn.synthetic_mel(2, 12, 1500, seed=6)
+    ref = orc.bigvgan_forward(sd, cfg, mel)
+    for prec in ("f32", "f16x3"):
+        from vocoder_amd.engine import Engine, upsampler_config
+        eng = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=sd, precision=prec)
+        y = _fwd(eng, mel)
+        assert y.shape == ref.shape == (2, 1, 6000)
+        assert np.abs(y - ref).max() <= TOL, (prec, np.abs(y - ref).max())
+
+
+def test_differential_fuzz_of_random_configurations():
+    """tools/fuzz_hifigan.py / tools/fuzz_vocos.py: random (but seeded) generator configurations, batch sizes and clip lengths
+    through the engine in both precisions against the oracle, plus graph capture / replay identity."""
+    import importlib.util, os
+    tools = os.path.join(os.path.dirname(__file__), "..", "tools")
+    for name, kw in (("fuzz_hifigan", dict(n_cases=6, seed=11)), ("fuzz_hifigan", dict(n_cases=2, seed=12, large=True)),
+                     ("fuzz_vocos", dict(n_cases=6, seed=13))):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(tools, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        assert mod.run(verbose=False, **kw) <= 1e-4
