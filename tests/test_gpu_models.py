@@ -473,6 +473,7 @@ def test_differential_fuzz_of_random_configurations():
     import importlib.util, os
     tools = os.path.join(os.path.dirname(__file__), "..", "tools")
     for name, kw in (("fuzz_hifigan", dict(n_cases=6, seed=11)), ("fuzz_hifigan", dict(n_cases=2, seed=12, large=True)),
+                     ("fuzz_hifigan", dict(n_cases=3, seed=15, model="bigvgan")),
                      ("fuzz_vocos", dict(n_cases=6, seed=13)), ("fuzz_refinegan", dict(n_cases=4, seed=14))):
         spec = importlib.util.spec_from_file_location(name, os.path.join(tools, name + ".py"))
         mod = importlib.util.module_from_spec(spec)

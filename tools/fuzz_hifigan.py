@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Differential fuzz: random small HiFiGAN configurations / batch sizes / clip lengths through the engine (both precisions)
-against the CPU oracle.  python tools/fuzz_hifigan.py [n_cases] [seed] [large]"""
+against the CPU oracle.  python tools/fuzz_hifigan.py [n_cases] [seed] [large] [bigvgan]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
@@ -27,26 +27,38 @@ def random_case(rng, large=False):
     return cfg, int(rng.integers(1, 4)), int(rng.integers(1, 30))
 
 
-def run(n_cases=30, seed=0, verbose=True, large=False):
+def run(n_cases=30, seed=0, verbose=True, large=False, model="hifigan"):
+    """model: "hifigan" (a third of the cases with the use_template=True branch) or "bigvgan"."""
     rng = np.random.default_rng(seed)
     worst = 0.0
     for i in range(n_cases):
         cfg, B, T = random_case(rng, large)
-        sd = syn.hifigan_state_dict(cfg, seed * 1000 + i)
-        mel = syn.synthetic_mel(B, cfg["num_mels"], T, seed + i)
-        ref = orc.hifigan_forward(sd, cfg, mel)
+        tmpl = None
+        if model == "bigvgan":
+            sd = syn.bigvgan_state_dict(cfg, seed * 1000 + i)
+            mel = syn.synthetic_mel(B, cfg["num_mels"], T, seed + i)
+            ref = orc.bigvgan_forward(sd, cfg, mel)
+        else:
+            cfg["use_template"] = bool(rng.random() < 0.34)
+            sd = syn.hifigan_state_dict(cfg, seed * 1000 + i)
+            mel = syn.synthetic_mel(B, cfg["num_mels"], T, seed + i)
+            if cfg["use_template"]:
+                tmpl = syn.synthetic_template(B, T, cfg["hop_length"], seed + i + 5)
+            ref = orc.hifigan_forward(sd, cfg, mel, template=tmpl)
+        kind = _lib.FV_MODEL_BIGVGAN if model == "bigvgan" else _lib.FV_MODEL_HIFIGAN
         for prec in ("f32", "f16x3"):
-            eng = Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**cfg), state_dict=sd, precision=prec)
+            eng = Engine(kind, ups=upsampler_config(**cfg), state_dict=sd, precision=prec)
             x = torch.from_numpy(mel).cuda()
-            y = eng(x)
-            y2 = eng(x)     # second call: the graph-capture path
-            y3 = eng(x)     # third: replay
+            tt = None if tmpl is None else torch.from_numpy(tmpl).cuda()
+            y = eng(x, None, tt)
+            y2 = eng(x, None, tt)     # second call: the graph-capture path
+            y3 = eng(x, None, tt)     # third: replay
             torch.cuda.synchronize()
             err = float(np.abs(y.cpu().numpy() - ref).max())
             same = bool(torch.equal(y, y2) and torch.equal(y, y3))
             worst = max(worst, err)
             if verbose or err > 1e-4 or not same:
-                print(f"case {i:3d} {prec:5s} B={B} T={T} C0={cfg['upsample_initial_channel']} rates={cfg['upsample_rates']} "
+                print(f"case {i:3d} {model}{'+template' if tmpl is not None else ''} {prec:5s} B={B} T={T} C0={cfg['upsample_initial_channel']} rates={cfg['upsample_rates']} "
                       f"k={cfg['upsample_kernel_sizes']} rb={cfg['resblock_kernel_sizes']} dil={cfg['resblock_dilation_sizes']} "
                       f"pre/post={cfg['pre_conv_kernel_size']}/{cfg['post_conv_kernel_size']} err={err:.2e} replay_identical={same}")
             assert y.shape == ref.shape, (y.shape, ref.shape)
@@ -58,4 +70,4 @@ def run(n_cases=30, seed=0, verbose=True, large=False):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     s = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    print("worst |d| =", run(n, s, large=len(sys.argv) > 3 and sys.argv[3] == "large"))
+    print("worst |d| =", run(n, s, large="large" in sys.argv[3:], model="bigvgan" if "bigvgan" in sys.argv[3:] else "hifigan"))
