@@ -480,3 +480,19 @@ def test_differential_fuzz_of_random_configurations():
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         assert mod.run(verbose=False, **kw) <= 1e-4
+
+
+def test_template_branch_with_a_long_first_stage_stride_vs_oracle():
+    """use_template=True with rates (2, 8, 8, 4): the first noise conv has stride 256 and 512 taps (more than 64 KiB of LDS
+    in the strided-conv kernel; found by tools/fuzz_hifigan.py)."""
+    cfg = dict(hop_length=512, upsample_rates=[2, 8, 8, 4], upsample_kernel_sizes=[4, 16, 16, 8], resblock_kernel_sizes=[3],
+               resblock_dilation_sizes=[[1, 3, 5]], num_mels=20, upsample_initial_channel=32, use_template=True,
+               pre_conv_kernel_size=7, post_conv_kernel_size=7)
+    sd = syn.hifigan_state_dict(cfg, 4)
+    mel = syn.synthetic_mel(2, 20, 5, seed=3)
+    tmpl = syn.synthetic_template(2, 5, 512, seed=4)
+    ref = orc.hifigan_forward(sd, cfg, mel, template=tmpl)
+    eng = _hifigan_engine(cfg, sd)
+    y = eng(torch.from_numpy(mel).to(_dev()), None, torch.from_numpy(tmpl).to(_dev()))
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy() - ref).max() <= TOL

@@ -734,9 +734,16 @@ fv_status launch_noise_conv_add(const float* tmpl, const float* w, const float* 
                                 int k, int stride, int pad, hipStream_t s) {
     const int n_tiles = (T + 31) / 32;
     const size_t lds = (size_t)k * 33 * sizeof(float);
-    if (lds > 64 * 1024) {
-        set_error("noise_conv: kernel size %d needs %zu B of LDS (> 64 KiB)", k, lds);
+    if (lds > 160 * 1024) {   // k = 2 * (product of the later up-sampling rates): 1024 taps cover a first stage of rate 1 at hop 512
+        set_error("noise_conv: kernel size %d needs %zu B of LDS (> 160 KiB)", k, lds);
         return FV_ERR_UNSUPPORTED;
+    }
+    if (lds > 64 * 1024) {    // above the default dynamic-LDS limit: opt in (gfx950 has 160 KiB per CU)
+        static bool attr = false;
+        if (!attr) {
+            FV_HIP_CHECK(hipFuncSetAttribute((const void*)noise_conv_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
     }
     hipLaunchKernelGGL(noise_conv_add_kernel, dim3(B * n_tiles), dim3(256), lds, s, tmpl, w, bias, x, C, T, Ta, k, stride, pad,
                        n_tiles);
