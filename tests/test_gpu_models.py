@@ -496,3 +496,27 @@ def test_template_branch_with_a_long_first_stage_stride_vs_oracle():
     y = eng(torch.from_numpy(mel).to(_dev()), None, torch.from_numpy(tmpl).to(_dev()))
     torch.cuda.synchronize()
     assert np.abs(y.cpu().numpy() - ref).max() <= TOL
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_bigvgan_and_vocos_benchmark_sizes_properties(prec):
+    """BASELINE config[2] / config[3] geometry at a batch that uses the full-size tiles (BigVGAN-24k B=12, Vocos-24k B=40,
+    94 frames): finite, deterministic, and every batch item equal to the same clip run alone — the pointwise convs of the
+    ConvNeXt trunk tile the flattened (batch, time) axis, so items share tiles."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config, upsampler_config
+    cfg = dict(syn.BIGVGAN_24K)
+    eng = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=syn.bigvgan_state_dict(cfg, 0), precision=prec)
+    cfgv = dict(syn.VOCOS_24K)
+    engv = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfgv["backbone"]), head=istft_head_config(**cfgv["head"]),
+                  state_dict=syn.vocos_state_dict(cfgv, 0), precision=prec)
+    for e, B, tol in ((eng, 12, 3e-5), (engv, 40, 3e-5)):
+        mel = syn.synthetic_mel(B, 80, 94, seed=B)
+        y = _fwd(e, mel)
+        assert y.shape == (B, 1, 94 * 256) and np.isfinite(y).all()
+        assert np.array_equal(y, _fwd(e, mel))
+        scale = max(1.0, np.abs(y).max())
+        for i in (0, B // 2, B - 1):
+            yi = _fwd(e, mel[i:i + 1])
+            assert np.abs(yi[0] - y[i]).max() <= tol * scale, (i, np.abs(yi[0] - y[i]).max(), scale)
+        e.close()
