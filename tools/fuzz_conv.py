@@ -76,6 +76,9 @@ def run(n_cases=60, seed=0, verbose=True):
             ref = ref + res
         ref = ACT[post](ref)
         scale = max(1.0, float(np.abs(ref).max()))
+        # both sides accumulate K = cin * k products in fp32 in different orders: the bound grows with sqrt(K) (seen: 2.25e-5
+        # at K = 5632, the only case in 4000 above 2e-5)
+        scale *= max(1.0, float(np.sqrt(cin * k / 1024.0)))
         for prec in ("f32", "f16x3"):
             conv = FusedConv(w, b, pre_act=pre, post_act=post, **kw).set_precision(prec)
             y = conv(torch.from_numpy(x).cuda(), None if res is None else torch.from_numpy(res).cuda())
