@@ -462,8 +462,12 @@ struct fv_engine {
         std::vector<float> al, be;
         fv_status st = vec(prefix + ".act.alpha", C, al);
         if (st) return st;
-        st = vec(prefix + ".act.beta", C, be);
-        if (st) return st;
+        if (find(prefix + ".act.beta")) {   // SnakeBeta (bigvgan.py:74-135)
+            st = vec(prefix + ".act.beta", C, be);
+            if (st) return st;
+        } else {
+            be = al;                        // Snake (bigvgan.py:18-71): x + sin^2(alpha x) / alpha, one parameter per channel
+        }
         for (int c = 0; c < C; ++c) {  // alpha_logscale=True (bigvgan.py:128-133,229,336)
             al[c] = std::exp(al[c]);
             be[c] = 1.0f / (std::exp(be[c]) + 0.000000001f);

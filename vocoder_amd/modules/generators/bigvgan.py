@@ -105,8 +105,8 @@ class BigVGANGenerator(_base.EngineModule):
     ):
         super().__init__()
         assert prod(upsample_rates) == hop_length, f"hop_length must be {prod(upsample_rates)}"
-        if activation is not SnakeBeta:
-            raise NotImplementedError("only activation=SnakeBeta (the reference default, bigvgan.py:266) is built")
+        if activation not in (SnakeBeta, Snake):
+            raise NotImplementedError("activation must be SnakeBeta (the reference default, bigvgan.py:266) or Snake")
         self.use_template = bool(use_template)
         self.num_upsamples, self.num_kernels = len(upsample_rates), len(resblock_kernel_sizes)
         self._cfg = dict(
@@ -122,7 +122,7 @@ class BigVGANGenerator(_base.EngineModule):
             weight_norm(nn.ConvTranspose1d(c0 >> i, c0 >> (i + 1), k, u, padding=(k - u) // 2))
             for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)))
         self.resblocks = nn.ModuleList(
-            AMPBlockParams(c0 >> (i + 1), k, d)
+            AMPBlockParams(c0 >> (i + 1), k, d, activation=activation)
             for i in range(self.num_upsamples) for k, d in zip(resblock_kernel_sizes, resblock_dilation_sizes))
         ch = c0 >> self.num_upsamples
         self.activation_post = Activation1dParams(activation(ch, alpha_logscale=True))
