@@ -47,6 +47,11 @@ class LinearSpectrogram(nn.Module):
         self.n_fft, self.win_length, self.hop_length, self.center, self.mode = n_fft, win_length, hop_length, center, mode
         self.register_buffer("window", torch.hann_window(win_length))
 
+    def forward(self, y: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError(
+            "LinearSpectrogram on its own (the VAE encoders' input, spectrogram.py:25-56) is outside the generator hot path; "
+            "it runs inside LogMelSpectrogram's engine (FV_MODEL_LOGMEL) — use LogMelSpectrogram, or compute it upstream")
+
 
 class _MelScaleBuffers(nn.Module):
     def __init__(self, fb):
