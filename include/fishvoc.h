@@ -120,7 +120,8 @@ typedef struct fv_istft_head_config {
 } fv_istft_head_config;
 
 /* LogMelSpectrogram ctor kwargs (spectrogram.py:60-70); center must be 0 (the reference default), win_length == n_fft,
- * hop_length <= n_fft (hop need not divide n_fft: resolution/24000_2048_3072.yaml). */
+ * hop_length <= n_fft (hop need not divide n_fft: resolution/24000_2048_3072.yaml).  n_mels == 0 selects LinearSpectrogram
+ * alone (spectrogram.py:25-56, mode "pow2_sqrt"): the output is the (B, n_fft/2+1, frames) magnitude, no filterbank, no log. */
 typedef struct fv_logmel_config {
     int32_t sample_rate;
     int32_t n_fft;

@@ -194,3 +194,26 @@ def test_bigvgan_with_the_one_parameter_snake_activation_vs_oracle():
     assert np.abs(y - ref).max() <= TOL
     with pytest.raises(NotImplementedError):
         BigVGANGenerator(**cfg, activation=torch.nn.ReLU)
+
+
+def test_linear_spectrogram_standalone_vs_reference_golden_and_oracle():
+    """LinearSpectrogram.forward on its own (spectrogram.py:25-56; the VAE encoders' input): the log-mel engine with the
+    filterbank stage switched off (fv_logmel_config.n_mels = 0)."""
+    import json
+    from vocoder_amd.data.transforms.spectrogram import LinearSpectrogram
+    from oracle import oracle as orc
+    z = load_golden("logmel.npz")
+    for tag in "ab":
+        cfg = json.loads(bytes(z[f"{tag}_cfg"]).decode())
+        m = LinearSpectrogram(cfg["n_fft"], cfg["win_length"], cfg["hop_length"]).eval().cuda()
+        assert set(m.state_dict()) == {"window"}
+        y = m(torch.from_numpy(z[f"{tag}_wave"]).cuda()).cpu().numpy()
+        if f"{tag}_linear" in z:
+            assert y.shape == z[f"{tag}_linear"].shape and np.abs(y - z[f"{tag}_linear"]).max() <= 1e-4 * max(1.0, np.abs(z[f"{tag}_linear"]).max())
+        ref = orc.linear_spectrogram(z[f"{tag}_wave"], cfg["n_fft"], cfg["win_length"], cfg["hop_length"])
+        assert y.shape == ref.shape and np.abs(y - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    m = LinearSpectrogram(3072, 3072, 2048).eval().cuda()      # 1537 bins: the vocos-small-vae encoder's input at 24000_2048_3072
+    wave = (0.1 * np.random.default_rng(0).normal(size=(2, 2048 * 5))).astype(np.float32)
+    y = m(torch.from_numpy(wave).cuda()[:, None, :]).cpu().numpy()
+    ref = orc.linear_spectrogram(wave, 3072, 3072, 2048)
+    assert y.shape == ref.shape == (2, 1537, 5) and np.abs(y - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())

@@ -999,6 +999,7 @@ fv_status fv_engine::build_logmel(const std::string& pfx) {
             }
     fv_status st;
     if ((st = conv_layer_create(mel.stft, false, hop, 2 * nb, taps, 1, 0, 1, wst.data(), nullptr))) return st;
+    if (c.n_mels == 0) return FV_OK;   // linear spectrogram only: no filterbank
     // filterbank (n_freqs, n_mels) -> pointwise conv weight (n_mels, n_freqs)
     std::vector<float> fbw((size_t)c.n_mels * nb);
     if (const HostTensor* t = find(pfx + "mel_scale.fb")) {
@@ -1043,6 +1044,10 @@ fv_status fv_engine::run_logmel(const float* d_in, float* d_out, int B, int L, f
     r.x = Yp;
     r.y = Sp;
     if ((st = conv_layer_run(mel.stft, r, s))) return st;
+    if (mel.cfg.n_mels == 0) {   // LinearSpectrogram alone (spectrogram.py:25-56): the magnitude is the result
+        FV_PROF(s, "magnitude", 4.0 * B * nb * T, 12.0 * B * nb * T, launch_magnitude(Sp, d_out, B, nb, T, s));
+        return FV_OK;
+    }
     FV_PROF(s, "magnitude", 4.0 * B * nb * T, 12.0 * B * nb * T, launch_magnitude(Sp, Mg, B, nb, T, s));
     r = ConvRun();
     r.batch = B;
@@ -1157,8 +1162,8 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
         case FV_MODEL_LOGMEL: {
             const fv_logmel_config& m = cfg->mel;
             if (m.n_fft < 2 || m.n_fft % 2 || m.hop_length < 1 || m.win_length != m.n_fft || m.hop_length > m.n_fft ||
-                m.n_mels < 1 || m.sample_rate < 2 || m.f_min < 0) {
-                set_error("logmel: need even n_fft == win_length, hop_length <= n_fft, n_mels >= 1");
+                m.n_mels < 0 || m.sample_rate < 2 || m.f_min < 0) {
+                set_error("logmel: need even n_fft == win_length, hop_length <= n_fft, n_mels >= 0");
                 st = FV_ERR_INVALID;
             }
             break;
@@ -1277,7 +1282,7 @@ FV_API int32_t fv_input_channels(const fv_engine* e) {
 }
 FV_API int32_t fv_output_channels(const fv_engine* e) {
     if (!e) return 0;
-    if (e->cfg.model == FV_MODEL_LOGMEL) return e->cfg.mel.n_mels;
+    if (e->cfg.model == FV_MODEL_LOGMEL) return e->cfg.mel.n_mels ? e->cfg.mel.n_mels : e->cfg.mel.n_fft / 2 + 1;
     return e->cfg.model == FV_MODEL_CONVNEXT ? e->cfg.backbone.dims[e->cfg.backbone.num_stages - 1] : 1;
 }
 FV_API int64_t fv_output_length(const fv_engine* e, int32_t t_in) {

@@ -37,8 +37,10 @@ def melscale_fbanks_slaney(n_freqs: int, f_min: float, f_max: float, n_mels: int
     return (fb * (2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])).unsqueeze(0)).to(torch.float32)
 
 
-class LinearSpectrogram(nn.Module):
-    """Buffer holder named like the reference class (``window``); the arithmetic lives in the engine."""
+class LinearSpectrogram(_base.EngineModule):
+    """Reference spectrogram.py:8-56: reflect-padded ``torch.stft(center=False)`` magnitude ``sqrt(re^2 + im^2 + 1e-6)``,
+    ``forward(y (B, L) or (B, 1, L)) -> (B, n_fft/2+1, frames)``.  Same buffer name (``window``); runs on the log-mel
+    engine with the filterbank stage switched off (``n_mels = 0``).  Inside LogMelSpectrogram it only holds the window."""
 
     def __init__(self, n_fft=2048, win_length=2048, hop_length=512, center=False, mode="pow2_sqrt"):
         super().__init__()
@@ -46,11 +48,17 @@ class LinearSpectrogram(nn.Module):
             raise NotImplementedError("only mode='pow2_sqrt' (the reference default) is built")
         self.n_fft, self.win_length, self.hop_length, self.center, self.mode = n_fft, win_length, hop_length, center, mode
         self.register_buffer("window", torch.hann_window(win_length))
+        self._cfg = dict(sample_rate=2, n_fft=n_fft, win_length=win_length, hop_length=hop_length, n_mels=0, center=center)
+        logmel_config(**self._cfg)   # validates center=False
+
+    def _make_engine(self, state_dict):
+        sd = {"spectrogram.window": v for k, v in state_dict.items() if k == "window"}
+        return Engine(_lib.FV_MODEL_LOGMEL, mel=logmel_config(**self._cfg), state_dict=sd, precision=self.precision)
 
     def forward(self, y: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError(
-            "LinearSpectrogram on its own (the VAE encoders' input, spectrogram.py:25-56) is outside the generator hot path; "
-            "it runs inside LogMelSpectrogram's engine (FV_MODEL_LOGMEL) — use LogMelSpectrogram, or compute it upstream")
+        if y.ndim == 2:
+            y = y[:, None, :]
+        return self._run(y)
 
 
 class _MelScaleBuffers(nn.Module):
