@@ -468,7 +468,7 @@ def test_bigvgan_long_clip_covers_the_interior_snake_tiles_vs_oracle():
 
 
 def test_differential_fuzz_of_random_configurations():
-    """tools/fuzz_{hifigan,vocos,refinegan,conv,logmel,sequence}.py: random (but seeded) generator configurations, batch sizes and clip lengths
+    """tools/fuzz_{hifigan,vocos,refinegan,conv,logmel,sequence,firefly}.py: random (but seeded) generator configurations, batch sizes and clip lengths
     through the engine in both precisions against the oracle, plus graph capture / replay identity."""
     import importlib.util, os
     tools = os.path.join(os.path.dirname(__file__), "..", "tools")
@@ -476,7 +476,7 @@ def test_differential_fuzz_of_random_configurations():
                      ("fuzz_hifigan", dict(n_cases=3, seed=15, model="bigvgan")),
                      ("fuzz_vocos", dict(n_cases=6, seed=13)), ("fuzz_refinegan", dict(n_cases=4, seed=14)),
                      ("fuzz_conv", dict(n_cases=40, seed=16)), ("fuzz_logmel", dict(n_cases=8, seed=17)),
-                     ("fuzz_sequence", dict(n_calls=40, seed=18))):
+                     ("fuzz_sequence", dict(n_calls=40, seed=18)), ("fuzz_firefly", dict(n_cases=4, seed=19))):
         spec = importlib.util.spec_from_file_location(name, os.path.join(tools, name + ".py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
