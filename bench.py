@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU (default 32 = BASELINE config)")
     ap.add_argument("--frames", type=int, default=T_MEL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=32, help="clips in the bounded CPU-oracle sample")
+    ap.add_argument("--cpu-clips", type=int, default=96, help="clips in the bounded CPU-oracle sample")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
                     help="arithmetic of the MFMA-bound convs: f32 = exact fp32 MFMA (the reference's arithmetic, headline); "
                          "f16x3 = opt-in split-fp16 MFMA with fp32-class accuracy")
