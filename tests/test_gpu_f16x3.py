@@ -1,6 +1,8 @@
 """GPU: the opt-in f16x3 precision mode (split-fp16 MFMA, vocoder_amd/csrc/conv_f16x3_impl.h) against the CPU oracle.
 Same tolerance as the fp32 path: |d| <= 1e-4 absolute (north_star); the split keeps ~22 mantissa bits per product, so the
 observed error must also stay in the fp32-roundoff class (<= 2e-5 of the output scale)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -222,6 +224,8 @@ PAIR_CASES = [(256, 11, 5, 1, 688), (256, 3, 1, 2, 100), (256, 7, 3, 1, 87), (12
 def test_f16x3_wide_fused_pair_matches_oracle(C, k, d, B, T):
     """y = x + c2(silu(c1(silu(x)))) in one launch on the split-fp16 path (fv_conv_pair_forward, pair_f16x3_impl.h):
     ragged tile edges, clips shorter than a tile, every (k, dilation) the ResBlocks use."""
+    if os.environ.get("FV_NO_F16X3_PAIRS"):
+        pytest.skip("the diagnostic switch FV_NO_F16X3_PAIRS turns these kernels off")
     from vocoder_amd import _lib
     from vocoder_amd.engine import FusedConv
     rng = np.random.default_rng(C + 13 * k + d)
@@ -243,6 +247,8 @@ def test_f16x3_wide_fused_pair_matches_oracle(C, k, d, B, T):
 
 
 def test_f16x3_pair16_needs_an_even_length_and_falls_back_to_fp32_otherwise():
+    if os.environ.get("FV_NO_F16X3_PAIRS"):
+        pytest.skip("the diagnostic switch FV_NO_F16X3_PAIRS turns this kernel off")
     from vocoder_amd import _lib
     from vocoder_amd.engine import FusedConv
     rng = np.random.default_rng(5)
