@@ -10,7 +10,7 @@ cfg = dict(syn.HIFIGAN_V1_44K)
 eng = Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**cfg), state_dict=syn.hifigan_state_dict(cfg, 0), precision=prec)
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
-    for B in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64):
+    for B in ([int(v) for v in os.environ["PROBE_BATCHES"].split(",")] if os.environ.get("PROBE_BATCHES") else (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64)):
         mel = torch.from_numpy(syn.synthetic_mel(B, 80, 86, 1)).cuda()
         out = torch.empty((B, 1, 86 * 512), device="cuda")
         for _ in range(4):

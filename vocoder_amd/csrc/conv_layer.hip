@@ -233,6 +233,17 @@ static int choose_tile(int M, long long N, int batch) {
         }
         return small;
     }
+    // Enough workgroups either way: weigh the last, partly filled round of each tiling (workgroups are dealt out in
+    // rounds of one per CU; e.g. 516 tiles of 128 x 128 cost three rounds for two rounds' worth of work, 1032 tiles of
+    // 128 x 64 cost five half-size rounds).  A half-width tile runs at ~0.9 of the full tile's rate; keep the full tile
+    // unless the model sees a clear win.
+    {   // (measured on HiFiGAN-V1: B = 12 ... 14 -2 ... -3.5 %, every other batch size from 1 to 64 unchanged)
+        const long long cus = num_cus();
+        const long long blocks_small = tiles_small * m_blks * batch;
+        const double cost_big = (double)((blocks_big + cus - 1) / cus) * nb_big;
+        const double cost_small = (double)((blocks_small + cus - 1) / cus) * nb_small / 0.90;
+        if (cost_small < 0.97 * cost_big) return small;
+    }
     return big;
 }
 
