@@ -198,3 +198,33 @@ def test_refinegan_oracle_matches_reference_golden(name):
     assert np.abs(y - g["out"]).max() <= 2e-6
     for tag, sf in (("d2", 0.5), ("d8", 0.125), ("u2", 2), ("u8", 8)):   # nn.Upsample(mode="linear"), refinegan.py:229,262
         assert np.abs(orc.linear_interp(g["interp_x"], sf) - g[f"interp_{tag}"]).max() <= 5e-7
+
+
+def test_slaney_filterbank_against_an_independent_library_implementation():
+    """torchaudio (where MelScale(norm="slaney", mel_scale="slaney") lives) is not in the image, so the filterbank is restated;
+    `transformers.audio_utils.mel_filter_bank` is an independent librosa-compatible implementation that IS installed: both
+    restatements (oracle, module) must agree with it."""
+    audio_utils = pytest.importorskip("transformers.audio_utils")
+    from vocoder_amd.data.transforms.spectrogram import melscale_fbanks_slaney
+    for sr, n_fft, n_mels, fmin, fmax in [(44100, 2048, 128, 0.0, 22050), (24000, 1024, 100, 0.0, 12000), (24000, 3072, 100, 0.0, 12000),
+                                          (16000, 512, 80, 40.0, 7600)]:
+        nb = n_fft // 2 + 1
+        ref = audio_utils.mel_filter_bank(nb, n_mels, fmin, fmax, sr, norm="slaney", mel_scale="slaney")
+        assert np.abs(orc.melscale_fbanks_slaney(nb, fmin, fmax, n_mels, sr) - ref).max() <= 1e-7
+        assert np.abs(melscale_fbanks_slaney(nb, fmin, fmax, n_mels, sr).numpy() - ref).max() <= 1e-7
+
+
+def test_kaiser_sinc_taps_against_scipy_and_torch_windows():
+    """alias_free_torch's kaiser_sinc_filter1d (absent) = 2 fc * kaiser_window(12, beta) * sinc(2 fc t), normalised: the window
+    from scipy.signal and from torch.kaiser_window (two independent Bessel-I0 implementations) gives the oracle's taps."""
+    windows = pytest.importorskip("scipy.signal.windows")
+    import torch
+    cutoff, half_width, ks = 0.25, 0.3, 12
+    A = 2.285 * (ks // 2 - 1) * np.pi * 4 * half_width + 7.95
+    beta = 0.1102 * (A - 8.7)
+    assert A > 50
+    t = np.arange(-ks // 2, ks // 2) + 0.5
+    for win in (windows.kaiser(ks, beta, sym=True), torch.kaiser_window(ks, beta=beta, periodic=False, dtype=torch.float64).numpy()):
+        f = 2 * cutoff * win * np.sinc(2 * cutoff * t)
+        f /= f.sum()
+        assert np.abs(f - orc.kaiser_sinc_filter(cutoff, half_width, ks)).max() <= 1e-7
