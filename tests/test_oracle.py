@@ -228,3 +228,27 @@ def test_kaiser_sinc_taps_against_scipy_and_torch_windows():
         f = 2 * cutoff * win * np.sinc(2 * cutoff * t)
         f /= f.sum()
         assert np.abs(f - orc.kaiser_sinc_filter(cutoff, half_width, ks)).max() <= 1e-7
+
+
+def test_alias_free_resamplers_against_scipy_upfirdn():
+    """UpSample1d / DownSample1d of alias_free_torch (absent), third implementation: replicate padding + scipy.signal.upfirdn
+    (zero-stuffing polyphase FIR) with the package's pad / crop arithmetic (ratio 2, 12 taps: pad 5 each side before the
+    transposed conv, crop 15 / 15 after it; pad 5 / 6 before the strided conv)."""
+    sig = pytest.importorskip("scipy.signal")
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(2, 3, 50)).astype(np.float32)
+    taps = orc.kaiser_sinc_filter(0.25, 0.3, 12).astype(np.float64)
+    up = orc.upsample_fir(x, taps.astype(np.float32), 2)
+    dn = orc.downsample_fir(up, taps.astype(np.float32), 2)
+    assert up.shape == (2, 3, 100) and dn.shape == (2, 3, 50)
+    for b in range(2):
+        for c in range(3):
+            xp = np.pad(x[b, c].astype(np.float64), (5, 5), mode="edge")
+            u = 2.0 * sig.upfirdn(taps, xp, up=2)[15:-15]          # conv_transpose1d(stride 2) == FIR on the zero-stuffed signal
+            u = u[:100]
+            assert np.abs(u - up[b, c]).max() <= 2e-6
+            ap = np.pad(up[b, c].astype(np.float64), (5, 6), mode="edge")
+            d = sig.upfirdn(taps[::-1], ap, down=2)                # full convolution, every 2nd sample
+            full = np.convolve(ap, taps[::-1])                     # conv1d (correlation, 'valid', stride 2) = full[k-1 :: 2]
+            assert np.allclose(d, full[::2])
+            assert np.abs(full[11::2][:50] - dn[b, c]).max() <= 2e-6
