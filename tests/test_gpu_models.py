@@ -521,3 +521,69 @@ def test_bigvgan_and_vocos_benchmark_sizes_properties(prec):
             yi = _fwd(e, mel[i:i + 1])
             assert np.abs(yi[0] - y[i]).max() <= tol * scale, (i, np.abs(yi[0] - y[i]).max(), scale)
         e.close()
+
+
+def test_no_writes_outside_the_output_and_the_declared_workspace():
+    """Guard bands around the caller's output tensor and around exactly fv_workspace_bytes of workspace stay untouched
+    (HiFiGAN with and without template, BigVGAN, Vocos, Firefly, RefineGAN, log-mel; both precisions; odd sizes)."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import (Engine, convnext_config, istft_head_config, logmel_config, refinegan_config,
+                                    upsampler_config)
+    dev = _dev()
+    G = 4096   # guard floats on each side
+    hcfg = dict(hop_length=16, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4], resblock_kernel_sizes=[3, 7, 11],
+                resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=20, upsample_initial_channel=128, use_template=False)
+    vcfg = dict(backbone=dict(input_channels=20, depths=[1, 2], dims=[64, 192], kernel_size=7),
+                head=dict(dim=192, n_fft=64, hop_length=16, win_length=64, padding="same"))
+    fcfg = dict(backbone=dict(input_channels=20, depths=[1], dims=[64], kernel_size=7), head=dict(hcfg, num_mels=64))
+    rcfg = dict(sampling_rate=16000, hop_length=16, downsample_rates=(2, 2, 4), upsample_rates=(4, 2, 2), leaky_relu_slope=0.2,
+                num_mels=20, start_channels=4)
+    mcfg = dict(sample_rate=16000, n_fft=64, win_length=64, hop_length=16, n_mels=20)
+
+    def engines(prec):
+        yield "hifigan", Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**hcfg), state_dict=syn.hifigan_state_dict(hcfg, 1), precision=prec), 20, None
+        tc = dict(hcfg, use_template=True)
+        yield "hifigan+template", Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**tc), state_dict=syn.hifigan_state_dict(tc, 1), precision=prec), 20, "template"
+        yield "bigvgan", Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**hcfg), state_dict=syn.bigvgan_state_dict(hcfg, 1), precision=prec), 20, None
+        yield "vocos", Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**vcfg["backbone"]), head=istft_head_config(**vcfg["head"]),
+                              state_dict=syn.vocos_state_dict(vcfg, 1), precision=prec), 20, None
+        yield "firefly", Engine(_lib.FV_MODEL_FIREFLY, backbone=convnext_config(**fcfg["backbone"]), ups=upsampler_config(**fcfg["head"]),
+                                state_dict=syn.firefly_state_dict(fcfg, 1), precision=prec), 20, None
+        yield "refinegan", Engine(_lib.FV_MODEL_REFINEGAN, refine=refinegan_config(**rcfg), state_dict=syn.refinegan_state_dict(rcfg, 1), precision=prec), 20, "refine"
+        yield "logmel", Engine(_lib.FV_MODEL_LOGMEL, mel=logmel_config(**mcfg), state_dict={}, precision=prec), 1, "wave"
+
+    for prec in ("f32", "f16x3"):
+        for name, eng, cin, extra in engines(prec):
+            ran = 0
+            for B, T in ((1, 1), (3, 37), (2, 130)):
+                if extra == "wave":
+                    T = 16 * T + 48
+                x = torch.randn(B, cin, T, device=dev) * (0.1 if extra == "wave" else 1.0)
+                L = eng.output_length(T)
+                if L <= 0:
+                    continue
+                n_out = B * eng.out_channels * L
+                obuf = torch.full((n_out + 2 * G,), 7.25, device=dev)
+                out = obuf[G:G + n_out].view(B, eng.out_channels, L)
+                need = (eng.workspace_bytes(B, T) + 3) // 4
+                wbuf = torch.full((need + 2 * G,), -3.5, device=dev)
+                eng._ws = wbuf[G:G + need]
+                kw = {}
+                if extra == "template":
+                    kw["template"] = torch.randn(B, 1, L, device=dev) * 0.3
+                if extra == "refine":
+                    kw["template"] = torch.randn(B, 1, L, device=dev) * 0.3
+                    kw["noise"] = torch.randn(eng.noise_elems(B, T), device=dev)
+                try:
+                    for _ in range(3):   # eager, capture, replay
+                        eng(x, out, **kw)
+                except ValueError:
+                    continue             # lengths RefineGAN cannot join
+                torch.cuda.synchronize()
+                assert eng._ws.data_ptr() == wbuf[G:].data_ptr(), "the engine replaced a workspace of the size it asked for"
+                assert bool((obuf[:G] == 7.25).all()) and bool((obuf[G + n_out:] == 7.25).all()), (name, prec, B, T, "output guard")
+                assert bool((wbuf[:G] == -3.5).all()) and bool((wbuf[G + need:] == -3.5).all()), (name, prec, B, T, "workspace guard")
+                assert bool(torch.isfinite(out).all()), (name, prec, B, T)
+                ran += 1
+            assert ran >= 2, (name, prec, ran)
+            eng.close()
