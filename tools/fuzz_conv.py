@@ -81,8 +81,11 @@ def run(n_cases=60, seed=0, verbose=True):
         scale *= max(1.0, float(np.sqrt(cin * k / 1024.0)))
         for prec in ("f32", "f16x3"):
             conv = FusedConv(w, b, pre_act=pre, post_act=post, **kw).set_precision(prec)
-            y = conv(torch.from_numpy(x).cuda(), None if res is None else torch.from_numpy(res).cuda())
+            guard = torch.full((ref.size + 2048,), 9.5, device="cuda")   # 1024 floats of guard band either side of the output
+            y = guard[1024:1024 + ref.size].view(*ref.shape)
+            conv(torch.from_numpy(x).cuda(), None if res is None else torch.from_numpy(res).cuda(), y)
             torch.cuda.synchronize()
+            assert bool((guard[:1024] == 9.5).all()) and bool((guard[1024 + ref.size:] == 9.5).all()), ("write outside the output", desc, cin, cout, B, T, prec)
             kern = _lib.last_kernel()
             err = float(np.abs(y.cpu().numpy() - ref).max())
             worst = max(worst, err / scale)
