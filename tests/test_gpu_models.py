@@ -524,8 +524,9 @@ def test_bigvgan_and_vocos_benchmark_sizes_properties(prec):
 
 
 def test_no_writes_outside_the_output_and_the_declared_workspace():
-    """Guard bands around the caller's output tensor and around exactly fv_workspace_bytes of workspace stay untouched
-    (HiFiGAN with and without template, BigVGAN, Vocos, Firefly, RefineGAN, log-mel; both precisions; odd sizes)."""
+    """Guard bands around the caller's output tensor and around exactly fv_workspace_bytes of workspace stay untouched, and a
+    workspace poisoned with NaNs before every call changes nothing (no kernel reads workspace it did not write in this
+    forward) — HiFiGAN with and without template, BigVGAN, Vocos, Firefly, RefineGAN, log-mel; both precisions; odd sizes."""
     from vocoder_amd import _lib
     from vocoder_amd.engine import (Engine, convnext_config, istft_head_config, logmel_config, refinegan_config,
                                     upsampler_config)
@@ -575,11 +576,17 @@ def test_no_writes_outside_the_output_and_the_declared_workspace():
                     kw["template"] = torch.randn(B, 1, L, device=dev) * 0.3
                     kw["noise"] = torch.randn(eng.noise_elems(B, T), device=dev)
                 try:
-                    for _ in range(3):   # eager, capture, replay
+                    eng._ws.zero_()
+                    eng(x, out, **kw)
+                    torch.cuda.synchronize()
+                    first = out.clone()
+                    for _ in range(3):   # eager, capture, replay — each time over a workspace full of NaNs: nothing may be
+                        eng._ws.fill_(float("nan"))   # read before this forward wrote it (halo columns, padded rows, ...)
                         eng(x, out, **kw)
+                        torch.cuda.synchronize()
+                        assert torch.equal(out, first), (name, prec, B, T, "result depends on stale workspace contents")
                 except ValueError:
                     continue             # lengths RefineGAN cannot join
-                torch.cuda.synchronize()
                 assert eng._ws.data_ptr() == wbuf[G:].data_ptr(), "the engine replaced a workspace of the size it asked for"
                 assert bool((obuf[:G] == 7.25).all()) and bool((obuf[G + n_out:] == 7.25).all()), (name, prec, B, T, "output guard")
                 assert bool((wbuf[:G] == -3.5).all()) and bool((wbuf[G + need:] == -3.5).all()), (name, prec, B, T, "workspace guard")
