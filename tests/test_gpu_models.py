@@ -594,3 +594,30 @@ def test_no_writes_outside_the_output_and_the_declared_workspace():
                 ran += 1
             assert ran >= 2, (name, prec, ran)
             eng.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_benchmark_size_kernels_do_not_read_stale_workspace(prec):
+    """The full-size tile shapes and fused pair kernels (HiFiGAN-V1 B=8, BigVGAN-24k B=4, Vocos-24k B=16, 86 / 94 frames):
+    the same forward over a zeroed and over a NaN-filled workspace must give identical, finite waveforms."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config, upsampler_config
+    dev = _dev()
+    h, b, v = dict(syn.HIFIGAN_V1_44K), dict(syn.BIGVGAN_24K), dict(syn.VOCOS_24K)
+    cases = [(Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**h), state_dict=syn.hifigan_state_dict(h, 0), precision=prec), 8, 86),
+             (Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**b), state_dict=syn.bigvgan_state_dict(b, 0), precision=prec), 4, 94),
+             (Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**v["backbone"]), head=istft_head_config(**v["head"]),
+                     state_dict=syn.vocos_state_dict(v, 0), precision=prec), 16, 94)]
+    for eng, B, T in cases:
+        x = torch.from_numpy(syn.synthetic_mel(B, 80, T, seed=B)).to(dev)
+        need = (eng.workspace_bytes(B, T) + 3) // 4
+        eng._ws = torch.zeros(need, device=dev)
+        first = eng(x).clone()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(first).all())
+        for _ in range(3):
+            eng._ws.fill_(float("nan"))
+            y = eng(x)
+            torch.cuda.synchronize()
+            assert torch.equal(y, first)
+        eng.close()
