@@ -559,7 +559,9 @@ def test_no_writes_outside_the_output_and_the_declared_workspace():
             for B, T in ((1, 1), (3, 37), (2, 130)):
                 if extra == "wave":
                     T = 16 * T + 48
-                x = torch.randn(B, cin, T, device=dev) * (0.1 if extra == "wave" else 1.0)
+                xbuf = torch.full((B * cin * T + 2 * G,), float("nan"), device=dev)   # NaNs either side of the input as well:
+                x = xbuf[G:G + B * cin * T].view(B, cin, T)                            # a stray read that is used would show
+                x.copy_(torch.randn(B, cin, T, device=dev) * (0.1 if extra == "wave" else 1.0))
                 L = eng.output_length(T)
                 if L <= 0:
                     continue

@@ -12,6 +12,13 @@ from oracle import oracle as orc
 ACT = {_lib.FV_ACT_NONE: lambda v: v, _lib.FV_ACT_SILU: orc.silu, _lib.FV_ACT_TANH: orc.tanh, _lib.FV_ACT_GELU: orc.gelu}
 
 
+def _nan_bordered(a: np.ndarray) -> torch.Tensor:
+    buf = torch.full((a.size + 2048,), float("nan"), device="cuda")
+    v = buf[1024:1024 + a.size].view(*a.shape)
+    v.copy_(torch.from_numpy(a))
+    return v
+
+
 def run(n_cases=60, seed=0, verbose=True):
     rng = np.random.default_rng(seed)
     worst = 0.0
@@ -32,7 +39,7 @@ def run(n_cases=60, seed=0, verbose=True):
                     continue   # no exact-fp32 pair kernel for the wide stages (they run per layer)
                 c1 = FusedConv(w1, b1, dilation=d, padding=(k - 1) * d // 2).set_precision(prec)
                 c2 = FusedConv(w2, b2, padding=(k - 1) // 2).set_precision(prec)
-                y = c1.pair(c2, torch.from_numpy(x).cuda())
+                y = c1.pair(c2, _nan_bordered(x))
                 torch.cuda.synchronize()
                 err = float(np.abs(y.cpu().numpy() - ref).max())
                 worst = max(worst, err / scale)
@@ -83,7 +90,7 @@ def run(n_cases=60, seed=0, verbose=True):
             conv = FusedConv(w, b, pre_act=pre, post_act=post, **kw).set_precision(prec)
             guard = torch.full((ref.size + 2048,), 9.5, device="cuda")   # 1024 floats of guard band either side of the output
             y = guard[1024:1024 + ref.size].view(*ref.shape)
-            conv(torch.from_numpy(x).cuda(), None if res is None else torch.from_numpy(res).cuda(), y)
+            conv(_nan_bordered(x), None if res is None else _nan_bordered(res), y)   # inputs sit between NaNs: a stray read that is used shows
             torch.cuda.synchronize()
             assert bool((guard[:1024] == 9.5).all()) and bool((guard[1024 + ref.size:] == 9.5).all()), ("write outside the output", desc, cin, cout, B, T, prec)
             kern = _lib.last_kernel()
