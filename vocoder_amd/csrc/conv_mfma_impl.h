@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 // its own dword of the packed weights).  Partial accumulators are reduced through LDS and wave 0 runs the epilogue.
 // 16x more workgroups than the 128 x 128 tile for the same problem.
 template <int KS, int DIL, int NT, int NW>
-__global__ __launch_bounds__(NW * 64, 4) void conv_mfma_splitk_kernel(const ConvParams p) {
+__global__ __launch_bounds__(NW * 64, (KS == 2 && NT == 2) ? 2 : 4) void conv_mfma_splitk_kernel(const ConvParams p) {   // (the 2-tap, two-n-tile instance needs more registers than four waves per SIMD leave)
     static_assert(NW == 4 || NW == 8, "4 or 8 waves split K");
     constexpr int THREADS = NW * 64;
     // 8-channel sub-chunks per LDS chunk (= per barrier): short kernels stage more channels at a time, otherwise a chunk is
