@@ -10,7 +10,7 @@
 namespace fv {
 
 void tile_dims(int cfg, int* m_blk, int* n_blk) {
-    static const int dims[TILE_COUNT][2] = {{128, 128}, {64, 256}, {32, 512}, {128, 64}, {32, 128}, {64, 128}, {32, 64}, {32, 32}};
+    static const int dims[TILE_COUNT][2] = {{128, 128}, {64, 256}, {32, 512}, {128, 64}, {32, 128}, {64, 128}, {32, 64}, {32, 32}, {256, 64}};
     *m_blk = dims[cfg][0];
     *n_blk = dims[cfg][1];
 }
@@ -247,7 +247,7 @@ static int choose_tile(int M, long long N, int batch) {
     return big;
 }
 
-static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64", "splitK32x32"};
+static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64", "splitK32x32", "256x64"};
 
 static const char* const kSplitNames[SPLIT_COUNT] = {"128x128", "64x256", "32x256"};
 
@@ -363,8 +363,12 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     int launch_batch = r.batch;
     if (!L.transposed && L.ks == 1 && L.pad_l == 0 && r.batch > 1 &&
         (long long)r.batch * std::max<long long>((long long)L.c_in * r.t_in, (long long)L.c_out * tout) < (1LL << 30)) {
-        const int cfg_flat = choose_tile(L.M, (long long)p.N * r.batch, 1);
-        if (cfg_flat < TILE_SPLITK_32x64) {
+        int cfg_flat = choose_tile(L.M, (long long)p.N * r.batch, 1);
+        // wide pointwise layers (ConvNeXt's 4x expansion): 256 x 64 tiles — the same workgroup count and accumulators as
+        // 128 x 128, but half the activation columns staged and read per MFMA (staging is what a k = 1 launch pays for:
+        // +4 ... 9 % on the Vocos GEMMs); only when 256-row blocks add no padded rows
+        if (cfg_flat == TILE_128x128 && L.M >= 512 && ((L.M + 127) / 128) % 2 == 0) cfg_flat = TILE_256x64;
+        if (cfg_flat != TILE_SPLITK_32x64 && cfg_flat != TILE_SPLITK_32x32) {
             cfg = cfg_flat;
             // 2: even T and 8-byte aligned rows -> the kernel stages column pairs (conv_mfma_impl.h)
             p.flat = (p.N % 2 == 0 && ((uintptr_t)r.x & 7) == 0) ? 2 : 1;
