@@ -49,6 +49,7 @@ CONV_CASES = [
     # C_in = 100 ends in a partial 32-channel chunk
     (100, 512, 1, 1, 40, 94), (512, 128, 1, 1, 70, 47), (128, 256, 1, 1, 64, 50), (64, 1026, 1, 1, 33, 98),
     (96, 2048, 1, 1, 48, 94), (72, 1280, 1, 1, 60, 47),   # 256 x 64 tiles (an even number of 128-row blocks)
+    (256, 512, 1, 1, 70, 94), (40, 768, 1, 1, 35, 63),     # 256 x 32 tiles
 ]
 
 

@@ -10,7 +10,7 @@
 namespace fv {
 
 void tile_dims(int cfg, int* m_blk, int* n_blk) {
-    static const int dims[TILE_COUNT][2] = {{128, 128}, {64, 256}, {32, 512}, {128, 64}, {32, 128}, {64, 128}, {32, 64}, {32, 32}, {256, 64}};
+    static const int dims[TILE_COUNT][2] = {{128, 128}, {64, 256}, {32, 512}, {128, 64}, {32, 128}, {64, 128}, {32, 64}, {32, 32}, {256, 64}, {256, 32}};
     *m_blk = dims[cfg][0];
     *n_blk = dims[cfg][1];
 }
@@ -247,7 +247,7 @@ static int choose_tile(int M, long long N, int batch) {
     return big;
 }
 
-static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64", "splitK32x32", "256x64"};
+static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64", "splitK32x32", "256x64", "256x32"};
 
 static const char* const kSplitNames[SPLIT_COUNT] = {"128x128", "64x256", "32x256"};
 
@@ -368,6 +368,8 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         // 128 x 128, but half the activation columns staged and read per MFMA (staging is what a k = 1 launch pays for:
         // +4 ... 9 % on the Vocos GEMMs); only when 256-row blocks add no padded rows
         if (cfg_flat == TILE_128x128 && L.M >= 512 && ((L.M + 127) / 128) % 2 == 0) cfg_flat = TILE_256x64;
+        // ... and 256 x 32 instead of 128 x 64 where the half-width tile was chosen (ConvNeXt's 4x contraction: +7 %)
+        if (cfg_flat == TILE_128x64 && L.M >= 512 && ((L.M + 127) / 128) % 2 == 0) cfg_flat = TILE_256x32;
         if (cfg_flat != TILE_SPLITK_32x64 && cfg_flat != TILE_SPLITK_32x32) {
             cfg = cfg_flat;
             // 2: even T and 8-byte aligned rows -> the kernel stages column pairs (conv_mfma_impl.h)

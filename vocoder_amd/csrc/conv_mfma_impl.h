@@ -549,6 +549,9 @@ inline bool launch_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
         case TILE_128x64: launch_one<KS, DIL, 4, 1, 1, 2>(p, batch, s); return true;
         case TILE_32x128: launch_one<KS, DIL, 1, 4, 1, 1>(p, batch, s); return true;
         case TILE_64x128: launch_one<KS, DIL, 1, 4, 2, 1>(p, batch, s); return true;
+        case TILE_256x32:
+            if constexpr (KS == 1) { launch_one<KS, DIL, 4, 1, 2, 1>(p, batch, s); return true; }
+            return false;
         case TILE_256x64:
             if constexpr (KS == 1) { launch_one<KS, DIL, 4, 1, 2, 2>(p, batch, s); return true; }
             return false;
