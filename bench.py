@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: HiFiGAN-V1 44.1 kHz synthesis throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: re-executes itself as N ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -9,20 +9,27 @@ A "step" = one generator forward (mel -> waveform) over one batch of 32 syntheti
 (BASELINE config[1]: hifigan V1 44.1 kHz, 80-bin mel, T_mel = 86 -> 44 032 samples per clip), inputs already resident in
 HBM, random-but-fixed weights of the real architecture (no network for checkpoints).  Multi-GPU = utterance sharding,
 weak scaling: every rank runs its own 32 clips (config[4] = 256 clips over 8 GPUs); weights are fanned out from rank 0 by
-one RCCL broadcast before the timed region; there is no collective on the data path.
+one RCCL broadcast before the timed region; there is no collective on the data path (the reference's analogue is
+Lightning's one-process-per-device launch, configs/trainer/default.yaml:6-9).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      — the dominant kernel of the forward (by total time), timed live with hipEvents on the launch stream by
-                  the engine's per-launch profiler (fv_profile_*), algorithmic flops per launch / avg duration vs the
-                  fp32-MFMA peak (or bytes vs HBM peak when that is the binding roof);
-  cpu_baseline  — the CPU oracle (oracle/, a C port of the reference forward) on a bounded sample of the same workload,
-                  all host cores, rank 0 / N=1 only.
+  roofline        — the dominant kernel of the forward (by total time), timed live with hipEvents on the launch stream by
+                    the engine's per-launch profiler (fv_profile_*), algorithmic flops per launch / avg duration vs the
+                    fp32-MFMA peak (or bytes vs HBM peak when that is the binding roof);
+  with_collectives— the same K steps with config[4]'s "result collection over RCCL" inside the timed region: rank 0 owns the
+                    global batch, every step = scatter mels -> forward -> gather waveforms (sharding.scatter_batch /
+                    gather_batch); not the headline value;
+  other_configs   — BASELINE config[2] (BigVGAN-24k B=64) and config[3] (Vocos-24k B=128): ms/step and step-level roofline;
+  cpu_baseline    — the CPU oracle (oracle/, a C port of the reference forward) on a bounded sample of the same workload,
+                    rank 0 / N=1 only; host core count, CPU model and the thread count used are stated.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,7 +40,6 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from vocoder_amd import _lib, synthetic as syn  # noqa: E402
-from vocoder_amd.engine import Engine, upsampler_config  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_MFMA_F16_TFLOPS = 2500.0  # same guide: dense fp16/bf16 matrix peak; the f16x3 mode spends 3 fp16 products per MAC,
@@ -58,38 +64,129 @@ def parse():
                          "f16x3 = opt-in split-fp16 MFMA with fp32-class accuracy")
     ap.add_argument("--no-alt-precision", action="store_true",
                     help="skip the extra f16x3 measurement that a default (f32) single-GPU run appends as 'alt_precision'")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the BigVGAN-24k B=64 / Vocos-24k B=128 measurements appended as 'other_configs' (N=1 only)")
+    ap.add_argument("--no-collectives", action="store_true", help="skip the scatter -> forward -> gather figure")
     ap.add_argument("--profile-json", default=None, help="also dump the per-kernel hipEvent table to this file")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / process-group / scatter-gather plumbing only, no engine and no timing claims "
+                         "(backend gloo when there is no GPU: the CPU test of the self-launch path)")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launch: `python bench.py --gpus N` with N > 1 and no torchrun environment re-executes itself as N ranks
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def maybe_self_launch(a) -> None:
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def init_dist(dev):
+    """One process per GPU over RCCL (backend "nccl"); gloo when there is no GPU (dry run on CPU)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if dev.type == "cuda":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    return dist
+
+
+def dry_run(a, world, rank, local_rank) -> None:
+    from vocoder_amd.sharding import gather_batch, scatter_batch, shard_sizes
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    dist = init_dist(dev) if (world > 1 or "TORCHELASTIC_RUN_ID" in os.environ) else None
+    ranks = dist.get_world_size() if dist is not None else 1
+    ok = True
+    if dist is not None:
+        gb = a.batch * ranks + 1   # ragged on purpose
+        full = torch.arange(gb * 4 * 3, dtype=torch.float32).reshape(gb, 4, 3) if rank == 0 else None
+        mine = scatter_batch(full, gb, (4, 3), src=0, device=dev)
+        ok = mine.shape[0] == shard_sizes(gb, ranks)[rank]
+        back = gather_batch(mine * 2.0, gb, dst=0)
+        if rank == 0:
+            ok = ok and bool(torch.equal(back.cpu(), full * 2.0))
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": ranks, "backend": "nccl" if use_gpu else "gloo",
+                          "scatter_gather_ok": bool(ok), "note": "plumbing only: no engine, nothing measured"}))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------------------------
+def _cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(cfg, sd, clips: int, frames: int) -> dict:
     """Times the oracle (kind 'port': oracle/fv_oracle.c restates the reference forward; the reference itself is
-    Python and does not travel to the GPU box) on `clips` one-second clips with all host cores."""
+    Python and does not travel to the GPU box) on `clips` one-second clips."""
     from oracle import oracle as orc
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     mel = syn.synthetic_mel(clips, cfg["num_mels"], frames, seed=1234)
     orc.hifigan_forward(sd, cfg, mel[:1, :, :8])  # page in / build
-    # the OpenMP port parallelises over (clip, out-channel) rows; on a many-core host the best thread count is well
-    # below the core count (barrier cost per conv), so pick it on a short probe and report the count actually used
-    best, best_dt = 1, float("inf")
+    # the OpenMP port parallelises over (clip, out-channel) rows; on a many-core host the best thread count can be below
+    # the core count (barrier cost per conv), so it is picked on a probe of the SAME shape as the sample (8 full one-second
+    # clips) and the count actually used is reported next to the host's core count
+    probe, best, best_dt, tried = mel[:8], 1, float("inf"), {}
     for n in (8, 16, 32, 64, 128, 256):
         if n > avail:
             break
         orc.set_num_threads(n)
         t0 = time.perf_counter()
-        orc.hifigan_forward(sd, cfg, mel[:1, :, :16])
+        orc.hifigan_forward(sd, cfg, probe)
         dt = time.perf_counter() - t0
+        tried[n] = round(dt, 3)
         if dt < best_dt:
             best, best_dt = n, dt
     orc.set_num_threads(best)
     t0 = time.perf_counter()
     y = orc.hifigan_forward(sd, cfg, mel)
     dt = time.perf_counter() - t0
-    return {"value": y.shape[0] * y.shape[-1] / dt, "unit": "samples/s", "cores": orc.num_threads(), "kind": "port",
-            "x_realtime": y.shape[0] * y.shape[-1] / dt / SAMPLE_RATE,
-            "sample": f"{clips} x 1 s clips (T_mel={frames}) of the same HiFiGAN-V1-44k workload, {dt:.2f} s of CPU work"}
+    # B = 1 (BASELINE config[0], the reference's own CPU-runnable case): one 1 s clip, median of 5
+    lat = []
+    for _ in range(5):
+        t1 = time.perf_counter()
+        orc.hifigan_forward(sd, cfg, mel[:1])
+        lat.append(time.perf_counter() - t1)
+    n_samp = y.shape[-1]
+    return {"value": y.shape[0] * n_samp / dt, "unit": "samples/s", "cores": orc.num_threads(), "kind": "port",
+            "host_cores": os.cpu_count(), "host_cores_usable": avail, "cpu_model": _cpu_model(),
+            "thread_probe_s": tried,
+            "x_realtime": y.shape[0] * n_samp / dt / SAMPLE_RATE,
+            "b1_clip_latency_ms": float(np.median(lat) * 1e3), "b1_x_realtime": n_samp / float(np.median(lat)) / SAMPLE_RATE,
+            "sample": f"{clips} x 1 s clips (T_mel={frames}) of the same HiFiGAN-V1-44k workload, {dt:.2f} s of CPU work on "
+                      f"{orc.num_threads()} threads (picked on an 8-clip probe) of {avail} usable cores; "
+                      "b1_* = one 1 s clip alone, median of 5"}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# roofline
+# ------------------------------------------------------------------------------------------------------------------
 def roofline_from_profile(table: list[dict], repeats: int) -> dict:
     """Dominant kernel = largest total time in the forward.  `achieved` = algorithmic flops (or bytes) per launch divided
     by its average hipEvent duration."""
@@ -102,14 +199,18 @@ def roofline_from_profile(table: list[dict], repeats: int) -> dict:
     t_hbm = top["bytes_per_launch"] / (PEAK_HBM_GBS * 1e9)
     # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.py);
     # PMC counters cannot be read from inside this process, so this is looked up, not measured live
-    traffic = None
+    traffic, traffic_src = None, None
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             sys.path.insert(0, os.path.join(REPO, "tools"))
             from pmc_traffic import bench_key
-            ent = json.load(open(tpath)).get(bench_key(top["kernel"]))
+            tj = json.load(open(tpath))
+            ent = tj.get(bench_key(top["kernel"]))
             traffic = ent["hbm_bytes_per_launch"] if ent else None
+            if ent:
+                traffic_src = ("profiles/traffic.json (rocprofv3 PMC passes of " + str(tj.get("_build", "round-1 build r01f")) +
+                               "; looked up by kernel name, not measured in this run)")
         except Exception:
             traffic = None
     if t_mfma >= t_hbm:
@@ -118,36 +219,97 @@ def roofline_from_profile(table: list[dict], repeats: int) -> dict:
             out["peak_note"] = "dense fp16 MFMA peak 2500 TFLOP/s / 3 products per MAC (f16x3 split)"
     else:
         out = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
-    out.update({"traffic": traffic, "kernel": top["kernel"], "avg_ms": top["avg_ms"],
+    out.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": top["kernel"], "avg_ms": top["avg_ms"],
                 "launches_per_step": top["launches"] // repeats,
                 "flops_per_launch": top["flops_per_launch"], "bytes_per_launch": top["bytes_per_launch"],
                 "share_of_step": top["total_ms"] / sum(r["total_ms"] for r in table)})
     return out
 
 
+def step_roofline(table, repeats, ms_per_step, peak_tf=PEAK_MFMA_F32_TFLOPS) -> dict:
+    flops = sum(r["flops_per_launch"] * (r["launches"] // repeats) for r in table)
+    ach = flops / (ms_per_step * 1e-3) / 1e12
+    return {"flops_per_step": flops, "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf}
+
+
+def time_engine(eng, mel, out, steps, warmup, dev) -> float:
+    for _ in range(warmup):
+        eng(mel, out)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng(mel, out)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps
+
+
+def other_configs(dev, steps, warmup) -> list[dict]:
+    """BASELINE config[2] and config[3] on one MI355X: same timing method as the headline, step-level roofline."""
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config, upsampler_config
+    res = []
+
+    def run(name, eng, mel, sr, workload):
+        out = torch.empty((mel.shape[0], 1, eng.output_length(mel.shape[2])), dtype=torch.float32, device=dev)
+        dt = time_engine(eng, mel, out, steps, warmup, dev)
+        tab = eng.profile(mel, repeats=2)
+        top = max(tab, key=lambda r: r["total_ms"])
+        n = out.numel()
+        r = {"config": workload, "model": name, "batch": int(mel.shape[0]), "t_mel": int(mel.shape[2]),
+             "ms_per_step": dt * 1e3, "value": n / dt, "unit": "samples/s", "x_realtime": n / dt / sr,
+             "output_finite": bool(torch.isfinite(out).all().item()),
+             "roofline_step": step_roofline(tab, 2, dt * 1e3),
+             "dominant_kernel": {"kernel": top["kernel"], "avg_ms": top["avg_ms"], "launches_per_step": top["launches"] // 2,
+                                 "tflops": top["flops_per_launch"] / (top["avg_ms"] * 1e-3) / 1e12,
+                                 "gbs": top["bytes_per_launch"] / (top["avg_ms"] * 1e-3) / 1e9,
+                                 "share_of_step": top["total_ms"] / sum(x["total_ms"] for x in tab)},
+             "serialized_kernel_ms": sum(x["total_ms"] for x in tab) / 2}
+        res.append(r)
+        eng.close()
+
+    try:
+        cfg = dict(syn.BIGVGAN_24K)
+        eng = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=syn.bigvgan_state_dict(cfg, 0))
+        run("bigvgan-24k", eng, torch.from_numpy(syn.synthetic_mel(64, 80, 94, 1)).to(dev), 24000,
+            "BASELINE config[2]: bigvgan (snake + anti-alias), 24 kHz, batch=64 x 1 s, 1 MI355X")
+    except Exception as exc:  # noqa: BLE001 - auxiliary figure: never cost the headline line
+        res.append({"model": "bigvgan-24k", "error": f"{type(exc).__name__}: {exc}"})
+    try:
+        cfg = dict(syn.VOCOS_24K)
+        eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), head=istft_head_config(**cfg["head"]),
+                     state_dict=syn.vocos_state_dict(cfg, 0))
+        run("vocos-24k", eng, torch.from_numpy(syn.synthetic_mel(128, 80, 94, 2)).to(dev), 24000,
+            "BASELINE config[3]: vocos ConvNeXt [3,3,27,3] + ISTFT head, 24 kHz, batch=128 x 1 s, 1 MI355X")
+    except Exception as exc:  # noqa: BLE001
+        res.append({"model": "vocos-24k", "error": f"{type(exc).__name__}: {exc}"})
+    return res
+
+
 def main():
     a = parse()
+    maybe_self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.dry_run:
+        dry_run(a, world, rank, local_rank)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    from vocoder_amd.engine import Engine, upsampler_config
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run: one process per GPU
-        import torch.distributed as dist  # noqa: PLC0415
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        dist = init_dist(dev)                               # RCCL over xGMI
+    ranks = dist.get_world_size() if dist is not None else 1
 
     cfg = dict(syn.HIFIGAN_V1_44K)
     sd = syn.hifigan_state_dict(cfg, seed=0) if rank == 0 else None
     if dist is not None:
         from vocoder_amd.sharding import broadcast_state_dict
-        sd_t = broadcast_state_dict(sd, src=0, device=dev)    # one-time weight fan-out (56 MB) over RCCL
-        sd_eng = sd_t
+        sd_eng = broadcast_state_dict(sd, src=0, device=dev)    # one-time weight fan-out (56 MB) over RCCL
     else:
         sd_eng = sd
     eng = Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**cfg), state_dict=sd_eng, precision=a.precision)
@@ -157,41 +319,85 @@ def main():
     out = torch.empty((B, 1, eng.output_length(T)), dtype=torch.float32, device=dev)
     samples_per_step = B * eng.output_length(T)
 
-    for _ in range(a.warmup):
-        eng(mel, out)
-
     def fence():
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    for _ in range(a.warmup):
+        eng(mel, out)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         eng(mel, out)
     fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     ok = bool(torch.isfinite(out).all().item()) and float(out.abs().max().item()) <= 1.0
 
+    # ---- config[4]'s "result collection over RCCL", timed: rank 0 owns the global batch -----------------------------
+    coll = None
+    if not a.no_collectives:
+        from vocoder_amd.sharding import gather_batch, scatter_batch
+        gb = B * ranks
+        full = None
+        if rank == 0:
+            full = torch.cat([torch.from_numpy(syn.synthetic_mel(B, cfg["num_mels"], T, seed=1234 + r)) for r in range(ranks)]).to(dev)
+
+        def coll_step():
+            if dist is None:
+                return eng(full, out)
+            mine = scatter_batch(full, gb, (cfg["num_mels"], T), src=0, device=dev)
+            y = eng(mine, out)
+            return gather_batch(y, gb, dst=0)
+
+        for _ in range(max(1, a.warmup)):
+            whole = coll_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            whole = coll_step()
+        fence()
+        dtc = max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            L = eng.output_length(T)
+            coll = {"ms_per_step": dtc / a.steps * 1e3, "value": gb * L * a.steps / dtc, "unit": "samples/s",
+                    "x_realtime": gb * L * a.steps / dtc / SAMPLE_RATE, "global_batch": gb,
+                    "scatter_bytes_per_step": (gb - B) * cfg["num_mels"] * T * 4, "gather_bytes_per_step": (gb - B) * L * 4,
+                    "collected_shape": list(whole.shape), "collected_finite": bool(torch.isfinite(whole).all().item()),
+                    "note": "each step: rank 0 scatters the global mel batch (send/recv over RCCL), every rank runs its shard, "
+                            "rank 0 gathers all waveforms; N=1 degenerates to the plain forward"}
+        del full, whole
+
     result = None
     if rank == 0:
-        # B=1 clip latency (p50) — the second half of BASELINE's metric
+        # B=1 clip latency (p50) — the second half of BASELINE's metric: hipGraph replay (same buffers every call) and
+        # eager (replay off: what a caller with ever-changing shapes / buffers gets)
         mel1 = mel[:1].contiguous()
-        for _ in range(5):
-            eng(mel1)
-        torch.cuda.synchronize(dev)
-        lat = []
-        for _ in range(30):
-            t1 = time.perf_counter()
-            eng(mel1)
+
+        def p_lat(n=30):
+            for _ in range(5):
+                eng(mel1)
             torch.cuda.synchronize(dev)
-            lat.append((time.perf_counter() - t1) * 1e3)
+            lat = []
+            for _ in range(n):
+                t1 = time.perf_counter()
+                eng(mel1)
+                torch.cuda.synchronize(dev)
+                lat.append((time.perf_counter() - t1) * 1e3)
+            return lat
+        lat = p_lat()
+        eng.set_graph_replay(False)
+        lat_eager = p_lat()
+        eng.set_graph_replay(True)
         repeats = 3
         table = eng.profile(mel, repeats=repeats)
         if a.profile_json:
@@ -200,7 +406,7 @@ def main():
         value = world * samples_per_step * a.steps / elapsed
         result = {
             "metric": "audio_samples_per_sec", "value": value, "unit": "samples/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": ranks, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.precision == "f32" else "f32 via f16x3 split (fp16 operand planes, fp32 accumulate)",
             "data": "synthetic",
@@ -210,40 +416,39 @@ def main():
                        "global_batch": B * world, "parallelism": f"utterance-shard x{world}"},
             "x_realtime": value / SAMPLE_RATE, "x_realtime_per_gpu": value / SAMPLE_RATE / world,
             "p50_clip_latency_ms": float(np.percentile(lat, 50)), "p90_clip_latency_ms": float(np.percentile(lat, 90)),
+            "p50_clip_latency_eager_ms": float(np.percentile(lat_eager, 50)),
+            "p90_clip_latency_eager_ms": float(np.percentile(lat_eager, 90)),
             "output_finite": ok,
             "roofline": roofline_from_profile(table, repeats),
         }
         # whole-step view next to the dominant-kernel one: algorithmic flops of the forward (55.97 GFLOP per
         # one-second clip at T_mel = 86; summed here from the profiler's per-launch figures) over the measured step time
-        step_flops = sum(r["flops_per_launch"] * (r["launches"] // repeats) for r in table)
         peak_tf = PEAK_F16X3_TFLOPS if a.precision == "f16x3" else PEAK_MFMA_F32_TFLOPS
-        ach = step_flops / (elapsed / a.steps) / 1e12
-        result["roofline_step"] = {"flops_per_step": step_flops, "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s",
-                                   "frac": ach / peak_tf,
-                                   "note": "all kernels of one forward, measured step time (branch streams + graph replay)"}
+        result["roofline_step"] = step_roofline(table, repeats, elapsed / a.steps * 1e3, peak_tf)
+        result["roofline_step"]["note"] = "all kernels of one forward, measured step time (branch streams + graph replay)"
+        result["with_collectives"] = coll
         if world == 1 and a.precision == "f32" and not a.no_alt_precision:
             # the opt-in f16x3 mode on the same batch: throughput and its deviation from the exact-fp32 output above.
             # Auxiliary: a failure here must not cost the headline line.
             try:
+                eng(mel, out)
                 ref_out = out.clone()
                 eng2 = Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**cfg), state_dict=sd_eng, precision="f16x3")
                 out2 = torch.empty_like(out)
-                for _ in range(a.warmup):
-                    eng2(mel, out2)
-                torch.cuda.synchronize(dev)
-                t1 = time.perf_counter()
-                for _ in range(a.steps):
-                    eng2(mel, out2)
-                torch.cuda.synchronize(dev)
-                dt2 = time.perf_counter() - t1
-                v2 = samples_per_step * a.steps / dt2
+                dt2 = time_engine(eng2, mel, out2, a.steps, a.warmup, dev)
+                v2 = samples_per_step / dt2
                 result["alt_precision"] = {
-                    "precision": "f16x3", "value": v2, "unit": "samples/s", "ms_per_step": dt2 / a.steps * 1e3,
+                    "precision": "f16x3", "value": v2, "unit": "samples/s", "ms_per_step": dt2 * 1e3,
                     "x_realtime": v2 / SAMPLE_RATE, "max_abs_diff_vs_f32_output": float((out2 - ref_out).abs().max().item()),
                     "note": "opt-in (Engine(precision='f16x3')); not the headline value"}
                 eng2.close()
+                del ref_out, out2
             except Exception as exc:  # noqa: BLE001
                 result["alt_precision"] = {"precision": "f16x3", "error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and a.precision == "f32" and not a.no_other_configs:
+            eng.close()
+            del out
+            result["other_configs"] = other_configs(dev, max(5, a.steps // 2), a.warmup)
         if world == 1 and not a.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(cfg, sd, a.cpu_clips, T)

@@ -178,6 +178,11 @@ FV_API void fv_destroy(fv_engine* e);
  * are packed at finalize; later -> FV_ERR_STATE).  No reference counterpart: torch runs this path in fp32 only. */
 FV_API fv_status fv_set_precision(fv_engine* e, int32_t precision);
 
+/* hipGraph replay of the static launch sequence (on by default; a call with the same buffers / shape / stream as an
+ * earlier one replays a captured graph).  enable = 0 makes every fv_forward* enqueue its kernels eagerly — what a server
+ * that never sees the same (buffers, batch, frames) twice gets.  May be called at any time.  No reference counterpart. */
+FV_API fv_status fv_set_graph_replay(fv_engine* e, int32_t enable);
+
 /* -------- forward: replaces `self.generator(input_spec)` (gan.py:286) -------- */
 
 /* Output length per clip for T_in input frames (T_mel * hop_length for the generators). */

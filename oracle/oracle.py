@@ -477,7 +477,8 @@ def refinegan_forward(sd, cfg, mel, template, noise) -> np.ndarray:
     it = iter(noise)
 
     def adain(x, w):                                                           # refinegan.py:124-127
-        return leaky_relu(x + next(it) * w[None, :, None], slope)
+        # AdaIN(channels=...) is built without the generator's slope (refinegan.py:157,165): always LeakyReLU(0.2)
+        return leaky_relu(x + next(it) * w[None, :, None], 0.2)
 
     for i, (r, down) in enumerate(zip(ups_r, reversed(downs))):
         x = leaky_relu(x, slope)

@@ -320,9 +320,10 @@ def gen_istft_head(name, cfg, seed, B, T):
 
 
 @torch.no_grad()
-def gen_bigvgan(name, cfg, seed, B, T, mel_seed):
-    sd = syn.bigvgan_state_dict(cfg, seed)
-    g = BigVGANGenerator(**cfg).eval()
+def gen_bigvgan(name, cfg, seed, B, T, mel_seed, activation=None):
+    """activation=Snake: only activation_post becomes Snake, the AMPBlocks stay SnakeBeta (bigvgan.py:330,335-337)."""
+    sd = syn.bigvgan_state_dict(cfg, seed, post_beta=activation is not Snake)
+    g = (BigVGANGenerator(**cfg) if activation is None else BigVGANGenerator(**cfg, activation=activation)).eval()
     missing, unexpected = g.load_state_dict(_t(sd), strict=False)
     assert not unexpected and all(k.endswith("filter") for k in missing), (missing, unexpected)
     mel = syn.synthetic_mel(B, cfg["num_mels"], T, mel_seed)
@@ -346,7 +347,7 @@ def gen_activation1d():
 
 
 @torch.no_grad()
-def gen_vocos(name, cfg, seed, B, T, mel_seed):
+def gen_vocos(name, cfg, seed, B, T, mel_seed, hidden=True):
     """Intended UnifyGenerator semantics head(backbone(x))[:, None, :] (the YAML as shipped
     raises TypeError on template=)."""
     sd = syn.vocos_state_dict(cfg, seed)
@@ -357,7 +358,8 @@ def gen_vocos(name, cfg, seed, B, T, mel_seed):
     mel = syn.synthetic_mel(B, cfg["backbone"]["input_channels"], T, mel_seed)
     h = bb(torch.from_numpy(mel))
     out = hd(h)[:, None, :].numpy()
-    _save(name, cfg=_cfg_arr(cfg), seed=seed, mel=mel, hidden=h.numpy(), out=out, pinned=False)
+    extra = {"hidden": h.numpy()} if hidden else {}
+    _save(name, cfg=_cfg_arr(cfg), seed=seed, mel=mel, out=out, pinned=False, **extra)
 
 
 @torch.no_grad()
@@ -411,6 +413,13 @@ def gen_refinegan(name, cfg, seed, B, T, mel_seed):
           pinned=True, **interp)
 
 
+ONLY = set(sys.argv[1:])   # optional: fixture file names to (re)generate; default = all
+
+
+def _want(name):
+    return not ONLY or name in ONLY
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -418,42 +427,74 @@ def main():
                 resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
                 num_mels=20, upsample_initial_channel=64, use_template=False,
                 pre_conv_kernel_size=7, post_conv_kernel_size=7)
-    gen_hifigan("hifigan_tiny.npz", tiny, seed=3, B=2, T=13, mel_seed=21)
+    if _want("hifigan_tiny.npz"):
+        gen_hifigan("hifigan_tiny.npz", tiny, seed=3, B=2, T=13, mel_seed=21)
     # narrow channels down to C=2 and odd kernel / rate mixes (edge cases for channel padding)
     narrow = dict(hop_length=32, upsample_rates=[2, 2, 2, 2, 2], upsample_kernel_sizes=[4, 4, 2, 2, 4],
                   resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2, 3], [2, 6, 1]],
                   num_mels=10, upsample_initial_channel=64, use_template=False,
                   pre_conv_kernel_size=5, post_conv_kernel_size=3)
-    gen_hifigan("hifigan_narrow.npz", narrow, seed=4, B=3, T=7, mel_seed=22)
+    if _want("hifigan_narrow.npz"):
+        gen_hifigan("hifigan_narrow.npz", narrow, seed=4, B=3, T=7, mel_seed=22)
     # the BASELINE config (HiFiGAN-V1-44k, 80 mel) on a short clip; weights regenerate from the seed
-    gen_hifigan("hifigan_v1_t12.npz", dict(syn.HIFIGAN_V1_44K), seed=0, B=1, T=12, mel_seed=1234, stages=False)
+    if _want("hifigan_v1_t12.npz"):
+        gen_hifigan("hifigan_v1_t12.npz", dict(syn.HIFIGAN_V1_44K), seed=0, B=1, T=12, mel_seed=1234, stages=False)
     # single-frame clip (ragged minimum)
-    gen_hifigan("hifigan_tiny_t1.npz", tiny, seed=3, B=1, T=1, mel_seed=23, stages=False)
-    gen_hifigan("hifigan_template.npz", dict(tiny, use_template=True), seed=13, B=2, T=9, mel_seed=27)
-    gen_ops()
-    gen_snake()
+    if _want("hifigan_tiny_t1.npz"):
+        gen_hifigan("hifigan_tiny_t1.npz", tiny, seed=3, B=1, T=1, mel_seed=23, stages=False)
+    if _want("hifigan_template.npz"):
+        gen_hifigan("hifigan_template.npz", dict(tiny, use_template=True), seed=13, B=2, T=9, mel_seed=27)
+    if _want("ops.npz"):
+        gen_ops()
+    if _want("snake.npz"):
+        gen_snake()
     cn = dict(input_channels=20, depths=[1, 2], dims=[16, 32], drop_path_rate=0.1, kernel_size=7)
-    gen_convnext("convnext_small.npz", cn, seed=5, B=2, T=17, mel_seed=24)
-    gen_istft_head("istft_head.npz", dict(dim=24, n_fft=64, hop_length=16, win_length=64, padding="same"),
-                   seed=6, B=2, T=9)
+    if _want("convnext_small.npz"):
+        gen_convnext("convnext_small.npz", cn, seed=5, B=2, T=17, mel_seed=24)
+    if _want("istft_head.npz"):
+        gen_istft_head("istft_head.npz", dict(dim=24, n_fft=64, hop_length=16, win_length=64, padding="same"),
+                       seed=6, B=2, T=9)
     bv = dict(hop_length=16, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4],
               resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
               num_mels=20, upsample_initial_channel=64, use_template=False,
               pre_conv_kernel_size=7, post_conv_kernel_size=7)
-    gen_bigvgan("bigvgan_tiny.npz", bv, seed=8, B=2, T=11, mel_seed=25)
-    gen_activation1d()
+    if _want("bigvgan_tiny.npz"):
+        gen_bigvgan("bigvgan_tiny.npz", bv, seed=8, B=2, T=11, mel_seed=25)
+    if _want("activation1d.npz"):
+        gen_activation1d()
     vc = dict(backbone=dict(input_channels=20, depths=[1, 1, 2, 1], dims=[16, 32, 48, 64], drop_path_rate=0.4,
                             kernel_size=7),
               head=dict(dim=64, n_fft=64, hop_length=16, win_length=64, padding="same"))
-    gen_vocos("vocos_tiny.npz", vc, seed=9, B=2, T=15, mel_seed=26)
-    gen_logmel()
+    if _want("vocos_tiny.npz"):
+        gen_vocos("vocos_tiny.npz", vc, seed=9, B=2, T=15, mel_seed=26)
+    if _want("logmel.npz"):
+        gen_logmel()
     rgc = dict(sampling_rate=16000, hop_length=16, downsample_rates=(2, 2, 2, 2), upsample_rates=(2, 2, 2, 2),
                leaky_relu_slope=0.2, num_mels=12, start_channels=4)
-    gen_refinegan("refinegan_tiny.npz", rgc, seed=14, B=2, T=7, mel_seed=31)
+    if _want("refinegan_tiny.npz"):
+        gen_refinegan("refinegan_tiny.npz", rgc, seed=14, B=2, T=7, mel_seed=31)
     # the reference defaults' rate pattern (2, 2, 8, 8) / (8, 8, 2, 2) at a reduced width
     rgd = dict(sampling_rate=44100, hop_length=256, downsample_rates=(2, 2, 8, 8), upsample_rates=(8, 8, 2, 2),
                leaky_relu_slope=0.2, num_mels=16, start_channels=2)
-    gen_refinegan("refinegan_rates.npz", rgd, seed=15, B=1, T=3, mel_seed=33)
+    if _want("refinegan_rates.npz"):
+        gen_refinegan("refinegan_rates.npz", rgd, seed=15, B=1, T=3, mel_seed=33)
+
+    # ---- round 2: BASELINE configs at their stated shapes ----
+    # config[0]/[1]: the full V1 generator on a ONE-SECOND clip (T_mel = 86 -> 44 032 samples), hifigan.py:226-249
+    if _want("hifigan_v1_t86.npz"):
+        gen_hifigan("hifigan_v1_t86.npz", dict(syn.HIFIGAN_V1_44K), seed=0, B=1, T=86, mel_seed=1234, stages=False)
+    # config[3]: vocos.yaml at full depth [3, 3, 27, 3] / dims [128 .. 1024] (configs/model/generator/vocos.yaml:4-8)
+    if _want("vocos_24k_t10.npz"):
+        gen_vocos("vocos_24k_t10.npz", dict(syn.VOCOS_24K), seed=0, B=2, T=10, mel_seed=41, hidden=False)
+    # config[2]: the full-width BigVGAN (512 -> 32 channels, rates 8 8 2 2) on a short clip
+    if _want("bigvgan_24k_t6.npz"):
+        gen_bigvgan("bigvgan_24k_t6.npz", dict(syn.BIGVGAN_24K), seed=0, B=1, T=6, mel_seed=42)
+    # activation=Snake: activation_post has no beta, the AMPBlocks keep theirs
+    if _want("bigvgan_snake_post.npz"):
+        gen_bigvgan("bigvgan_snake_post.npz", bv, seed=18, B=2, T=9, mel_seed=43, activation=Snake)
+    # RefineGAN with leaky_relu_slope != 0.2: AdaIN keeps 0.2 (refinegan.py:157,165), everything else follows the config
+    if _want("refinegan_slope.npz"):
+        gen_refinegan("refinegan_slope.npz", dict(rgc, leaky_relu_slope=0.1), seed=16, B=1, T=5, mel_seed=35)
 
 
 if __name__ == "__main__":

@@ -30,7 +30,8 @@ def _fwd(eng, x):
     return y.cpu().numpy()
 
 
-@pytest.mark.parametrize("name", ["hifigan_tiny.npz", "hifigan_narrow.npz", "hifigan_tiny_t1.npz", "hifigan_v1_t12.npz"])
+@pytest.mark.parametrize("name", ["hifigan_tiny.npz", "hifigan_narrow.npz", "hifigan_tiny_t1.npz", "hifigan_v1_t12.npz",
+                                  "hifigan_v1_t86.npz"])
 def test_hifigan_golden(name):
     g = load_golden(name)
     sd = syn.hifigan_state_dict(g["cfg"], g["seed"])
@@ -38,6 +39,29 @@ def test_hifigan_golden(name):
     assert y.shape == g["out"].shape
     err = np.abs(y - g["out"]).max()
     assert err <= TOL, f"waveform max|d| = {err:.3e} vs reference golden"
+
+
+def test_hifigan_one_second_reference_clip_alone_and_inside_a_full_batch():
+    """BASELINE config[0] / [1]: the reference's own output for a full V1 generator on a 1 s clip (T_mel = 86, hifigan.py:226-249)
+    against the HIP path run alone (latency kernels) and with the same clip placed at three positions of a B = 32 batch of other
+    clips (throughput kernels, flattened / batched tiles)."""
+    g = load_golden("hifigan_v1_t86.npz")
+    sd = syn.hifigan_state_dict(g["cfg"], g["seed"])
+    eng = _hifigan_engine(g["cfg"], sd)
+    assert g["mel"].shape == (1, 80, 86) and g["out"].shape == (1, 1, 44032)
+    y1 = _fwd(eng, g["mel"])
+    assert np.abs(y1 - g["out"]).max() <= TOL
+    mel = syn.synthetic_mel(32, 80, 86, seed=99)
+    for pos in (0, 13, 31):
+        mel[pos] = g["mel"][0]
+    y = _fwd(eng, mel)
+    for pos in (0, 13, 31):
+        err = np.abs(y[pos] - g["out"][0]).max()
+        assert err <= TOL, f"clip at batch position {pos}: max|d| = {err:.3e} vs reference golden"
+    # every other item against the oracle at full length would take minutes; two of them do
+    for i in (7, 30):
+        ref = orc.hifigan_forward(sd, g["cfg"], mel[i:i + 1])
+        assert np.abs(y[i] - ref[0]).max() <= TOL
 
 
 def test_hifigan_v1_vs_oracle_seeded_batch():
@@ -109,6 +133,45 @@ def test_bigvgan_golden_and_oracle():
     y = _fwd(_hifigan_engine(cfg, sd, _lib.FV_MODEL_BIGVGAN), mel)
     err = np.abs(y - ref).max()
     assert err <= TOL, f"max|d| = {err:.3e} vs oracle"
+
+
+@pytest.mark.parametrize("name,kw", [("bigvgan_24k_t6.npz", {}), ("bigvgan_snake_post.npz", {"post_beta": False})])
+def test_bigvgan_full_width_and_snake_post_goldens(name, kw):
+    """Engine and drop-in module against the reference captures: the full-width config[2] generator, and activation=Snake
+    (activation_post only; the AMPBlocks keep SnakeBeta and their beta keys — reference bigvgan.py:330,335-337)."""
+    from vocoder_amd import _lib
+    from vocoder_amd.modules.generators import bigvgan as bv
+    g = load_golden(name)
+    sd = syn.bigvgan_state_dict(g["cfg"], g["seed"], **kw)
+    y = _fwd(_hifigan_engine(g["cfg"], sd, _lib.FV_MODEL_BIGVGAN), g["mel"])
+    assert np.abs(y - g["out"]).max() <= TOL
+    gen = bv.BigVGANGenerator(**g["cfg"], activation=bv.Snake if kw else bv.SnakeBeta).eval()
+    keys = set(gen.state_dict().keys())
+    assert ("activation_post.act.beta" in keys) == (not kw) and "resblocks.0.activations.0.act.beta" in keys
+    missing, unexpected = gen.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("filter") for k in missing), (missing, unexpected)
+    y2 = gen.to(_dev())(torch.from_numpy(g["mel"]).to(_dev()))
+    assert np.abs(y2.cpu().numpy() - g["out"]).max() <= TOL
+
+
+def test_vocos_full_depth_golden_and_oracle():
+    """BASELINE config[3] at its real depth [3, 3, 27, 3] / dims [128 .. 1024] (vocos.yaml:4-8): reference capture (B=2, T=10)
+    and the oracle on another seed."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config
+    g = load_golden("vocos_24k_t10.npz")
+    cfg = g["cfg"]
+    assert cfg["backbone"]["depths"] == [3, 3, 27, 3]
+    sd = syn.vocos_state_dict(cfg, g["seed"])
+    eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), head=istft_head_config(**cfg["head"]),
+                 state_dict=sd)
+    y = _fwd(eng, g["mel"])
+    scale = max(1.0, float(np.abs(g["out"]).max()))
+    assert np.abs(y - g["out"]).max() <= TOL * scale, (np.abs(y - g["out"]).max(), scale)
+    mel = syn.synthetic_mel(2, 80, 10, seed=61)
+    ref = orc.vocos_forward(sd, cfg, mel)
+    y = _fwd(eng, mel)
+    assert np.abs(y - ref).max() <= TOL * max(1.0, float(np.abs(ref).max()))
 
 
 def test_convnext_and_vocos():
@@ -240,7 +303,7 @@ def test_template_branch_golden_and_module():
     assert np.abs(y.cpu().numpy() - ref).max() <= TOL
 
 
-@pytest.mark.parametrize("name", ["refinegan_tiny.npz", "refinegan_rates.npz"])
+@pytest.mark.parametrize("name", ["refinegan_tiny.npz", "refinegan_rates.npz", "refinegan_slope.npz"])
 def test_refinegan_golden(name):
     """RefineGAN through the engine (fv_forward_refinegan) and through the drop-in module, against the reference capture."""
     from vocoder_amd import _lib
@@ -388,6 +451,38 @@ def test_two_engines_on_two_host_threads_match_single_threaded_results():
         assert torch.equal(g, w)
 
 
+def test_one_engine_shared_by_two_threads_and_streams_is_serialised():
+    """One engine owns one workspace and one set of branch streams: forwards from two host threads on two torch streams are
+    serialised by the handle (host lock + event chain), so they cannot corrupt each other."""
+    import threading
+    cfg = dict(hop_length=16, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4], resblock_kernel_sizes=[3, 7, 11],
+               resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=20, upsample_initial_channel=64, use_template=False)
+    eng = _hifigan_engine(cfg, syn.hifigan_state_dict(cfg, 5))
+    xs = [torch.from_numpy(syn.synthetic_mel(4, 20, 150 + 40 * i, 31 + i)).to(_dev()) for i in range(2)]
+    want = [eng(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    bad, errs = [0, 0], []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(25):
+                    y = eng(xs[i])
+                    s.synchronize()
+                    bad[i] += int(not torch.equal(y, want[i]))
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert bad == [0, 0], bad
+
+
 _RES = {"24000_256_1024": dict(num_mels=100, n_fft=1024, hop_length=256, win_length=1024),
         "44100_512_2048": dict(num_mels=128, n_fft=2048, hop_length=512, win_length=2048)}
 
@@ -497,6 +592,35 @@ def test_template_branch_with_a_long_first_stage_stride_vs_oracle():
     y = eng(torch.from_numpy(mel).to(_dev()), None, torch.from_numpy(tmpl).to(_dev()))
     torch.cuda.synchronize()
     assert np.abs(y.cpu().numpy() - ref).max() <= TOL
+
+
+def test_bigvgan_and_vocos_at_the_baseline_batch_sizes_vs_oracle():
+    """BASELINE config[2] (BigVGAN-24k, B = 64) and config[3] (Vocos-24k, depths [3,3,27,3], B = 128) at their stated sizes,
+    94 frames = 1 s: finite, deterministic, every checked item equal to the same clip run alone, and the first / last items
+    against the CPU oracle run on the whole 1 s clip."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config, upsampler_config
+    cfg = dict(syn.BIGVGAN_24K)
+    sdb = syn.bigvgan_state_dict(cfg, 0)
+    eng = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=sdb)
+    cfgv = dict(syn.VOCOS_24K)
+    sdv = syn.vocos_state_dict(cfgv, 0)
+    engv = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfgv["backbone"]), head=istft_head_config(**cfgv["head"]),
+                  state_dict=sdv)
+    for e, B, oracle in ((eng, 64, lambda m: orc.bigvgan_forward(sdb, cfg, m)), (engv, 128, lambda m: orc.vocos_forward(sdv, cfgv, m))):
+        mel = syn.synthetic_mel(B, 80, 94, seed=B)
+        y = _fwd(e, mel)
+        assert y.shape == (B, 1, 94 * 256) and np.isfinite(y).all()
+        assert np.array_equal(y, _fwd(e, mel))
+        scale = max(1.0, np.abs(y).max())
+        for i in (0, B // 2, B - 1):
+            yi = _fwd(e, mel[i:i + 1])
+            assert np.abs(yi[0] - y[i]).max() <= 3e-5 * scale, (i, np.abs(yi[0] - y[i]).max(), scale)
+        for i in (0, B - 1):
+            ref = oracle(mel[i:i + 1])
+            err = np.abs(ref[0] - y[i]).max()
+            assert err <= TOL * scale, f"B={B} item {i}: max|d| = {err:.3e} vs oracle on the full clip (scale {scale:.2f})"
+        e.close()
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])

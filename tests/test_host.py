@@ -125,6 +125,27 @@ def test_lightning_checkpoint_prefix_and_mel_preparation(tmp_path):
         InferenceModel(torch.nn.Identity())(torch.zeros(1, 1, 8))
 
 
+class _HParams:   # a module-level non-tensor object, like the DictConfig / callbacks a Lightning .ckpt carries
+    def __init__(self):
+        self.lr = 1e-4
+
+
+def test_lightning_checkpoint_with_non_tensor_objects_needs_explicit_trust(tmp_path):
+    """The reference loads checkpoints with a plain torch.load (test.py:32); ours is weights-only by default and says how to
+    opt in when a checkpoint holds pickled objects."""
+    from vocoder_amd.inference import load_generator_state_dict
+    sd = {"generator.conv_pre.bias": torch.arange(4.0), "discriminators.x": torch.zeros(1)}
+    p = tmp_path / "lightning.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": _HParams(), "epoch": 3}, p)
+    with pytest.raises(RuntimeError, match="trust-checkpoint"):
+        load_generator_state_dict(p)
+    got = load_generator_state_dict(p, trust_checkpoint=True)
+    assert list(got) == ["conv_pre.bias"] and torch.equal(got["conv_pre.bias"], torch.arange(4.0))
+    q = tmp_path / "weights.pt"            # tensors only: loads without the opt-in
+    torch.save({"state_dict": sd}, q)
+    assert list(load_generator_state_dict(q)) == ["conv_pre.bias"]
+
+
 def test_shard_slices_cover_batch_exactly():
     for batch, world in [(256, 8), (5, 8), (0, 2), (33, 4), (1, 1)]:
         sizes = shard_sizes(batch, world)
@@ -211,3 +232,27 @@ def test_refinegan_dropin_has_the_reference_state_dict_keys():
     assert gen.noise_elems(2, 7) == sum(2 * c * t for c, t in syn.refinegan_stage_shapes(cfg, 7)) * 6
     with pytest.raises(AssertionError):
         RefineGANGenerator(**dict(cfg, hop_length=32))   # refinegan.py:202
+
+
+def test_bench_self_launches_n_ranks_without_torchrun():
+    """`python bench.py --gpus 2` (no torchrun environment) must re-execute itself as 2 ranks through torch.distributed.run
+    and report n_gpus == the process group's world size (a plain `--gpus 8` silently ran one rank).  --dry-run
+    exercises only the launcher, the process group (gloo here, RCCL on a GPU box) and the scatter/gather plumbing."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""    # the CPU path of the dry run, also on a GPU box
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run", "--batch", "3"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 prints exactly one line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["scatter_gather_ok"] is True and j["dry_run"] is True
+    # and a mismatch between --gpus and an existing torchrun environment is an error, not a silent single-rank run
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=repo)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

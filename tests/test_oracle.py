@@ -58,7 +58,7 @@ def test_snake_variants():
 
 
 @pytest.mark.parametrize("name", ["hifigan_tiny.npz", "hifigan_narrow.npz", "hifigan_tiny_t1.npz",
-                                  "hifigan_v1_t12.npz"])
+                                  "hifigan_v1_t12.npz", "hifigan_v1_t86.npz"])   # t86 = BASELINE config[0]: one 1 s clip
 def test_hifigan_forward_matches_reference(name):
     g = load_golden(name)
     sd = syn.hifigan_state_dict(g["cfg"], g["seed"])
@@ -157,6 +157,25 @@ def test_bigvgan_forward_matches_reference_wiring():
     _close(orc.bigvgan_forward(sd, g["cfg"], g["mel"]), g["out"], 3e-5)
 
 
+@pytest.mark.parametrize("name,kw", [("bigvgan_24k_t6.npz", {}), ("bigvgan_snake_post.npz", {"post_beta": False})])
+def test_bigvgan_full_width_and_snake_post_match_reference_wiring(name, kw):
+    """Full-width BASELINE config[2] generator on a short clip; and activation=Snake, which only changes activation_post
+    (the AMPBlocks are built without the argument and stay SnakeBeta, bigvgan.py:330,335-337)."""
+    g = load_golden(name)
+    sd = syn.bigvgan_state_dict(g["cfg"], g["seed"], **kw)
+    assert ("activation_post.act.beta" in sd) == (not kw) and "resblocks.0.activations.0.act.beta" in sd
+    _close(orc.bigvgan_forward(sd, g["cfg"], g["mel"]), g["out"], 3e-5)
+
+
+def test_vocos_full_depth_matches_reference_wiring():
+    """BASELINE config[3]: vocos.yaml at depths [3, 3, 27, 3], dims [128 .. 1024] (configs/model/generator/vocos.yaml:4-8)."""
+    g = load_golden("vocos_24k_t10.npz")
+    assert g["cfg"]["backbone"]["depths"] == [3, 3, 27, 3]
+    sd = syn.vocos_state_dict(g["cfg"], g["seed"])
+    y = orc.vocos_forward(sd, g["cfg"], g["mel"])
+    _close(y, g["out"], 3e-5, 1e-5)
+
+
 def test_vocos_forward_matches_reference_wiring():
     g = load_golden("vocos_tiny.npz")
     sd = syn.vocos_state_dict(g["cfg"], g["seed"])
@@ -185,7 +204,7 @@ def test_logmel_frontend_matches_reference():
         _close(orc.logmel_forward(z[f"{tag}_wave"], cfg), z[f"{tag}_logmel"], 2e-5)
 
 
-@pytest.mark.parametrize("name", ["refinegan_tiny.npz", "refinegan_rates.npz"])
+@pytest.mark.parametrize("name", ["refinegan_tiny.npz", "refinegan_rates.npz", "refinegan_slope.npz"])   # slope.npz: 0.1
 def test_refinegan_oracle_matches_reference_golden(name):
     """RefineGANGenerator (refinegan.py:182-323) captured from the reference with AdaIN's torch.randn_like replaced by seeded
     samples; the oracle consumes the same samples."""
@@ -252,3 +271,94 @@ def test_alias_free_resamplers_against_scipy_upfirdn():
             full = np.convolve(ap, taps[::-1])                     # conv1d (correlation, 'valid', stride 2) = full[k-1 :: 2]
             assert np.allclose(d, full[::2])
             assert np.abs(full[11::2][:50] - dn[b, c]).max() <= 2e-6
+
+
+# ---- a10 / a17 pinned against an independent PUBLISHED copy of the two third-party algorithms -------------------------
+# alias_free_torch==0.0.6 and vocos==0.0.2 are not in the image, but `transformers` (installed) vendors both algorithms:
+# Qwen2.5-Omni's BigVGAN code-to-wav decoder carries alias-free-torch's kaiser_sinc_filter1d / UpSample1d / DownSample1d /
+# Activation1d + SnakeBeta, and X-Codec2's head carries vocos' "same"-padding ISTFT (irfft -> window -> fold -> crop ->
+# envelope division).  Status after these tests: "unpinned vs the named package, pinned vs an independent published copy".
+def _qwen_omni():
+    return pytest.importorskip("transformers.models.qwen2_5_omni.modeling_qwen2_5_omni")
+
+
+def test_kaiser_sinc_taps_against_transformers_vendored_alias_free():
+    m = _qwen_omni()
+    for cutoff, hw, ks in [(0.25, 0.3, 12), (0.25, 0.3, 11), (0.125, 0.15, 24), (0.5 / 3, 0.6 / 3, 18)]:
+        ref = m.kaiser_sinc_filter1d(cutoff, hw, ks).reshape(-1).numpy()
+        _close(orc.kaiser_sinc_filter(cutoff, hw, ks), ref, 2e-7)
+
+
+def test_resamplers_against_transformers_vendored_alias_free():
+    import torch
+    m = _qwen_omni()
+    rng = np.random.default_rng(11)
+    taps = orc.kaiser_sinc_filter(0.25, 0.3, 12)
+    up, dn = m.Qwen2_5OmniUpSample1d(2, 12), m.Qwen2_5OmniDownSample1d(2, 12)
+    for shape in [(2, 3, 40), (1, 5, 1), (1, 2, 7), (3, 1, 129)]:   # incl. a single-sample clip (all replicate padding)
+        x = rng.normal(size=shape).astype(np.float32) * 3
+        with torch.no_grad():
+            u = up(torch.from_numpy(x)).numpy()
+            d = dn(torch.from_numpy(u)).numpy()
+        _close(orc.upsample_fir(x, taps, 2), u, 2e-6, 1e-6)
+        _close(orc.downsample_fir(u, taps, 2), d, 2e-6, 1e-6)
+
+
+def test_activation1d_snakebeta_against_transformers_vendored_alias_free():
+    """Activation1d(SnakeBeta(C, alpha_logscale=True)) — the exact composition bigvgan.py:226-233,335-337 builds."""
+    import torch
+    m = _qwen_omni()
+    rng = np.random.default_rng(12)
+    C = 6
+    act = m.Qwen2_5OmniSnakeBeta(C)
+    alpha = rng.normal(size=C).astype(np.float32) * 0.5
+    beta = rng.normal(size=C).astype(np.float32) * 0.5
+    with torch.no_grad():
+        act.alpha.copy_(torch.from_numpy(alpha))
+        act.beta.copy_(torch.from_numpy(beta))
+    aa = m.Qwen2_5OmniAntiAliasedActivation1d(act)
+    taps = orc.kaiser_sinc_filter(0.25, 0.3, 12)
+    for T in (1, 9, 64, 257):
+        x = rng.normal(size=(2, C, T)).astype(np.float32) * 2
+        with torch.no_grad():
+            ref = aa(torch.from_numpy(x)).numpy()
+        y = orc.activation1d(x, lambda z: orc.snake(z, alpha, beta, True), taps, taps)
+        _close(y, ref, 3e-6, 2e-6)
+    # SnakeBeta alone, same parameters (a9 is pinned by the reference itself; this ties the two copies together)
+    x = rng.normal(size=(1, C, 33)).astype(np.float32)
+    with torch.no_grad():
+        _close(orc.snake(x, alpha, beta, True), act(torch.from_numpy(x)).numpy(), 2e-6, 1e-6)
+
+
+def test_istft_same_against_transformers_vendored_vocos_istft():
+    """X-Codec2's head = exp/clamp(100)/polar -> irfft -> hann -> fold -> crop (n_fft-hop)/2 -> envelope division, i.e.
+    ISTFTHead.forward after the projection (vocos.py:57-69) + vocos.spectral_ops.ISTFT('same').  The head's Linear is set to
+    the identity so that its input IS (log-magnitude, phase)."""
+    import torch
+    x2 = pytest.importorskip("transformers.models.xcodec2.modeling_xcodec2")
+    rng = np.random.default_rng(13)
+    for n_fft, hop, T, B in [(64, 16, 12, 2), (1024, 256, 9, 1), (32, 8, 1, 1), (48, 12, 5, 3)]:
+        nb = n_fft // 2 + 1
+
+        class _Cfg:
+            hidden_size = 2 * nb
+        _Cfg.n_fft, _Cfg.hop_length = n_fft, hop
+        head = x2.Xcodec2ISTFTHead(_Cfg())
+        with torch.no_grad():
+            head.linear.weight.copy_(torch.eye(2 * nb))
+            head.linear.bias.zero_()
+        logmag = rng.normal(size=(B, nb, T)).astype(np.float32)
+        logmag[0, 0, 0] = 6.0                       # exp(6) = 403 -> exercises the clamp at 100 (vocos.py:60)
+        phase = (rng.uniform(-4, 4, size=(B, nb, T))).astype(np.float32)
+        h = np.concatenate([logmag, phase], 1).transpose(0, 2, 1)   # (B, T, 2*nb)
+        with torch.no_grad():
+            ref = head(torch.from_numpy(np.ascontiguousarray(h))).numpy()[:, 0]
+        mag = np.minimum(np.exp(logmag.astype(np.float64)), 100.0)
+        re = np.zeros((B, n_fft, T), np.float32)
+        im = np.zeros((B, n_fft, T), np.float32)
+        re[:, :nb] = (mag * np.cos(phase.astype(np.float64))).astype(np.float32)
+        im[:, :nb] = (mag * np.sin(phase.astype(np.float64))).astype(np.float32)
+        y = orc.istft_same(re, im, n_fft, hop, n_fft)
+        assert y.shape == ref.shape == (B, T * hop)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(y - ref).max() <= 5e-6 * scale, np.abs(y - ref).max()

@@ -475,6 +475,7 @@ static fv_status conv_pair_run_f16x3(const ConvLayer& c1, const ConvLayer& c2, c
         default: break;
     }
     if (!ok) {
+        if (dynamic_lds_refused()) return FV_ERR_HIP;
         set_error("conv_pair_run: no f16x3 pair kernel for (C=%d k=%d d=%d)", C, c1.k, c1.dil);
         return FV_ERR_UNSUPPORTED;
     }
@@ -521,6 +522,7 @@ static fv_status conv_pair16_run_f16x3(const ConvLayer& c1, const ConvLayer& c2,
     p.out_scale = out_scale;
     const int prof_idx = prof_begin(stream);
     if (!launch_pair16_f16x3(p, c1.k, c1.dil, batch, stream)) {
+        if (dynamic_lds_refused()) return FV_ERR_HIP;   // error text already names the refused attribute
         set_error("conv_pair_run: no f16x3 pair kernel for (C=16 k=%d d=%d)", c1.k, c1.dil);
         return FV_ERR_UNSUPPORTED;
     }
@@ -567,6 +569,7 @@ fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x
     p.out_scale = out_scale;
     const int prof_idx = prof_begin(stream);
     if (!launch_resblock_pair(p, C, c1.k, c1.dil, batch, stream)) {
+        if (dynamic_lds_refused()) return FV_ERR_HIP;
         set_error("conv_pair_run: no kernel for (C=%d k=%d d=%d)", C, c1.k, c1.dil);
         return FV_ERR_UNSUPPORTED;
     }

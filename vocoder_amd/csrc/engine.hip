@@ -33,6 +33,25 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 void set_last_kernel(const char* name) { g_kernel = name; }
+static thread_local bool g_lds_refused = false;
+bool dynamic_lds_refused() {   // true once after a failed ensure_dynamic_lds (lets the caller keep that error text)
+    const bool r = g_lds_refused;
+    g_lds_refused = false;
+    return r;
+}
+bool ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long* done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && dev >= 0 && dev < 64 && (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) >> dev & 1ull)) return true;
+    if (e == hipSuccess) e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d B) failed on device %d: %s", bytes, dev, hipGetErrorString(e));
+        g_lds_refused = true;
+        return false;
+    }
+    if (dev >= 0 && dev < 64) __atomic_fetch_or(done_mask, 1ull << dev, __ATOMIC_RELEASE);   // devices >= 64: set every time
+    return true;
+}
 int num_cus() {
     static thread_local int cached_dev = -1, cached = 0;
     int dev = 0;
@@ -526,6 +545,8 @@ struct fv_engine {
 };
 
 static int get_padding(int k, int d = 1) { return (k * d - d) / 2; }  // hifigan.py:21-22
+// RefineGAN builds AdaIN(channels=...) without forwarding the generator's slope (refinegan.py:157,165): always 0.2
+constexpr float kAdaINSlope = 0.2f;
 
 fv_status fv_engine::build_upsampler(const std::string& pfx, bool bigvgan) {
     const fv_upsampler_config& c = cfg.ups;
@@ -1235,6 +1256,15 @@ FV_API fv_status fv_set_precision(fv_engine* e, int32_t precision) {
     return FV_OK;
 }
 
+FV_API fv_status fv_set_graph_replay(fv_engine* e, int32_t enable) {
+    if (!e) {
+        set_error("fv_set_graph_replay: null engine");
+        return FV_ERR_INVALID;
+    }
+    e->use_graph = enable != 0;
+    return FV_OK;
+}
+
 FV_API fv_status fv_finalize(fv_engine* e) {
     if (!e) {
         set_error("fv_finalize: null engine");
@@ -1688,11 +1718,11 @@ fv_status fv_engine::run_refinegan(const float* d_mel, float* d_out, int B, int 
         if ((st = conv_layer_run(u.input_conv, r, s))) return st;
         const size_t nelem = (size_t)B * u.cout * t;
         for (int j = 0; j < 3; ++j) {
-            FV_PROF(s, "adain", 3.0 * nelem, 12.0 * nelem, launch_adain(XI, noise, u.d_w1[j], XA, B, u.cout, t, slope, 0, 1.0f, s));
+            FV_PROF(s, "adain", 3.0 * nelem, 12.0 * nelem, launch_adain(XI, noise, u.d_w1[j], XA, B, u.cout, t, kAdaINSlope, 0, 1.0f, s));
             noise += nelem;
             if ((st = resblock(u.rb[j], XA, CAT, XT, XB, t, /*post_leaky=*/false))) return st;   // CAT is free again: branch output
             FV_PROF(s, "adain", 4.0 * nelem, 16.0 * nelem,
-                    launch_adain(CAT, noise, u.d_w2[j], Y, B, u.cout, t, slope, j > 0, j == 2 ? 1.0f / 3.0f : 1.0f, s));
+                    launch_adain(CAT, noise, u.d_w2[j], Y, B, u.cout, t, kAdaINSlope, j > 0, j == 2 ? 1.0f / 3.0f : 1.0f, s));
             noise += nelem;
         }
         xcur = Y;

@@ -41,6 +41,18 @@ void prof_end(hipStream_t s, int idx, const char* label, double flops, double by
         }                                                                                        \
     } while (0)
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS (gfx950: 160 KiB per CU).  The attribute is PER DEVICE, so the
+// "already done" state is a bit per device ordinal (one mask per call site), set with an atomic OR: a process that drives
+// several GPUs, or several host threads, gets every (kernel, device) pair opted in exactly once.  Returns false and sets
+// the error string when the runtime refuses.
+bool ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long* done_mask);
+bool dynamic_lds_refused();
+#define FV_ENSURE_DYN_LDS(kernel, bytes)                                                   \
+    ([&]() -> bool {                                                                       \
+        static unsigned long long _fv_mask = 0;                                            \
+        return ::fv::ensure_dynamic_lds((const void*)(kernel), (int)(bytes), &_fv_mask);   \
+    }())
+
 // ---------------------------------------------------------------------------------------------
 // Fused conv layer ("implicit GEMM on fp32 MFMA").
 //

@@ -252,12 +252,7 @@ template <int KS, int DIL1>
 static bool launch_pair16_one(PairF16Params q, int batch, hipStream_t s) {
     using G = Pair16Geom<KS, DIL1>;
     q.n_tiles = (q.T + G::TT - 1) / G::TT;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)pair16_f16x3_kernel<KS, DIL1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)G::LDS_BYTES);
-        attr = true;
-    }
+    if (!FV_ENSURE_DYN_LDS((pair16_f16x3_kernel<KS, DIL1>), G::LDS_BYTES)) return false;
     hipLaunchKernelGGL((pair16_f16x3_kernel<KS, DIL1>), dim3(batch * q.n_tiles), dim3(256), G::LDS_BYTES, s, q);
     return true;
 }

@@ -301,16 +301,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pair_f16x3_kernel(const PairF
 }
 
 template <int KS, int DIL1, int WM, int WN, int NT>
-inline void launch_pair_f16x3_one(PairF16Params q, int batch, hipStream_t s) {
+inline bool launch_pair_f16x3_one(PairF16Params q, int batch, hipStream_t s) {
     using G = PairF16Geom<KS, DIL1, WM, WN, NT>;
     q.n_tiles = (q.T + G::TT - 1) / G::TT;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)pair_f16x3_kernel<KS, DIL1, WM, WN, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)G::LDS_BYTES);
-        attr = true;
-    }
+    if (!FV_ENSURE_DYN_LDS((pair_f16x3_kernel<KS, DIL1, WM, WN, NT>), G::LDS_BYTES)) return false;
     hipLaunchKernelGGL((pair_f16x3_kernel<KS, DIL1, WM, WN, NT>), dim3(batch * q.n_tiles), dim3(WM * WN * 64), G::LDS_BYTES, s, q);
+    return true;
 }
 
 // C = 128: 128 rows x 96 intermediate columns; C = 64: 64 rows x 128 columns (49 / 33 KB of LDS, two workgroups per CU);
@@ -318,20 +314,16 @@ inline void launch_pair_f16x3_one(PairF16Params q, int batch, hipStream_t s) {
 template <int KS, int DIL1>
 inline bool launch_pair_f16x3_cfg(const PairF16Params& p, int C, int batch, hipStream_t s) {
     if (C == 128) {
-        launch_pair_f16x3_one<KS, DIL1, 4, 1, 3>(p, batch, s);
-        return true;
+        return launch_pair_f16x3_one<KS, DIL1, 4, 1, 3>(p, batch, s);
     }
     if (C == 64) {
-        launch_pair_f16x3_one<KS, DIL1, 2, 2, 2>(p, batch, s);
-        return true;
+        return launch_pair_f16x3_one<KS, DIL1, 2, 2, 2>(p, batch, s);
     }
     if (C == 256) {   // eight waves (one m-tile each), 98 KB of intermediate planes: one workgroup per CU, two waves per SIMD
-        launch_pair_f16x3_one<KS, DIL1, 8, 1, 3>(p, batch, s);
-        return true;
+        return launch_pair_f16x3_one<KS, DIL1, 8, 1, 3>(p, batch, s);
     }
     if (C == 32) {    // a single m-tile: the four waves split the columns (A fragments reused across NT n-tiles only)
-        launch_pair_f16x3_one<KS, DIL1, 1, 4, kPairF16NtC32>(p, batch, s);
-        return true;
+        return launch_pair_f16x3_one<KS, DIL1, 1, 4, kPairF16NtC32>(p, batch, s);
     }
     return false;
 }

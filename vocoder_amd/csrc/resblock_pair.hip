@@ -358,11 +358,7 @@ static bool launch_pair_c(const PairParams& p, int C, int batch, hipStream_t s) 
         PairParams q = p;
         q.n_tiles = (p.T + G::TT - 1) / G::TT;
         const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)resblock_pair16_kernel<KS, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        if (!FV_ENSURE_DYN_LDS((resblock_pair16_kernel<KS, DIL>), lds)) return false;
         hipLaunchKernelGGL((resblock_pair16_kernel<KS, DIL>), dim3(batch * q.n_tiles), dim3(256), lds, s, q);
         return true;
     }
@@ -371,11 +367,7 @@ static bool launch_pair_c(const PairParams& p, int C, int batch, hipStream_t s) 
         PairParams q = p;
         q.n_tiles = (p.T + G::TT - 1) / G::TT;
         const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)resblock_pair32_kernel<KS, DIL, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        if (!FV_ENSURE_DYN_LDS((resblock_pair32_kernel<KS, DIL, 32>), lds)) return false;
         hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 32>), dim3(batch * q.n_tiles), dim3(256), lds, s, q);
         return true;
     }
@@ -384,11 +376,7 @@ static bool launch_pair_c(const PairParams& p, int C, int batch, hipStream_t s) 
         PairParams q = p;
         q.n_tiles = (p.T + G::TT - 1) / G::TT;
         const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)resblock_pair32_kernel<KS, DIL, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        if (!FV_ENSURE_DYN_LDS((resblock_pair32_kernel<KS, DIL, 64>), lds)) return false;
         hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 64>), dim3(batch * q.n_tiles), dim3(256), lds, s, q);
         return true;
     }

@@ -739,11 +739,7 @@ fv_status launch_noise_conv_add(const float* tmpl, const float* w, const float* 
         return FV_ERR_UNSUPPORTED;
     }
     if (lds > 64 * 1024) {    // above the default dynamic-LDS limit: opt in (gfx950 has 160 KiB per CU)
-        static bool attr = false;
-        if (!attr) {
-            FV_HIP_CHECK(hipFuncSetAttribute((const void*)noise_conv_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr = true;
-        }
+        if (!FV_ENSURE_DYN_LDS(noise_conv_add_kernel, 160 * 1024)) return FV_ERR_HIP;
     }
     hipLaunchKernelGGL(noise_conv_add_kernel, dim3(B * n_tiles), dim3(256), lds, s, tmpl, w, bias, x, C, T, Ta, k, stride, pad,
                        n_tiles);

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import Mapping
 
 import numpy as np
@@ -148,6 +149,11 @@ class Engine:
         self.out_channels = self._lib.fv_output_channels(self._h)
         self._ws: torch.Tensor | None = None
         self._side: torch.cuda.Stream | None = None
+        # One engine owns ONE workspace and one set of branch streams / events (fv_engine): forwards on the same engine are
+        # serialised — a host lock around the enqueue, and an event recorded after each forward that the next forward's
+        # stream waits on, so that calls from two threads or two torch streams cannot overlap on the device either.
+        self._lock = threading.Lock()
+        self._done: torch.cuda.Event | None = None
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -159,6 +165,10 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_graph_replay(self, enable: bool) -> None:
+        """hipGraph replay of repeated identical calls (default on); off = every forward enqueues its kernels eagerly."""
+        check(self._lib.fv_set_graph_replay(self._h, int(bool(enable))))
 
     def output_length(self, t_in: int) -> int:
         return int(self._lib.fv_output_length(self._h, int(t_in)))
@@ -201,21 +211,28 @@ class Engine:
                 raise ValueError(f"expected {self.noise_elems(B, T)} fp32 noise samples, got {noise.numel()} ({noise.dtype})")
             nptr = noise.data_ptr()
         need = self.workspace_bytes(B, T)
-        if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != x.device:
-            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with self._lock, torch.cuda.device(x.device):
+            if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != x.device:
+                if self._done is not None:
+                    self._done.synchronize()   # the old workspace goes back to the caching allocator: nothing may still use it
+                self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
             cur = torch.cuda.current_stream(x.device)
+            run = cur
             if cur.cuda_stream == 0:
                 # The legacy default stream cannot be stream-captured, which would rule out the engine's hipGraph
                 # replay.  Run on an engine-owned side stream, ordered after / before the caller's stream.
                 if self._side is None or self._side.device != x.device:
                     self._side = torch.cuda.Stream(x.device)
-                side = self._side
-                side.wait_stream(cur)
-                check(self._launch(x, tptr, nptr, out, B, T, int(side.cuda_stream)))
-                cur.wait_stream(side)
-            else:
-                check(self._launch(x, tptr, nptr, out, B, T, int(cur.cuda_stream)))
+                run = self._side
+                run.wait_stream(cur)
+            if self._done is not None:
+                run.wait_event(self._done)       # order after the previous forward, whatever stream it ran on
+            check(self._launch(x, tptr, nptr, out, B, T, int(run.cuda_stream)))
+            if self._done is None:
+                self._done = torch.cuda.Event()
+            self._done.record(run)
+            if run is not cur:
+                cur.wait_stream(run)
         return out
 
     def _launch(self, x, tptr, nptr, out, B, T, stream: int) -> int:

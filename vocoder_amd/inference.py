@@ -46,11 +46,26 @@ class InferenceModel(nn.Module):
         return self.generator(input_spec), 0
 
 
-def load_generator_state_dict(ckpt) -> dict:
+def load_generator_state_dict(ckpt, trust_checkpoint: bool = False) -> dict:
     """Raw state dict, or Lightning checkpoint with the ``generator.`` prefix (other prefixes — discriminators,
-    mel_transforms — are dropped, they are not part of the generator)."""
+    mel_transforms — are dropped, they are not part of the generator).
+
+    Files are read with ``torch.load(weights_only=True)``.  The reference (test.py:32) uses a plain ``torch.load``, and real
+    Lightning ``.ckpt`` files usually carry non-tensor objects (hyper_parameters as a DictConfig, callbacks, optimizer
+    state) that the weights-only unpickler rejects: pass ``trust_checkpoint=True`` (CLI ``--trust-checkpoint``) to fall
+    back to a full unpickle for a file you trust, or export just the tensors once with
+    ``torch.save({"state_dict": ckpt["state_dict"]}, "weights.pt")``."""
     if isinstance(ckpt, (str, Path)):
-        ckpt = torch.load(ckpt, map_location="cpu", weights_only=True)
+        path = ckpt
+        try:
+            ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception as exc:  # noqa: BLE001 - pickle.UnpicklingError or a RuntimeError wrapping it, by torch version
+            if not trust_checkpoint:
+                raise RuntimeError(
+                    f"{path}: the weights-only loader refused this checkpoint ({type(exc).__name__}: {str(exc)[:200]}). "
+                    "Lightning checkpoints often hold non-tensor objects (hyper_parameters, callbacks). If you trust the "
+                    "file, pass trust_checkpoint=True / --trust-checkpoint, or re-save only its 'state_dict'.") from exc
+            ckpt = torch.load(path, map_location="cpu", weights_only=False)
     if "state_dict" in ckpt:
         ckpt = ckpt["state_dict"]
     if any(k.startswith("generator.") for k in ckpt):
@@ -109,11 +124,11 @@ def read_wav(path) -> tuple[np.ndarray, int]:
 
 
 def build_model(generator="hifigan", resolution="44100_512_2048", overrides=None, config_root=None,
-                ckpt_path=None, device="cuda") -> InferenceModel:
+                ckpt_path=None, device="cuda", trust_checkpoint=False) -> InferenceModel:
     from .data.transforms import LogMelSpectrogram
     gen, cfg = fvconfig.build_generator(generator, resolution, overrides, config_root)
     if ckpt_path is not None:
-        gen.load_state_dict(load_generator_state_dict(ckpt_path), strict=True)
+        gen.load_state_dict(load_generator_state_dict(ckpt_path, trust_checkpoint), strict=True)
     m = cfg["model"]
     # configs/model/spectrogram/mel.yaml:1-8 (mel_transforms.input)
     mel = LogMelSpectrogram(sample_rate=m["sampling_rate"], n_fft=m["n_fft"], win_length=m["win_length"],
@@ -133,9 +148,12 @@ def main(argv=None):
     ap.add_argument("--output-path", required=True)
     ap.add_argument("--num-mels", type=int, default=None)
     ap.add_argument("--diffsinger", action="store_true", help="inputs are log10 mels")
+    ap.add_argument("--trust-checkpoint", action="store_true",
+                    help="fall back to a full unpickle (like the reference's plain torch.load) when the weights-only loader "
+                         "refuses a Lightning checkpoint that holds non-tensor objects")
     a = ap.parse_args(argv)
     model = build_model(a.generator, a.resolution, {"num_mels": a.num_mels} if a.num_mels else None, a.config_root,
-                        a.ckpt_path)
+                        a.ckpt_path, trust_checkpoint=a.trust_checkpoint)
     inp = Path(a.input_path)
     files = [inp] if inp.is_file() else sorted(p for p in inp.rglob("*") if p.suffix in (".pt", ".pth", ".wav"))
     base = inp.parent if inp.is_file() else inp

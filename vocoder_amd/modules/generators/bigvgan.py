@@ -121,8 +121,10 @@ class BigVGANGenerator(_base.EngineModule):
         self.ups = nn.ModuleList(
             weight_norm(nn.ConvTranspose1d(c0 >> i, c0 >> (i + 1), k, u, padding=(k - u) // 2))
             for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)))
+        # the reference builds AMPBlock(ch, k, d) with no activation argument (bigvgan.py:330): the blocks are always
+        # SnakeBeta(alpha_logscale=True); the generator's `activation` only selects activation_post (bigvgan.py:335-337)
         self.resblocks = nn.ModuleList(
-            AMPBlockParams(c0 >> (i + 1), k, d, activation=activation)
+            AMPBlockParams(c0 >> (i + 1), k, d)
             for i in range(self.num_upsamples) for k, d in zip(resblock_kernel_sizes, resblock_dilation_sizes))
         ch = c0 >> self.num_upsamples
         self.activation_post = Activation1dParams(activation(ch, alpha_logscale=True))

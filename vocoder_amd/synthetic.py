@@ -80,7 +80,7 @@ def hifigan_state_dict(cfg: dict, seed: int = 0) -> dict:
     return sd
 
 
-def bigvgan_state_dict(cfg: dict, seed: int = 0, with_filters: bool = True) -> dict:
+def bigvgan_state_dict(cfg: dict, seed: int = 0, with_filters: bool = True, post_beta: bool = True) -> dict:
     """State dict for BigVGANGenerator(**cfg): flat ``resblocks.{i*nk+j}`` AMPBlocks with
     ``activations.{m}.act.{alpha,beta}`` (log-scale) and ``activation_post``
     (/root/reference/fish_vocoder/modules/generators/bigvgan.py:277-349)."""
@@ -107,7 +107,9 @@ def bigvgan_state_dict(cfg: dict, seed: int = 0, with_filters: bool = True) -> d
                 sd[f"{p}.activations.{m}.act.beta"] = rng.normal(0.0, 0.3, size=ch).astype(np.float32)
     ch = c0 // 2 ** len(cfg["upsample_rates"])
     sd["activation_post.act.alpha"] = rng.normal(0.0, 0.3, size=ch).astype(np.float32)
-    sd["activation_post.act.beta"] = rng.normal(0.0, 0.3, size=ch).astype(np.float32)
+    beta_post = rng.normal(0.0, 0.3, size=ch).astype(np.float32)   # drawn either way: the other tensors keep their values
+    if post_beta:   # activation=Snake (bigvgan.py:266,335-337) has no beta on activation_post; the AMPBlocks always do
+        sd["activation_post.act.beta"] = beta_post
     _put_wn(sd, "conv_post", rng, (1, ch, qk), ch * qk, 0.25, 1)
     del with_filters  # filter buffers are derived, not random: modules recreate them (kaiser-sinc design)
     return sd
