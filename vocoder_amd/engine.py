@@ -154,6 +154,7 @@ class Engine:
         # stream waits on, so that calls from two threads or two torch streams cannot overlap on the device either.
         self._lock = threading.Lock()
         self._done: torch.cuda.Event | None = None
+        self._last_stream = None
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -225,12 +226,13 @@ class Engine:
                     self._side = torch.cuda.Stream(x.device)
                 run = self._side
                 run.wait_stream(cur)
-            if self._done is not None:
-                run.wait_event(self._done)       # order after the previous forward, whatever stream it ran on
+            if self._done is not None and self._last_stream != run.cuda_stream:
+                run.wait_event(self._done)       # order after the previous forward when it ran on another stream
             check(self._launch(x, tptr, nptr, out, B, T, int(run.cuda_stream)))
             if self._done is None:
                 self._done = torch.cuda.Event()
             self._done.record(run)
+            self._last_stream = run.cuda_stream
             if run is not cur:
                 cur.wait_stream(run)
         return out
