@@ -153,8 +153,8 @@ def cpu_baseline(cfg, sd, clips: int, frames: int) -> dict:
     # the core count (barrier cost per conv), so it is picked on a probe of the SAME shape as the sample (8 full one-second
     # clips) and the count actually used is reported next to the host's core count
     probe, best, best_dt, tried = mel[:8], 1, float("inf"), {}
-    for n in (8, 16, 32, 64, 128, 256):
-        if n > avail:
+    for n in (8, 16, 32, 64, 128):
+        if n > avail or (tried and best_dt < 0.5 * min(list(tried.values())[-1:])):   # stop once a count is 2x worse than the best
             break
         orc.set_num_threads(n)
         t0 = time.perf_counter()

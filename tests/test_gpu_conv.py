@@ -181,3 +181,63 @@ def test_fused_pair_rejects_unsupported_shapes():
     c = FusedConv(w, None, padding=2)
     with pytest.raises(FishVocError, match="unsupported pair"):
         c.pair(c, torch.zeros(1, 64, 32, device=_dev()))
+
+
+# ---- the LDS-free persistent GEMM of the pointwise convs (gemm_pw.hip): every configuration, against the oracle -------------
+PW_CASES = [
+    # (Cin, Cout, B, T): even T -> 8-byte column pairs; odd T -> single columns; ragged rows / columns; more waves than tiles
+    (512, 2048, 16, 94), (2048, 512, 16, 94), (128, 512, 40, 47), (256, 96, 9, 33), (64, 1026, 33, 98), (72, 200, 5, 7),
+    (1024, 256, 3, 94), (64, 32, 2, 5),
+]
+
+
+@pytest.mark.parametrize("cfg", ["0", "1", "2", None])
+@pytest.mark.parametrize("cin,cout,B,T", PW_CASES)
+def test_pointwise_gemm_every_configuration_matches_oracle(cin, cout, B, T, cfg, monkeypatch):
+    """Linear -> (+bias) [-> +residual] [-> GELU] of the ConvNeXt block (convnext.py:130-141).  cfg = forced kernel
+    configuration (FV_PW), None = the host's own choice (which may be the general conv kernel for tiny launches)."""
+    from vocoder_amd import _lib
+    if cfg is None:
+        monkeypatch.delenv("FV_PW", raising=False)
+    else:
+        monkeypatch.setenv("FV_PW", cfg)
+    rng = np.random.default_rng(cin + 3 * cout + B + T)
+    x = rng.normal(size=(B, cin, T)).astype(np.float32)
+    w = (rng.normal(size=(cout, cin, 1)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(B, cout, T)).astype(np.float32)
+    lin = orc.conv1d(x, w, b)
+    y = _run(w, b, x, post_act=_lib.FV_ACT_GELU)
+    if cfg is not None and cin >= 64:
+        assert _lib.last_kernel().startswith("gemm_pw<"), _lib.last_kernel()
+    _check(y, orc.gelu(lin))
+    _check(_run(w, b, x, res), lin + res)
+
+
+def test_fast_gelu_of_the_pointwise_gemm_against_the_exact_function():
+    """gemm_pw.hip evaluates GELU with the erfc form of Abramowitz & Stegun 7.1.26 (16 VALU instructions instead of erff):
+    pinned here against float64 erf over the whole useful range, bar |err| <= 1e-6 absolute (torch's own fp32 nn.GELU is
+    off by up to 1.2e-6 over the same range)."""
+    import math
+    from vocoder_amd import _lib
+    n = 64 * 94 * 2
+    v = np.linspace(-12.0, 12.0, n).astype(np.float32)
+    # identity weights: y[c] = x[c]; one input row carries the sweep, the others random values
+    cin = 64
+    x = np.zeros((2, cin, n // 2), np.float32)
+    x[:, 0, :] = v.reshape(2, -1)
+    x[:, 1:, :] = np.random.default_rng(0).normal(size=(2, cin - 1, n // 2)).astype(np.float32) * 3
+    w = np.eye(cin, dtype=np.float32)[:, :, None]
+    import os
+    os.environ["FV_PW"] = "1"
+    try:
+        y = _run(w, np.zeros(cin, np.float32), x, post_act=_lib.FV_ACT_GELU)
+        assert _lib.last_kernel().startswith("gemm_pw<"), _lib.last_kernel()
+    finally:
+        del os.environ["FV_PW"]
+    x64 = x.astype(np.float64)
+    erf = np.vectorize(math.erf)
+    exact = 0.5 * x64 * (1.0 + erf(x64 / math.sqrt(2.0)))
+    err = np.abs(y - exact)
+    assert err.max() <= 1e-6, err.max()
+    assert err[:, 0, :].max() <= 1e-6

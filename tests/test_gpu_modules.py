@@ -179,15 +179,19 @@ def test_cli_wav_branch_matches_the_direct_pipeline(tmp_path):
 
 
 def test_bigvgan_with_the_one_parameter_snake_activation_vs_oracle():
-    """BigVGANGenerator(activation=Snake) (bigvgan.py:18-71,266): state dict without the beta parameters."""
+    """BigVGANGenerator(activation=Snake) (bigvgan.py:18-71,266): only activation_post becomes Snake (no beta); the AMPBlocks
+    are built without the argument and keep SnakeBeta with their beta keys (bigvgan.py:330,335-337) — so a reference checkpoint
+    of such a model loads strictly (apart from the derived filter buffers)."""
     from vocoder_amd.modules.generators.bigvgan import BigVGANGenerator, Snake
     from oracle import oracle as orc
     cfg = dict(hop_length=16, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4], resblock_kernel_sizes=[3, 7],
                resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5]], num_mels=20, upsample_initial_channel=64, use_template=False)
-    sd = {k: v for k, v in syn.bigvgan_state_dict(cfg, 6).items() if not k.endswith(".act.beta")}
+    sd = syn.bigvgan_state_dict(cfg, 6, post_beta=False)
     gen = BigVGANGenerator(**cfg, activation=Snake).eval()
-    assert not any(k.endswith(".act.beta") for k in gen.state_dict())
-    gen.load_state_dict(_t(sd), strict=False)   # (the alias-free filter buffers are not in the synthetic dict)
+    own = set(gen.state_dict())
+    assert "activation_post.act.beta" not in own and "resblocks.0.activations.0.act.beta" in own
+    missing, unexpected = gen.load_state_dict(_t(sd), strict=False)   # (the alias-free filter buffers are not in the synthetic dict)
+    assert not unexpected and all(k.endswith("filter") for k in missing), (missing, unexpected)
     mel = syn.synthetic_mel(2, 20, 11, 4)
     y = gen.cuda()(torch.from_numpy(mel).cuda()).cpu().numpy()
     ref = orc.bigvgan_forward(sd, cfg, mel)

@@ -247,6 +247,41 @@ static int choose_tile(int M, long long N, int batch) {
     return big;
 }
 
+// Configuration of the LDS-free pointwise GEMM (gemm_pw.hip) for this call, or -1 to stay on the general conv kernel.
+// The persistent kernel runs CUs x 4 x W waves that share the tile list equally, so what matters is how evenly
+// tiles / SIMD divides: busy time of the fullest SIMD vs the average.
+static const char* const kGemmPwNames[GEMM_PW_COUNT] = {"64x64 w2", "32x64 w3", "64x64 w1"};
+static int choose_gemm_pw(const ConvLayer& L, const ConvRun& r, long long tout) {
+    // 32-bit byte offsets over all batch items
+    const long long bytes = 4LL * r.batch * std::max<long long>((long long)L.c_in * r.t_in, (long long)L.c_out * tout);
+    if (bytes >= 0xFFFFFF00LL || L.c_in < 64) return -1;   // (>= 8 chunks: the operand ring is primed unconditionally)
+    if (const char* v = std::getenv("FV_PW")) {   // experiments: force a configuration, or "old" / -1 for the conv kernel
+        const int n = std::atoi(v);
+        return (v[0] == 'o' || n < 0 || n >= GEMM_PW_COUNT) ? -1 : n;
+    }
+    const long long simds = (long long)(num_cus() / 8 * 8) * 4;
+    const long long n64 = ((long long)tout * r.batch + 63) / 64;
+    struct Cand { int cfg, mt, w; double pref; };
+    // pref: measured rate of the configuration on a well-balanced large GEMM, relative to the best one (profiles/README.md)
+    static const Cand cands[] = {{GEMM_PW_64x64_W2, 2, 2, 1.00}, {GEMM_PW_32x64_W3, 1, 3, 0.94}, {GEMM_PW_64x64_W1, 2, 1, 0.93}};
+    int best = -1;
+    double best_score = 0.0;
+    for (const Cand& c : cands) {
+        const long long tiles = ((L.M + 32 * c.mt - 1) / (32 * c.mt)) * n64;
+        const long long waves = simds * c.w;
+        // fullest SIMD: with fewer tiles than waves the slot-major order fills SIMDs evenly; otherwise W waves of ceil() tiles
+        const long long simd_max = tiles < waves ? (tiles + simds - 1) / simds : c.w * ((tiles + waves - 1) / waves);
+        const double eff = (double)tiles / (double)simds / (double)simd_max;
+        const double score = eff * c.pref;
+        if (score > best_score) {
+            best_score = score;
+            best = c.cfg;
+        }
+    }
+    // under half of the SIMDs' time used: the launch is too small for whole tiles — the conv kernel's split-K tiles do better
+    return best_score >= 0.5 ? best : -1;
+}
+
 static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64", "splitK32x32", "256x64", "256x32"};
 
 static const char* const kSplitNames[SPLIT_COUNT] = {"128x128", "64x256", "32x256"};
@@ -356,6 +391,31 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     // the split kernels implement the pre-activations of the MFMA-bound layers only (none / SiLU)
     if (L.precision == FV_PRECISION_F16X3 && L.d_wph && f16x3_per_layer_ok(L) && (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU))
         return conv_layer_run_f16x3(L, r, p, stream);
+
+    // pointwise convs of the MFMA-bound kind (ConvNeXt's Linear layers): the LDS-free GEMM kernel (gemm_pw.hip)
+    if (!L.transposed && L.ks == 1 && L.pad_l == 0 && L.c_in % 8 == 0 && r.pre_act == FV_ACT_NONE && r.out_mode == OUT_SET) {
+        const int variant = choose_gemm_pw(L, r, tout);
+        if (variant >= 0) {
+            p.flat = 1;
+            p.n_total = p.N * r.batch;
+            const bool pair = p.N % 2 == 0 && (((uintptr_t)r.x | (uintptr_t)r.y | (uintptr_t)r.res) & 7) == 0;
+            const int prof_idx = prof_begin(stream);
+            const int grid = launch_gemm_pw(p, variant, pair, stream);
+            static thread_local char name[96];
+            std::snprintf(name, sizeof(name), "gemm_pw<%s%s>", kGemmPwNames[variant], pair ? " pair" : "");
+            set_last_kernel(name);
+            if (prof_idx >= 0) {
+                double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
+                if (r.res) elems += (double)L.c_out * tout;
+                char lbl[160];
+                std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d grid=%d", name, L.c_in, L.c_out, grid);
+                prof_end(stream, prof_idx, lbl, 2.0 * L.c_in * L.c_out * (double)tout * r.batch,
+                         elems * r.batch * 4.0 + (double)L.c_in * L.c_out * 4.0);
+            }
+            FV_HIP_CHECK(hipGetLastError());
+            return FV_OK;
+        }
+    }
 
     int cfg = choose_tile(L.M, p.N, r.batch);
     // pointwise convs have no halo, so batch and time flatten into one GEMM column axis: no per-item partial tiles

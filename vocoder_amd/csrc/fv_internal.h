@@ -158,6 +158,11 @@ bool launch_conv_f16x3_misc(const ConvParams& p, int cfg, int batch, hipStream_t
 bool launch_conv_f16x3_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_f16x3_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
 
+// Pointwise (k = 1) convs as a persistent fp32-MFMA GEMM without LDS (gemm_pw.hip).  p as for a flat conv launch
+// (n_total = batch * N); pair: even T and 8-byte aligned tensors.  Returns the workgroup count (0: unknown configuration).
+enum GemmPwCfg : int { GEMM_PW_64x64_W2 = 0, GEMM_PW_32x64_W3 = 1, GEMM_PW_64x64_W1 = 2, GEMM_PW_COUNT };
+int launch_gemm_pw(const ConvParams& p, int cfg, bool pair, hipStream_t s);
+
 #ifndef FV_X_PAIRCOLS
 #define FV_X_PAIRCOLS 4096
 #endif
