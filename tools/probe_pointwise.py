@@ -8,7 +8,7 @@ import numpy as np
 import torch
 from vocoder_amd import _lib
 from vocoder_amd.engine import FusedConv
-variants = sys.argv[1].split(",") if len(sys.argv) > 1 and sys.argv[1] else ["0", "1", "2"]
+variants = sys.argv[1].split(",") if len(sys.argv) > 1 and sys.argv[1] else ["0", "1"]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 94
 rng = np.random.default_rng(0)

@@ -250,7 +250,7 @@ static int choose_tile(int M, long long N, int batch) {
 // Configuration of the LDS-free pointwise GEMM (gemm_pw.hip) for this call, or -1 to stay on the general conv kernel.
 // The persistent kernel runs CUs x 4 x W waves that share the tile list equally, so what matters is how evenly
 // tiles / SIMD divides: busy time of the fullest SIMD vs the average.
-static const char* const kGemmPwNames[GEMM_PW_COUNT] = {"64x64 w2", "32x64 w3", "64x64 w1"};
+static const char* const kGemmPwNames[GEMM_PW_COUNT] = {"64x64 w2", "32x64 w3"};
 static int choose_gemm_pw(const ConvLayer& L, const ConvRun& r, long long tout) {
     // 32-bit byte offsets over all batch items
     const long long bytes = 4LL * r.batch * std::max<long long>((long long)L.c_in * r.t_in, (long long)L.c_out * tout);
@@ -263,14 +263,15 @@ static int choose_gemm_pw(const ConvLayer& L, const ConvRun& r, long long tout) 
     const long long n64 = ((long long)tout * r.batch + 63) / 64;
     struct Cand { int cfg, mt, w; double pref; };
     // pref: measured rate of the configuration on a well-balanced large GEMM, relative to the best one (profiles/README.md)
-    static const Cand cands[] = {{GEMM_PW_64x64_W2, 2, 2, 1.00}, {GEMM_PW_32x64_W3, 1, 3, 0.94}, {GEMM_PW_64x64_W1, 2, 1, 0.93}};
+    static const Cand cands[] = {{GEMM_PW_64x64_W2, 2, 2, 1.00}, {GEMM_PW_32x64_W3, 1, 3, 0.94}};
     int best = -1;
     double best_score = 0.0;
     for (const Cand& c : cands) {
         const long long tiles = ((L.M + 32 * c.mt - 1) / (32 * c.mt)) * n64;
         const long long waves = simds * c.w;
-        // fullest SIMD: with fewer tiles than waves the slot-major order fills SIMDs evenly; otherwise W waves of ceil() tiles
-        const long long simd_max = tiles < waves ? (tiles + simds - 1) / simds : c.w * ((tiles + waves - 1) / waves);
+        // fullest SIMD: whole rounds give each of its W waves one tile, the last partial round fills first slots first
+        const long long left = tiles % waves;
+        const long long simd_max = c.w * (tiles / waves) + std::min<long long>(c.w, (left + simds - 1) / simds);
         const double eff = (double)tiles / (double)simds / (double)simd_max;
         const double score = eff * c.pref;
         if (score > best_score) {
@@ -278,8 +279,9 @@ static int choose_gemm_pw(const ConvLayer& L, const ConvRun& r, long long tout) 
             best = c.cfg;
         }
     }
-    // under half of the SIMDs' time used: the launch is too small for whole tiles — the conv kernel's split-K tiles do better
-    return best_score >= 0.5 ? best : -1;
+    // a sixth of the SIMDs' time used or less (single clips): too few whole tiles — the conv kernel's split-K tiles do better
+    // (measured crossover, tools/probe_pointwise.py: B = 32 x 86 frames, 512 -> 128 at 0.17 still wins by a third)
+    return best_score >= 0.15 ? best : -1;
 }
 
 static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64", "splitK32x32", "256x64", "256x32"};

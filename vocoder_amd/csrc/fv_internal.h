@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "fishvoc.h"
@@ -17,6 +19,18 @@ namespace fv {
 void set_error(const char* fmt, ...);
 void set_last_kernel(const char* name);
 int num_cus();   // compute units of the current device (cached)
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  Register-resident operand
+// rings need every index to be a constant expression in the source (an index that only becomes constant after loop unrolling
+// can leave the array in scratch memory: the optimiser promotes arrays to registers before it unrolls).
+template <class F, int... Is>
+__device__ __host__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __host__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 // Optional per-launch timing (fv_profile_begin / fv_profile_end): hipEvents recorded on the launch stream around every
 // kernel of a forward, aggregated by label together with the launch's ALGORITHMIC flops and bytes.
@@ -160,7 +174,7 @@ bool launch_conv_f16x3_k11(const ConvParams& p, int cfg, int batch, hipStream_t 
 
 // Pointwise (k = 1) convs as a persistent fp32-MFMA GEMM without LDS (gemm_pw.hip).  p as for a flat conv launch
 // (n_total = batch * N); pair: even T and 8-byte aligned tensors.  Returns the workgroup count (0: unknown configuration).
-enum GemmPwCfg : int { GEMM_PW_64x64_W2 = 0, GEMM_PW_32x64_W3 = 1, GEMM_PW_64x64_W1 = 2, GEMM_PW_COUNT };
+enum GemmPwCfg : int { GEMM_PW_64x64_W2 = 0, GEMM_PW_32x64_W3 = 1, GEMM_PW_COUNT };
 int launch_gemm_pw(const ConvParams& p, int cfg, bool pair, hipStream_t s);
 
 #ifndef FV_X_PAIRCOLS

@@ -19,23 +19,9 @@
 //   constant VGPR per load stream: the main loop has no VALU instruction at all — on gfx950 fp32 VALU work and fp32 MFMA
 //   share issue, so every VALU instruction removed is matrix time.
 //   Waves never synchronise; 1 - 3 of them per SIMD (persistent launch, see gemm_pw_persist_kernel).
-#include <type_traits>
-
 #include "conv_mfma_impl.h"
 
 namespace fv {
-
-// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  Register-resident operand
-// rings need every index to be a constant expression in the source (an index that only becomes constant after loop unrolling
-// can leave the array in scratch memory: the optimiser promotes arrays to registers before it unrolls).
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
 
 // GELU = v * Phi(v) with Phi(-|v|) = erfc(|v| / sqrt 2) / 2 ~ poly(t) * exp(-v^2 / 2) / 2, t = 1 / (1 + p |v| / sqrt 2)
 // (Abramowitz & Stegun 7.1.26, |eps_erf| <= 1.5e-7): 16 VALU instructions, two of them transcendental, no branches — about a
@@ -58,9 +44,10 @@ __device__ __forceinline__ float gelu_fast(float v) {
 // whole launch is 1.5 rounds of 4 waves per SIMD) is lock-step and quantisation: every wave of a round sits in its prologue
 // (first loads), main loop and epilogue (GELU + a burst of stores) at the same time, and the last round is partly empty.
 // Here a launch has exactly as many waves as the chip holds (CUs x 4 SIMDs x W); the output is cut into tiles of MT x 32
-// rows x 64 columns, ordered rows-fastest inside a 64-column block, and every wave owns a contiguous, equal (+-1) share of
-// the tile list (workgroups of one XCD own neighbouring column blocks: activations are read once per XCD, the weights
-// stay in every L2).  The host picks (MT, W) per layer so that tiles / (1024 W) is just under an integer (conv_layer.hip).
+// rows x 64 columns, ordered rows-fastest inside a 64-column block, and dealt out round by round (wave g takes tiles g,
+// g + waves, ...; the blocks of one XCD are neighbours in that order, so a round's column blocks are read once per XCD and
+// the weights stay in every L2).  The host picks (MT, W) per layer so that the fullest SIMD is close to the average
+// (conv_layer.hip).
 // A wave requests the first chunks of its NEXT tile before it runs the epilogue of the current one (XPF), and spreads the
 // loads of the chunk PD ahead between the MFMAs of the current chunk.
 template <int MT, int PD, bool PAIR, int W, bool XPF, bool STAGGER>
@@ -84,8 +71,11 @@ __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParam
     const int bslot = blockIdx.x / ncu, bcu = blockIdx.x - bslot * ncu;
     const int lb = bslot * ncu + (bcu % 8) * (ncu / 8) + bcu / 8;
     const long long gw = (long long)lb * 4 + wave, nw = (long long)nb * 4;
-    int u = __builtin_amdgcn_readfirstlane((int)(gw * U / nw));
-    const int u1 = __builtin_amdgcn_readfirstlane((int)((gw + 1) * U / nw));
+    // wave gw takes tiles gw, gw + nw, gw + 2 nw ...: every round hands neighbouring tiles (one column block) to neighbouring
+    // waves, and the last, partial round fills the first slot of every SIMD before any second one
+    int u = __builtin_amdgcn_readfirstlane((int)gw);
+    const int u1 = __builtin_amdgcn_readfirstlane((int)U);
+    const int ustep = __builtin_amdgcn_readfirstlane((int)nw);
     if (u >= u1) return;
     const long long t_start = ts ? (long long)wall_clock64() : 0;
     const int u_first = u;
@@ -300,7 +290,7 @@ __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParam
     for (;;) {
         mainloop();
         const int e_m32 = m32, e_ncol0 = ncol0;
-        ++u;
+        u += ustep;
         const bool more = u < u1;
         if (XPF && more) {   // the next tile's first chunks travel while this tile's epilogue runs
             setup(u);
@@ -317,7 +307,7 @@ __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParam
         ts[gw * 4 + 0] = t_start;
         ts[gw * 4 + 1] = (long long)wall_clock64();
         ts[gw * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);   // HW_ID, XCC_ID
-        ts[gw * 4 + 3] = ((long long)u_first << 32) | (unsigned)u1;
+        ts[gw * 4 + 3] = ((long long)u_first << 32) | (unsigned)((u1 - u_first + ustep - 1) / ustep + u_first);
     }
 }
 
@@ -341,7 +331,6 @@ int launch_gemm_pw(const ConvParams& p, int cfg, bool pair, hipStream_t s) {
     switch (cfg) {
         case GEMM_PW_64x64_W2: return launch_pw_persist<2, 4, 2, true, true>(p, pair, s);   // 64 x 64 tiles, 4 chunks ahead, 2 waves / SIMD
         case GEMM_PW_32x64_W3: return launch_pw_persist<1, 3, 3, true, true>(p, pair, s);   // 32 x 64 tiles, 3 chunks ahead, 3 waves / SIMD
-        case GEMM_PW_64x64_W1: return launch_pw_persist<2, 4, 1, true, false>(p, pair, s);  // 64 x 64 tiles, one wave / SIMD (few tiles)
         default: return 0;
     }
 }

@@ -188,6 +188,7 @@ fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, 
 // 2T-long intermediate never touches HBM (the reference makes ~9 tensor passes per activation).
 // ---------------------------------------------------------------------------------------------
 constexpr int AA_TT = 1024;
+constexpr int AA_ODD = AA_TT + 64;   // offset of the odd-sample array behind the even-sample one (a multiple of 64 dwords)
 
 // sin(z)^2 with a three-constant Cody-Waite reduction to [-pi/2, pi/2] and an odd degree-11 polynomial: |error| < 2e-7 for
 // |z| < 1e3 (the snake argument alpha*u stays far below that).  libm's sinf costs ~4x more VALU work and made this
@@ -257,7 +258,8 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
             if (h < 0) a.y = a.x;
             if (h > T - 1) a.x = a.y;
         }
-        *reinterpret_cast<f32x2*>(&A[2 * m]) = a;
+        A[m] = a.x;             // even and odd samples in separate arrays: lane-consecutive dwords in both phases — the
+        A[AA_ODD + m] = a.y;    // interleaved layout made every read of the down-sampler a 2-way bank conflict (stride 2)
     };
 #pragma unroll
     for (int i = 0; i < AA_TT / 256; ++i) up_snake(tid + i * 256);
@@ -272,8 +274,8 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
         f32x2 s2 = {0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            const int mo = i + q;   // odd sample of m = i + q, even sample of m + 1: A[2mo + 1], A[2mo + 2]
-            const f32x2 ap = {A[2 * mo + 1], A[2 * mo + 2]};
+            const int mo = i + q;   // odd sample of m = i + q, even sample of m + 1
+            const f32x2 ap = {A[AA_ODD + mo], A[mo + 1]};
             s2 = __builtin_elementwise_fma(dnp[q], ap, s2);
         }
         if (!EDGE || t0 + i < T) yr[t0 + i] = s2.x + s2.y;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restric
                                                           const float* __restrict__ up_taps,
                                                           const float* __restrict__ down_taps, int C, int T, int n_tiles) {
     __shared__ float xs[AA_TT + 16];
-    __shared__ __attribute__((aligned(8))) float A[2 * (AA_TT + 8)];
+    __shared__ __attribute__((aligned(8))) float A[2 * AA_ODD];
     const int tile = blockIdx.x % n_tiles;
     const long long row = blockIdx.x / n_tiles;  // b * C + c
     const int c = (int)(row % C);
