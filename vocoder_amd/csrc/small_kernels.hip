@@ -490,27 +490,31 @@ __global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __rest
         off[i] = (in && tt >= 0 && tt < T) ? (unsigned)(r * T + tt) * 4u : 0xC0000000u;   // + chunk row offset below
         lds_at[i] = in ? r * DWT_PITCH + cc : -1;
     }
-    float st[NLD], stw[2] = {0.f, 0.f};   // taps + bias of the chunk: 64 rows x 8 slots = 2 per thread
-    auto issue = [&](int ch) {
+    // Requests run PF - 1 chunks ahead of the chunk being computed (register ring st[PF]): a chunk is only 8 rows x K taps of
+    // FMAs per thread, far less than one HBM round trip, and with T = 94 frames per clip a launch has ~1.5 workgroups per CU
+    // — nothing else hides the latency (one chunk ahead: 22 us per launch of the 512-channel stage, 2.2 TB/s).
+    constexpr int PF = NCHUNK >= 4 ? 4 : (NCHUNK > 1 ? NCHUNK : 2);
+    float st[PF][NLD], stw[PF][2];
+    auto issue = [&](int SL, int ch) {   // SL: ring slot (a constant after unrolling)
         const unsigned base = (unsigned)(ch * DWT_CH * T) * 4u;   // rows past C fall outside the descriptor -> 0
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) st[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off[i] + base, 0, 0));
+        for (int i = 0; i < NLD; ++i) st[SL][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off[i] + base, 0, 0));
         if (K > 1) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = tid + u * 256, r = e >> 3, j = e & 7, c = ch * DWT_CH + r;
-                stw[u] = c < C ? (j < K ? dw_w[(long long)c * K + j] : (j == 7 && dw_b ? dw_b[c] : 0.f)) : 0.f;
+                stw[SL][u] = c < C ? (j < K ? dw_w[(long long)c * K + j] : (j == 7 && dw_b ? dw_b[c] : 0.f)) : 0.f;
             }
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int SL, int buf) {
         float* xsb = &xs[buf][0][0];
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (lds_at[i] >= 0) xsb[lds_at[i]] = st[i];
+            if (lds_at[i] >= 0) xsb[lds_at[i]] = st[SL][i];
         if (K > 1) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) wsm[buf][(tid + u * 256) >> 3][tid & 7] = stw[u];
+            for (int u = 0; u < 2; ++u) wsm[buf][(tid + u * 256) >> 3][tid & 7] = stw[SL][u];
         }
     };
 
@@ -518,14 +522,17 @@ __global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < CMAX / 8; ++i) h[i] = 0.f;
     float s = 0.f;
-    issue(0);
-    commit(0);
+#pragma unroll
+    for (int d = 0; d < PF - 1; ++d)
+        if (d < nchunk) issue(d, d);
+    commit(0, 0);
     __syncthreads();
 #pragma unroll
     for (int ch = 0; ch < NCHUNK; ++ch) {
         if (ch < nchunk) {
             const int buf = ch & 1;
-            if (ch + 1 < nchunk) issue(ch + 1);
+            // chunks ch + 1 .. ch + PF - 2 are in flight; the slot of chunk ch (committed last round) takes chunk ch + PF - 1
+            if (ch + PF - 1 < nchunk) issue((ch + PF - 1) % PF, ch + PF - 1);
 #pragma unroll
             for (int qq = 0; qq < 8; ++qq) {
                 const int cl = cg + 8 * qq;
@@ -540,7 +547,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __rest
                 h[ch * 8 + qq] = v;
                 s += (ch * DWT_CH + cl < C) ? v : 0.f;
             }
-            if (ch + 1 < nchunk) commit(buf ^ 1);
+            if (ch + 1 < nchunk) commit((ch + 1) % PF, buf ^ 1);
             __syncthreads();
         }
     }
