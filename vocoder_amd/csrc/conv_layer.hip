@@ -284,6 +284,21 @@ static int choose_gemm_pw(const ConvLayer& L, const ConvRun& r, long long tout) 
     return best_score >= 0.15 ? best : -1;
 }
 
+// Row groups of the XCD partition (gemm_pw.hip).  An XCD reads 1 / PX of the weights and PX / 8 of the activation columns:
+// four row groups when the weights are the operand that does not fit (activations under ten times their size: the C -> 4C
+// layers, +2 ... 3 %), one (every XCD owns a column range and streams all weights) when the activations dominate (4C -> C:
+// four row groups measured -5 %).  tools/px_probe.sh.
+static int choose_gemm_pw_xcd_rows(const ConvLayer& L, const ConvRun& r, long long tout, int cfg) {
+    const int mt = cfg == GEMM_PW_64x64_W2 ? 2 : 1;
+    const int mtiles = (L.M + 32 * mt - 1) / (32 * mt);
+    const double a_bytes = 4.0 * L.c_in * L.c_out, b_bytes = 4.0 * L.c_in * (double)tout * r.batch;
+    int px = b_bytes < 10.0 * a_bytes ? 4 : 1;
+    if (const char* v = std::getenv("FV_PW_PX")) px = std::atoi(v);
+    if (px != 1 && px != 2 && px != 4 && px != 8) px = 1;
+    while (px > 1 && mtiles % px != 0) px /= 2;
+    return px;
+}
+
 static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64", "splitK32x32", "256x64", "256x32"};
 
 static const char* const kSplitNames[SPLIT_COUNT] = {"128x128", "64x256", "32x256"};
@@ -401,6 +416,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
             p.flat = 1;
             p.n_total = p.N * r.batch;
             const bool pair = p.N % 2 == 0 && (((uintptr_t)r.x | (uintptr_t)r.y | (uintptr_t)r.res) & 7) == 0;
+            p.xcd_rows = choose_gemm_pw_xcd_rows(L, r, tout, variant);
             const int prof_idx = prof_begin(stream);
             const int grid = launch_gemm_pw(p, variant, pair, stream);
             static thread_local char name[96];

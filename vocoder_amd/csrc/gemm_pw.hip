@@ -61,20 +61,23 @@ __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParam
     // tile list
     const int mtiles = (p.M + 32 * MT - 1) / (32 * MT);
     const int n64 = (p.n_total + 63) / 64;
-    const long long U = (long long)mtiles * n64;
     // Wave order.  The dispatcher deals blocks round-robin: block b runs on XCD b % 8, and blocks b, b + CUs, b + 2 CUs ... share
-    // a CU, one wave per SIMD each (observed, tools/probe_pw_timeline.py; only speed depends on it).  Shares are handed out
-    // slot-major (all first blocks of every CU, then all second blocks ...), inside a slot XCD by XCD: with fewer tiles than
-    // waves the busy waves then sit on different SIMDs, and the blocks of one XCD own neighbouring column blocks.
+    // a CU, one wave per SIMD each (observed, tools/probe_pw_timeline.py; only speed depends on it).  The 8 XCDs split the
+    // output PX x PY (PX row groups of m-tiles, PY column ranges): an XCD's L2 then has to hold only 1 / PX of the weights next
+    // to the activation columns streaming through it.  Inside an XCD waves are ordered slot-major (all first blocks of its CUs,
+    // then all second blocks ...) and wave w takes the XCD's tiles w, w + waves, ...: a round hands neighbouring tiles to
+    // neighbouring waves, and a partial last round fills the first slot of every SIMD before any second one.
     const int nb = gridDim.x;           // W x CUs, CUs a multiple of 8 (host)
     const int ncu = nb / W;
     const int bslot = blockIdx.x / ncu, bcu = blockIdx.x - bslot * ncu;
-    const int lb = bslot * ncu + (bcu % 8) * (ncu / 8) + bcu / 8;
-    const long long gw = (long long)lb * 4 + wave, nw = (long long)nb * 4;
-    // wave gw takes tiles gw, gw + nw, gw + 2 nw ...: every round hands neighbouring tiles (one column block) to neighbouring
-    // waves, and the last, partial round fills the first slot of every SIMD before any second one
+    const int xcd = bcu % 8;
+    const int px = p.xcd_rows, py = 8 / px;            // host: px in {1, 2, 4, 8}, mtiles % px == 0
+    const int xr = xcd % px, xc = xcd / px;
+    const int mtl = mtiles / px;                        // m-tiles of this XCD's row group
+    const int cb0 = (int)((long long)xc * n64 / py), cb1 = (int)((long long)(xc + 1) * n64 / py);
+    const long long gw = (long long)(bslot * (ncu / 8) + bcu / 8) * 4 + wave, nw = (long long)nb * 4 / 8;   // wave index / waves of this XCD
     int u = __builtin_amdgcn_readfirstlane((int)gw);
-    const int u1 = __builtin_amdgcn_readfirstlane((int)U);
+    const int u1 = __builtin_amdgcn_readfirstlane((cb1 - cb0) * mtl);
     const int ustep = __builtin_amdgcn_readfirstlane((int)nw);
     if (u >= u1) return;
     const long long t_start = ts ? (long long)wall_clock64() : 0;
@@ -100,9 +103,9 @@ __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParam
     unsigned voffB[NL];
     int m32 = 0, ncol0 = 0, wbase = 0;
     auto setup = [&](int uu) {
-        const int blk = uu / mtiles;
-        m32 = (uu - blk * mtiles) * MT;
-        ncol0 = blk * 64;
+        const int blk = uu / mtl;
+        m32 = (xr * mtl + (uu - blk * mtl)) * MT;
+        ncol0 = (cb0 + blk) * 64;
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
             const int n = PAIR ? ncol0 + 2 * (lane & 31) : ncol0 + q * 32 + (lane & 31);
@@ -304,10 +307,11 @@ __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParam
         }
     }
     if (ts && lane == 0) {
-        ts[gw * 4 + 0] = t_start;
-        ts[gw * 4 + 1] = (long long)wall_clock64();
-        ts[gw * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);   // HW_ID, XCC_ID
-        ts[gw * 4 + 3] = ((long long)u_first << 32) | (unsigned)((u1 - u_first + ustep - 1) / ustep + u_first);
+        const long long gi = ((long long)xcd * nw + gw) * 4;
+        ts[gi + 0] = t_start;
+        ts[gi + 1] = (long long)wall_clock64();
+        ts[gi + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);   // HW_ID, XCC_ID
+        ts[gi + 3] = ((long long)u_first << 32) | (unsigned)((u1 - u_first + ustep - 1) / ustep + u_first);
     }
 }
 
