@@ -17,8 +17,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
                     the engine's per-launch profiler (fv_profile_*), algorithmic flops per launch / avg duration vs the
                     fp32-MFMA peak (or bytes vs HBM peak when that is the binding roof);
   with_collectives— the same K steps with config[4]'s "result collection over RCCL" inside the timed region: rank 0 owns the
-                    global batch, every step = scatter mels -> forward -> gather waveforms (sharding.scatter_batch /
-                    gather_batch); not the headline value;
+                    global batch, every step = broadcast mels -> forward on the rank's shard -> all_gather waveforms; not the
+                    headline value;
   other_configs   — BASELINE config[2] (BigVGAN-24k B=64) and config[3] (Vocos-24k B=128): ms/step and step-level roofline;
   cpu_baseline    — the CPU oracle (oracle/, a C port of the reference forward) on a bounded sample of the same workload,
                     rank 0 / N=1 only; host core count, CPU model and the thread count used are stated.
@@ -122,6 +122,16 @@ def dry_run(a, world, rank, local_rank) -> None:
         back = gather_batch(mine * 2.0, gb, dst=0)
         if rank == 0:
             ok = ok and bool(torch.equal(back.cpu(), full * 2.0))
+        # the two bulk collectives of the timed with_collectives figure: broadcast in, all_gather out (equal shards)
+        eq = torch.arange(ranks * 2 * 5, dtype=torch.float32, device=dev).reshape(ranks * 2, 5) if rank == 0 else torch.zeros((ranks * 2, 5), device=dev)
+        dist.broadcast(eq, src=0)
+        mine2 = eq[rank * 2:(rank + 1) * 2] + 1.0
+        allw = torch.empty_like(eq)
+        dist.all_gather_into_tensor(allw, mine2.contiguous())
+        ok = ok and bool(torch.equal(allw.cpu(), torch.arange(ranks * 2 * 5, dtype=torch.float32).reshape(ranks * 2, 5) + 1.0))
+        oks = torch.tensor([1.0 if ok else 0.0], device=dev)
+        dist.all_reduce(oks, op=dist.ReduceOp.MIN)
+        ok = bool(oks.item() == 1.0)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -344,38 +354,47 @@ def main():
     ok = bool(torch.isfinite(out).all().item()) and float(out.abs().max().item()) <= 1.0
 
     # ---- config[4]'s "result collection over RCCL", timed: rank 0 owns the global batch -----------------------------
+    # Two bulk collectives per step (the forms RCCL is exercised with everywhere: no point-to-point ordering to get wrong):
+    # the mels fan out with one broadcast from rank 0 (every rank slices its shard), the waveforms come back with one
+    # all_gather.  sharding.scatter_batch / gather_batch (ragged shards, point-to-point) are the library form of the same.
     coll = None
     if not a.no_collectives:
-        from vocoder_amd.sharding import gather_batch, scatter_batch
-        gb = B * ranks
-        full = None
-        if rank == 0:
-            full = torch.cat([torch.from_numpy(syn.synthetic_mel(B, cfg["num_mels"], T, seed=1234 + r)) for r in range(ranks)]).to(dev)
-
-        def coll_step():
-            if dist is None:
-                return eng(full, out)
-            mine = scatter_batch(full, gb, (cfg["num_mels"], T), src=0, device=dev)
-            y = eng(mine, out)
-            return gather_batch(y, gb, dst=0)
-
-        for _ in range(max(1, a.warmup)):
-            whole = coll_step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            whole = coll_step()
-        fence()
-        dtc = max_over_ranks(time.perf_counter() - t0)
-        if rank == 0:
+        try:
+            from vocoder_amd.sharding import shard_slice
+            gb = B * ranks
             L = eng.output_length(T)
-            coll = {"ms_per_step": dtc / a.steps * 1e3, "value": gb * L * a.steps / dtc, "unit": "samples/s",
-                    "x_realtime": gb * L * a.steps / dtc / SAMPLE_RATE, "global_batch": gb,
-                    "scatter_bytes_per_step": (gb - B) * cfg["num_mels"] * T * 4, "gather_bytes_per_step": (gb - B) * L * 4,
-                    "collected_shape": list(whole.shape), "collected_finite": bool(torch.isfinite(whole).all().item()),
-                    "note": "each step: rank 0 scatters the global mel batch (send/recv over RCCL), every rank runs its shard, "
-                            "rank 0 gathers all waveforms; N=1 degenerates to the plain forward"}
-        del full, whole
+            full = torch.empty((gb, cfg["num_mels"], T), dtype=torch.float32, device=dev)
+            if rank == 0:
+                full.copy_(torch.cat([torch.from_numpy(syn.synthetic_mel(B, cfg["num_mels"], T, seed=1234 + r)) for r in range(ranks)]))
+            whole = torch.empty((gb, 1, L), dtype=torch.float32, device=dev)
+
+            def coll_step():
+                if dist is None:
+                    eng(full, whole)
+                    return
+                dist.broadcast(full, src=0)
+                eng(full[shard_slice(gb, ranks, rank)], out)
+                dist.all_gather_into_tensor(whole, out)
+
+            for _ in range(max(1, a.warmup)):
+                coll_step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                coll_step()
+            fence()
+            dtc = max_over_ranks(time.perf_counter() - t0)
+            if rank == 0:
+                coll = {"ms_per_step": dtc / a.steps * 1e3, "value": gb * L * a.steps / dtc, "unit": "samples/s",
+                        "x_realtime": gb * L * a.steps / dtc / SAMPLE_RATE, "global_batch": gb,
+                        "broadcast_bytes_per_step": gb * cfg["num_mels"] * T * 4 if ranks > 1 else 0,
+                        "all_gather_bytes_per_step": gb * L * 4 if ranks > 1 else 0,
+                        "collected_shape": list(whole.shape), "collected_finite": bool(torch.isfinite(whole).all().item()),
+                        "note": "each step: rank 0 broadcasts the global mel batch over RCCL, every rank runs its shard, one "
+                                "all_gather returns all waveforms; N=1 degenerates to the plain forward"}
+            del full, whole
+        except Exception as exc:  # noqa: BLE001 - auxiliary figure: never cost the headline line
+            coll = {"error": f"{type(exc).__name__}: {exc}"} if rank == 0 else None
 
     result = None
     if rank == 0:
