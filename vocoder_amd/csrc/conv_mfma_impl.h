@@ -385,7 +385,10 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 // its own dword of the packed weights).  Partial accumulators are reduced through LDS and wave 0 runs the epilogue.
 // 16x more workgroups than the 128 x 128 tile for the same problem.
 template <int KS, int DIL, int NT, int NW>
-__global__ __launch_bounds__(NW * 64, (KS == 2 && NT == 2) ? 2 : 4) void conv_mfma_splitk_kernel(const ConvParams p) {   // (the 2-tap, two-n-tile instance needs more registers than four waves per SIMD leave)
+#ifndef FV_X_SPLITK_MINW
+#define FV_X_SPLITK_MINW 4
+#endif
+__global__ __launch_bounds__(NW * 64, (KS == 2 && NT == 2) ? 2 : FV_X_SPLITK_MINW) void conv_mfma_splitk_kernel(const ConvParams p) {   // (the 2-tap, two-n-tile instance needs more registers than four waves per SIMD leave)
     static_assert(NW == 4 || NW == 8, "4 or 8 waves split K");
     constexpr int THREADS = NW * 64;
     // 8-channel sub-chunks per LDS chunk (= per barrier): short kernels stage more channels at a time, otherwise a chunk is
@@ -434,7 +437,13 @@ __global__ __launch_bounds__(NW * 64, (KS == 2 && NT == 2) ? 2 : 4) void conv_mf
     // Prefetch distance in LDS chunks for both operands: a chunk holds only KS * NT MFMAs per wave (256 cycles at KS = 2), far
     // less than one L2 / HBM round trip, so short kernels keep several chunks of weights and window elements in flight
     // (one chunk ahead left the transposed convs of a single-clip forward waiting ~1 us per chunk).
-    constexpr int PF = KS >= 8 ? 1 : 2;
+#ifndef FV_X_SPLITK_PF_LONG
+#define FV_X_SPLITK_PF_LONG 1
+#endif
+#ifndef FV_X_SPLITK_PF_SHORT
+#define FV_X_SPLITK_PF_SHORT 2
+#endif
+    constexpr int PF = KS >= 8 ? FV_X_SPLITK_PF_LONG : FV_X_SPLITK_PF_SHORT;
     float stage[PF][NE];
     auto load_chunk = [&](float (&dst)[NE], int c) {
         const int cbase = c * CHW;
