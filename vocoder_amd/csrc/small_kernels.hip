@@ -449,22 +449,27 @@ __global__ __launch_bounds__(256) void dwconv_ln_reg_kernel(const float* __restr
 // The register-only kernel above issues its 7 x C/16 window loads in dependent rounds and runs at ~0.4 TB/s on the
 // short rows of the ConvNeXt path (T = 94): this one needs a tenth of the load instructions and has them all in flight.
 constexpr int DWT_TT = 32, DWT_CH = 64, DWT_PITCH = 40;
-template <int K, int CMAX>
-__global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
+// NG channel groups of 32 columns each = NG x 32 threads: 16 groups (512 threads) for the wide stages halve the rows and the
+// FIR-output registers per thread and double the waves a launch puts on a CU (T = 94: only 1.5 workgroups per CU exist).
+template <int K, int CMAX, int NG>
+__global__ __launch_bounds__(NG * 32) void dwconv_ln_tile_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
                                                              const float* __restrict__ dw_b,
                                                              const float* __restrict__ ln_w,
                                                              const float* __restrict__ ln_b, float* __restrict__ y, int C,
                                                              int T, float eps, int n_tiles) {
     constexpr int WE = DWT_TT + K - 1;                    // staged columns per channel row
     constexpr int NEL = DWT_CH * WE;
-    constexpr int NLD = (NEL + 255) / 256;
+    constexpr int NTH = NG * 32;                          // threads per workgroup
+    constexpr int RPT = DWT_CH / NG;                      // channel rows per thread and chunk
+    constexpr int NWT = DWT_CH * 8 / NTH;                 // tap / bias slots per thread and chunk
+    constexpr int NLD = (NEL + NTH - 1) / NTH;
     constexpr int NCHUNK = CMAX / DWT_CH;
     constexpr int PAD = (K - 1) / 2;
     static_assert(WE <= DWT_PITCH, "halo does not fit the LDS pitch");
     __shared__ float xs[2][DWT_CH][DWT_PITCH];
     __shared__ float wsm[2][DWT_CH][8];                   // taps 0..6, bias in slot 7
     __shared__ float lnp[2][CMAX];
-    __shared__ float red[8][33];
+    __shared__ float red[NG][33];
     const int tid = threadIdx.x;
     const int col = tid & 31, cg = tid >> 5;
     const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
@@ -473,16 +478,16 @@ __global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __rest
     const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(x + (long long)b * C * T, (unsigned)((long long)C * T * 4));
     const int nchunk = (C + DWT_CH - 1) / DWT_CH;
 
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NTH) {
         lnp[0][c] = ln_w[c];
         lnp[1][c] = ln_b[c];
     }
-    // staging plan (same for every chunk): element idx = tid + i*256 -> (row, column) of the chunk window
+    // staging plan (same for every chunk): element idx = tid + i*NTH -> (row, column) of the chunk window
     unsigned off[NLD];
     int lds_at[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        int idx = tid + i * 256;
+        int idx = tid + i * NTH;
         const bool in = idx < NEL;
         idx = in ? idx : NEL - 1;
         const int r = idx / WE, cc = idx - r * WE;
@@ -494,15 +499,15 @@ __global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __rest
     // FMAs per thread, far less than one HBM round trip, and with T = 94 frames per clip a launch has ~1.5 workgroups per CU
     // — nothing else hides the latency (one chunk ahead: 22 us per launch of the 512-channel stage, 2.2 TB/s).
     constexpr int PF = NCHUNK >= 4 ? 4 : (NCHUNK > 1 ? NCHUNK : 2);
-    float st[PF][NLD], stw[PF][2];
+    float st[PF][NLD], stw[PF][NWT];
     auto issue = [&](int SL, int ch) {   // SL: ring slot (a constant after unrolling)
         const unsigned base = (unsigned)(ch * DWT_CH * T) * 4u;   // rows past C fall outside the descriptor -> 0
 #pragma unroll
         for (int i = 0; i < NLD; ++i) st[SL][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off[i] + base, 0, 0));
         if (K > 1) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int e = tid + u * 256, r = e >> 3, j = e & 7, c = ch * DWT_CH + r;
+            for (int u = 0; u < NWT; ++u) {
+                const int e = tid + u * NTH, r = e >> 3, j = e & 7, c = ch * DWT_CH + r;
                 stw[SL][u] = c < C ? (j < K ? dw_w[(long long)c * K + j] : (j == 7 && dw_b ? dw_b[c] : 0.f)) : 0.f;
             }
         }
@@ -514,13 +519,13 @@ __global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __rest
             if (lds_at[i] >= 0) xsb[lds_at[i]] = st[SL][i];
         if (K > 1) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) wsm[buf][(tid + u * 256) >> 3][tid & 7] = stw[SL][u];
+            for (int u = 0; u < NWT; ++u) wsm[buf][(tid + u * NTH) >> 3][tid & 7] = stw[SL][u];
         }
     };
 
-    float h[CMAX / 8];
+    float h[CMAX / NG];
 #pragma unroll
-    for (int i = 0; i < CMAX / 8; ++i) h[i] = 0.f;
+    for (int i = 0; i < CMAX / NG; ++i) h[i] = 0.f;
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < PF - 1; ++d)
@@ -534,8 +539,8 @@ __global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __rest
             // chunks ch + 1 .. ch + PF - 2 are in flight; the slot of chunk ch (committed last round) takes chunk ch + PF - 1
             if (ch + PF - 1 < nchunk) issue((ch + PF - 1) % PF, ch + PF - 1);
 #pragma unroll
-            for (int qq = 0; qq < 8; ++qq) {
-                const int cl = cg + 8 * qq;
+            for (int qq = 0; qq < RPT; ++qq) {
+                const int cl = cg + NG * qq;
                 float v;
                 if (K > 1) {
                     v = wsm[buf][cl][7];
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __rest
                 } else {
                     v = xs[buf][cl][col];
                 }
-                h[ch * 8 + qq] = v;
+                h[ch * RPT + qq] = v;
                 s += (ch * DWT_CH + cl < C) ? v : 0.f;
             }
             if (ch + 1 < nchunk) commit((ch + 1) % PF, buf ^ 1);
@@ -555,36 +560,36 @@ __global__ __launch_bounds__(256) void dwconv_ln_tile_kernel(const float* __rest
     __syncthreads();
     float mean = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) mean += red[g][col];
+    for (int g = 0; g < NG; ++g) mean += red[g][col];
     mean /= (float)C;
     __syncthreads();
     float qv = 0.f;
 #pragma unroll
     for (int ch = 0; ch < NCHUNK; ++ch)
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq) {
-            const int c = ch * DWT_CH + cg + 8 * qq;
+        for (int qq = 0; qq < RPT; ++qq) {
+            const int c = ch * DWT_CH + cg + NG * qq;
             // chunks past ceil(C / 64) were never computed (h holds whatever the registers held): they must not enter
             // the sum in any form — a "subtract it back out" formulation turned such garbage into NaN for C = 320 / 384 / 640
-            const float d = c < C ? h[ch * 8 + qq] - mean : 0.f;
+            const float d = c < C ? h[ch * RPT + qq] - mean : 0.f;
             qv = fmaf(d, d, qv);
         }
     red[cg][col] = qv;
     __syncthreads();
     float var = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) var += red[g][col];
+    for (int g = 0; g < NG; ++g) var += red[g][col];
     var /= (float)C;
     const float inv = 1.0f / sqrtf(var + eps);
     const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(y + (long long)b * C * T, (unsigned)((long long)C * T * 4));
 #pragma unroll
     for (int ch = 0; ch < NCHUNK; ++ch)
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq) {
-            const int c = ch * DWT_CH + cg + 8 * qq;
+        for (int qq = 0; qq < RPT; ++qq) {
+            const int c = ch * DWT_CH + cg + NG * qq;
             const bool ok = c < C && t < T;
             const int cc = c < C ? c : 0;
-            const float v = (h[ch * 8 + qq] - mean) * inv * lnp[0][cc] + lnp[1][cc];
+            const float v = (h[ch * RPT + qq] - mean) * inv * lnp[0][cc] + lnp[1][cc];
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, ok ? (unsigned)(c * T + t) * 4u : 0xFFFFFFFFu, 0, 0);
         }
 }
@@ -593,10 +598,13 @@ template <int K>
 static bool launch_dwconv_ln_tile(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                                   float* y, int B, int C, int T, float eps, hipStream_t s) {
     const int n_tiles = (T + DWT_TT - 1) / DWT_TT;
-    const dim3 grid(B * n_tiles), blk(256);
-    if (C <= 256) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 256>), grid, blk, 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
-    else if (C <= 512) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512>), grid, blk, 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
-    else if (C <= 1024) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 1024>), grid, blk, 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
+    const dim3 grid(B * n_tiles);
+    const bool wide = getenv("FV_DWLN_NG8") == nullptr;   // 16 channel groups (512 threads) for C > 256
+    if (C <= 256) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 256, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
+    else if (C <= 512 && wide) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512, 16>), grid, dim3(512), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
+    else if (C <= 512) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
+    else if (C <= 1024 && wide) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 1024, 16>), grid, dim3(512), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
+    else if (C <= 1024) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 1024, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
     else return false;
     return true;
 }
