@@ -289,7 +289,7 @@ static int choose_gemm_pw(const ConvLayer& L, const ConvRun& r, long long tout) 
 // layers, +2 ... 3 %), one (every XCD owns a column range and streams all weights) when the activations dominate (4C -> C:
 // four row groups measured -5 %).  tools/px_probe.sh.
 static int choose_gemm_pw_xcd_rows(const ConvLayer& L, const ConvRun& r, long long tout, int cfg) {
-    const int mt = cfg == GEMM_PW_64x64_W2 ? 2 : 1;
+    const int mt = cfg == GEMM_PW_32x64_W3 ? 1 : 2;
     const int mtiles = (L.M + 32 * mt - 1) / (32 * mt);
     const double a_bytes = 4.0 * L.c_in * L.c_out, b_bytes = 4.0 * L.c_in * (double)tout * r.batch;
     int px = b_bytes < 10.0 * a_bytes ? 4 : 1;

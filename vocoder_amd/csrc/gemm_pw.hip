@@ -50,7 +50,7 @@ __device__ __forceinline__ float gelu_fast(float v) {
 // (conv_layer.hip).
 // A wave requests the first chunks of its NEXT tile before it runs the epilogue of the current one (XPF), and spreads the
 // loads of the chunk PD ahead between the MFMAs of the current chunk.
-template <int MT, int PD, bool PAIR, int W, bool XPF, bool STAGGER>
+template <int MT, int PD, bool PAIR, int W, bool XPF, bool STAGGER, int EB>
 __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParams p, long long* ts) {
     constexpr int NT = 2;
     constexpr int NL = PAIR ? 1 : 2;
@@ -203,15 +203,15 @@ __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParam
         }
         static_for<MT>([&](auto i_c) {
             constexpr int i = decltype(i_c)::value;
-            static_for<2>([&](auto hb_c) {
+            static_for<16 / EB>([&](auto hb_c) {
                 constexpr int hb = decltype(hb_c)::value;
-                // everything these 8 rows (acc registers 8 hb .. 8 hb + 7) read — bias, layer scale, residual — is requested
+                // everything these EB rows (acc registers EB hb .. EB hb + EB - 1) read — bias, layer scale, residual — is requested
                 // up front: one memory latency per half m-tile, not one per row group
-                const int mrow = (e_m32 + i) * 32 + 4 * (lane >> 5) + 16 * hb;
-                float gm[8], bs[8];
-                float rv[8][NT];
+                const int mrow = (e_m32 + i) * 32 + 4 * (lane >> 5) + 2 * EB * hb;   // acc register r <-> row (r & 3) + 8 (r >> 2)
+                float gm[EB], bs[EB];
+                float rv[EB][NT];
 #pragma unroll
-                for (int rq = 0; rq < 2; ++rq) {
+                for (int rq = 0; rq < EB / 4; ++rq) {
                     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)((mrow + 8 * rq) * 4), 0, 0);
                     bs[4 * rq + 0] = __uint_as_float(v.x);
                     bs[4 * rq + 1] = __uint_as_float(v.y);
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParam
                 }
                 if (has_gamma) {
 #pragma unroll
-                    for (int rq = 0; rq < 2; ++rq) {
+                    for (int rq = 0; rq < EB / 4; ++rq) {
                         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(grs, (unsigned)((mrow + 8 * rq) * 4), 0, 0);
                         gm[4 * rq + 0] = __uint_as_float(v.x);
                         gm[4 * rq + 1] = __uint_as_float(v.y);
@@ -228,16 +228,16 @@ __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParam
                         gm[4 * rq + 3] = __uint_as_float(v.w);
                     }
                 }
-                unsigned off[8][NL];
+                unsigned off[EB][NL];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
+                for (int r = 0; r < EB; ++r) {
                     const int m = mrow + (r & 3) + 8 * (r >> 2);
 #pragma unroll
                     for (int q = 0; q < NL; ++q) off[r][q] = (m < p.M && cok[q]) ? (unsigned)(m * p.N + coff[q]) * 4u : 0xFFFFFFF0u;
                 }
                 if (has_res) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
+                    for (int r = 0; r < EB; ++r) {
                         if constexpr (PAIR) {
                             const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rrs, off[r][0], 0, 0);
                             rv[r][0] = __uint_as_float(v.x);
@@ -249,11 +249,11 @@ __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParam
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
+                for (int r = 0; r < EB; ++r) {
                     float val[NT];
 #pragma unroll
                     for (int jn = 0; jn < NT; ++jn) {
-                        float v = acc[i][jn][8 * hb + r] + bs[r];
+                        float v = acc[i][jn][EB * hb + r] + bs[r];
                         if (has_gamma) v *= gm[r];
                         if (has_res) v += rv[r][jn];
                         val[jn] = v;
@@ -320,13 +320,13 @@ __global__ __launch_bounds__(256, W) void gemm_pw_persist_kernel(const ConvParam
 static long long* g_pw_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void fv_debug_set_pw_timestamps(void* device_buffer) { g_pw_ts = (long long*)device_buffer; }
 
-template <int MT, int PD, int W, bool XPF, bool STAGGER = false>
+template <int MT, int PD, int W, bool XPF, bool STAGGER = false, int EB = 8>
 static int launch_pw_persist(const ConvParams& p, bool pair, hipStream_t s) {
     const int grid = num_cus() / 8 * 8 * W;   // one workgroup = one wave per SIMD; W of them fill a CU
     if (pair)
-        hipLaunchKernelGGL((gemm_pw_persist_kernel<MT, PD, true, W, XPF, STAGGER>), dim3(grid), dim3(256), 0, s, p, g_pw_ts);
+        hipLaunchKernelGGL((gemm_pw_persist_kernel<MT, PD, true, W, XPF, STAGGER, EB>), dim3(grid), dim3(256), 0, s, p, g_pw_ts);
     else
-        hipLaunchKernelGGL((gemm_pw_persist_kernel<MT, PD, false, W, XPF, STAGGER>), dim3(grid), dim3(256), 0, s, p, g_pw_ts);
+        hipLaunchKernelGGL((gemm_pw_persist_kernel<MT, PD, false, W, XPF, STAGGER, EB>), dim3(grid), dim3(256), 0, s, p, g_pw_ts);
     return grid;
 }
 
@@ -335,6 +335,7 @@ int launch_gemm_pw(const ConvParams& p, int cfg, bool pair, hipStream_t s) {
     switch (cfg) {
         case GEMM_PW_64x64_W2: return launch_pw_persist<2, 4, 2, true, true>(p, pair, s);   // 64 x 64 tiles, 4 chunks ahead, 2 waves / SIMD
         case GEMM_PW_32x64_W3: return launch_pw_persist<1, 3, 3, true, true>(p, pair, s);   // 32 x 64 tiles, 3 chunks ahead, 3 waves / SIMD
+        // (64 x 64 tiles at 3 waves / SIMD do not fit 168 registers even with 4-row epilogue batches: 109 spills)
         default: return 0;
     }
 }
