@@ -149,6 +149,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
 }
 
+#ifndef FV_X_INTERLEAVE
+#define FV_X_INTERLEAVE 1
+#endif
 constexpr int kWeightPrefetch = 3;   // weight-fragment prefetch distance in k-steps (taps)
 
 // 8-channel sub-chunks staged per barrier (LDS budget 2 * 8*SUBS * W floats, <= 36 KiB)
@@ -349,6 +352,34 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
         load_b(b_cur, xsb, 0, 0);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
+#if FV_X_INTERLEAVE
+            // the step's memory operations (MT weight loads for k-step st + DA, 4 NT LDS fragment reads for k-step st + 1)
+            // spread between its MFMAs instead of issued in a burst before them: an in-order wave hides a memory
+            // instruction's issue time only under an MFMA that is already executing (gemm_pw.hip, round 2)
+            {
+                constexpr int NM = 4 * MT * NT, NLDX = MT + 4 * NT;
+                const int sub_n = (st + 1) / KS, j_n = (st + 1) % KS;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const int pp = m / (MT * NT), i = (m / NT) % MT, jn = m % NT;
+                    const float av = pp == 0 ? aq[0][i].x : pp == 1 ? aq[0][i].y : pp == 2 ? aq[0][i].z : aq[0][i].w;
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[pp][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < NLDX; ++k) {
+                        if (k * NM / NLDX == m) {
+                            if (k < MT) {
+                                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wbase[k] + gchunk_b + st * 1024, 0);
+                                aq[DA][k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                            } else if (st + 1 < STEPS) {
+                                const int pp2 = (k - MT) / NT, jn2 = (k - MT) % NT;
+                                b_nxt[pp2][jn2] = xsb[b_lane + (sub_n * kChunk + 2 * pp2) * WL + jn2 * 32 + j_n * DIL];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+#else
             load_a(aq[DA], gchunk_b + st * 1024);
             if (st + 1 < STEPS) load_b(b_nxt, xsb, (st + 1) / KS, (st + 1) % KS);
             __builtin_amdgcn_sched_barrier(0);
@@ -362,6 +393,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[pp][jn], acc[i][jn], 0, 0, 0);
                 }
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int d = 0; d < DA; ++d)
