@@ -97,20 +97,31 @@ __device__ __forceinline__ void gemm32_resident(const float4* __restrict__ w, in
     load_b(b_cur, 0);
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-        if (st + 1 < STEPS) {
-            load_a(a_nxt, st + 1);
-            load_b(b_nxt, st + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        // next step's operands (MT weight loads, 4 NT LDS fragment reads) requested BETWEEN this step's MFMAs: an in-order wave
+        // hides a memory instruction's issue time only under an MFMA that is already executing (conv_mfma_impl.h)
+        constexpr int NM = 4 * MT * NT, NLDX = MT + 4 * NT;
+        const int cc_n = (st + 1) / KS, j_n = (st + 1) % KS;
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp)
+        for (int m = 0; m < NM; ++m) {
+            const int pp = m / (MT * NT), i = (m / NT) % MT, jn = m % NT;
+            const float av = pp == 0 ? a_cur[i].x : pp == 1 ? a_cur[i].y : pp == 2 ? a_cur[i].z : a_cur[i].w;
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[pp][jn], acc[i][jn], 0, 0, 0);
+            if (st + 1 < STEPS) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const float av = pp == 0 ? a_cur[i].x : pp == 1 ? a_cur[i].y : pp == 2 ? a_cur[i].z : a_cur[i].w;
-#pragma unroll
-                for (int jn = 0; jn < NT; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[pp][jn], acc[i][jn], 0, 0, 0);
+                for (int k = 0; k < NLDX; ++k) {
+                    if (k * NM / NLDX == m) {
+                        if (k < MT) {
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (k * STEPS + st + 1) * 1024, 0);
+                            a_nxt[k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                        } else {
+                            const int pp2 = (k - MT) / NT, jn2 = (k - MT) % NT;
+                            b_nxt[pp2][jn2] = bsrc[(cc_n * 8 + 2 * pp2) * STRIDE + jn2 * 32 + j_n * DILX];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (st + 1 < STEPS) {
 #pragma unroll

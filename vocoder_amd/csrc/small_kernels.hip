@@ -282,114 +282,20 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
     }
 }
 
-// sin(z)^2, scalar form of sin_squared2 (same reduction, same polynomial, same operation order)
-__device__ __forceinline__ float sin_squared1(float z) {
-    const float k = rintf(z * 0.318309886183790672f);
-    float r = fmaf(k, -3.140625f, z);
-    r = fmaf(k, -9.67502593994140625e-4f, r);
-    r = fmaf(k, -1.509957990978376432e-7f, r);
-    const float r2 = r * r;
-    float p = fmaf(r2, -2.50521083854417188e-8f, 2.75573192239858925e-6f);
-    p = fmaf(r2, p, -1.98412698412698413e-4f);
-    p = fmaf(r2, p, 8.33333333333333322e-3f);
-    p = fmaf(r2, p, -1.66666666666666657e-1f);
-    const float sn = fmaf(r * r2, p, r);
-    return sn * sn;
-}
-
-// Interior tiles (tile + 8-sample halo inside [0, T)): TWO neighbouring positions per thread, every LDS access 8 bytes wide at
-// an 8-byte lane stride (conflict-free, 2 LDS cycles per wave-instruction).  The PMC pass of the one-position kernel showed
-// the LDS as its first bound (76 % active): 24 four-byte reads + 3 writes per output ~ 60 LDS cycles per 64 outputs.  Here a
-// thread reads the 8-float input window of its two positions with four ds_read_b64 and the 2 x 8 activated samples its two
-// outputs need with eight: ~22 LDS cycles per 64 outputs.  FIR steps are plain v_fma_f32 on the window registers (full rate
-// on gfx950's SIMD-32; packed FMAs would need even-aligned register pairs, which a sliding window is not).  Same taps, same
-// summation order per output as aa_snake_tile: both paths agree to the last bit.
-__device__ __forceinline__ void aa_snake_tile2(const float* __restrict__ xr, float* __restrict__ yr, float* __restrict__ xs,
-                                               float* __restrict__ A, const float* __restrict__ up_taps,
-                                               const float* __restrict__ down_taps, float al, float ib, int t0) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < AA_TT / 256; ++i) xs[tid + i * 256] = xr[t0 - 6 + tid + i * 256];
-    if (tid < 16) xs[AA_TT + tid] = xr[t0 - 6 + AA_TT + tid];
-    float upe[6], upo[6], dn[12];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        upe[q] = 2.0f * up_taps[2 * q + 1];
-        upo[q] = 2.0f * up_taps[2 * q];
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) dn[k] = down_taps[k];
-    __syncthreads();
-    auto up_snake2 = [&](int g) {   // positions m = 2g, 2g + 1 (h = t0 - 3 + m); x[h + j] = xs[m + 3 + j]
-        float X[8];
-        static_for<4>([&](auto v_c) {
-            constexpr int v = decltype(v_c)::value;
-            const float2 w = *reinterpret_cast<const float2*>(&xs[2 * g + 2 * v]);
-            X[2 * v] = w.x;
-            X[2 * v + 1] = w.y;
-        });
-        float ae[2], ao[2];
-        static_for<2>([&](auto p_c) {
-            constexpr int p = decltype(p_c)::value;
-            float ue = 0.f, uo = 0.f;
-            static_for<6>([&](auto q_c) {
-                constexpr int q = decltype(q_c)::value;
-                ue = fmaf(upe[q], X[p + 5 - q], ue);
-                uo = fmaf(upo[q], X[p + 6 - q], uo);
-            });
-            ae[p] = fmaf(ib, sin_squared1(ue * al), ue);
-            ao[p] = fmaf(ib, sin_squared1(uo * al), uo);
-        });
-        *reinterpret_cast<float2*>(&A[2 * g]) = make_float2(ae[0], ae[1]);
-        *reinterpret_cast<float2*>(&A[AA_ODD + 2 * g]) = make_float2(ao[0], ao[1]);
-    };
-#pragma unroll
-    for (int i = 0; i < AA_TT / 512; ++i) up_snake2(tid + i * 256);
-    if (tid < 4) up_snake2(AA_TT / 2 + tid);   // positions AA_TT .. AA_TT + 7 (the down-sampler reads up to AA_TT + 6)
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < AA_TT / 512; ++k) {   // outputs i = 2j, 2j + 1:  y[i] = sum_q dn[2q] * odd(i + q) + dn[2q+1] * even(i + q + 1)
-        const int j = tid + k * 256;
-        float E[8], O[8];
-        static_for<4>([&](auto v_c) {
-            constexpr int v = decltype(v_c)::value;
-            const float2 we = *reinterpret_cast<const float2*>(&A[2 * j + 2 * v]);
-            const float2 wo = *reinterpret_cast<const float2*>(&A[AA_ODD + 2 * j + 2 * v]);
-            E[2 * v] = we.x;
-            E[2 * v + 1] = we.y;
-            O[2 * v] = wo.x;
-            O[2 * v + 1] = wo.y;
-        });
-        float out[2];
-        static_for<2>([&](auto r_c) {
-            constexpr int r = decltype(r_c)::value;
-            float s0 = 0.f, s1 = 0.f;   // even / odd taps summed separately, added at the end: aa_snake_tile's order
-            static_for<6>([&](auto q_c) {
-                constexpr int q = decltype(q_c)::value;
-                s0 = fmaf(dn[2 * q], O[r + q], s0);
-                s1 = fmaf(dn[2 * q + 1], E[r + q + 1], s1);
-            });
-            out[r] = s0 + s1;
-        });
-        yr[t0 + 2 * j] = out[0];
-        yr[t0 + 2 * j + 1] = out[1];
-    }
-}
-
 __global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           const float* __restrict__ alpha_eff,
                                                           const float* __restrict__ inv_beta,
                                                           const float* __restrict__ up_taps,
                                                           const float* __restrict__ down_taps, int C, int T, int n_tiles) {
-    __shared__ __attribute__((aligned(8))) float xs[AA_TT + 16];
+    __shared__ float xs[AA_TT + 16];
     __shared__ __attribute__((aligned(8))) float A[2 * AA_ODD];
     const int tile = blockIdx.x % n_tiles;
     const long long row = blockIdx.x / n_tiles;  // b * C + c
     const int c = (int)(row % C);
     const int t0 = tile * AA_TT;
     const float al = alpha_eff[c], ib = inv_beta[c];
-    if (t0 >= 6 && t0 + AA_TT + 10 < T)
-        aa_snake_tile2(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0);
+    if (t0 >= 6 && t0 + AA_TT + 6 < T)
+        aa_snake_tile<false>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T);
     else
         aa_snake_tile<true>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T);
 }
@@ -982,6 +888,23 @@ fv_status launch_adain(const float* x, const float* noise, const float* w, float
     hipLaunchKernelGGL(adain_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, s, x, noise, w, y, C, T, slope, accumulate, scale);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
+}
+
+// Debug aid (tools/probe_lds_poison.py): fills the LDS of every CU with signalling garbage (NaN bit patterns) so that a kernel
+// which reads LDS it never wrote shows up as a changed / non-finite result instead of silently inheriting whatever the previous
+// kernel on that CU left behind (which makes results depend on which kernels of OTHER streams ran there).
+__global__ __launch_bounds__(256) void lds_poison_kernel(float* sink) {
+    __shared__ float junk[16000];   // 62.5 KiB: two workgroups cover a CU's 160 KiB minus whatever is resident
+    for (int i = threadIdx.x; i < 16000; i += 256) junk[i] = __uint_as_float(0x7fc00000u | (unsigned)i);
+    __syncthreads();
+    if (sink && junk[(threadIdx.x * 37 + blockIdx.x) % 16000] == 1.0f) sink[0] = 1.0f;   // keeps the stores alive
+}
+extern "C" __attribute__((visibility("default"))) int fv_debug_aa_snake(const float* x, float* y, const float* alpha, const float* inv_beta,
+                                                                       const float* up, const float* down, int B, int C, int T, void* stream) {
+    return (int)launch_aa_snake(x, y, alpha, inv_beta, up, down, B, C, T, (hipStream_t)stream);
+}
+extern "C" __attribute__((visibility("default"))) void fv_debug_poison_lds(void* stream) {
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(num_cus() * 2), dim3(256), 0, (hipStream_t)stream, (float*)nullptr);
 }
 
 }  // namespace fv
