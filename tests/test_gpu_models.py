@@ -751,7 +751,7 @@ def test_benchmark_size_kernels_do_not_read_stale_workspace(prec):
 
 @pytest.mark.parametrize("model,prec", [("bigvgan", "f32"), ("bigvgan", "f16x3"), ("hifigan", "f32"), ("hifigan", "f16x3")])
 def test_single_clip_forward_is_bitwise_repeatable_across_branch_streams(model, prec):
-    """A single-clip forward runs its three MRF branches on three streams (eager here: graph replay off).  40 repeats must be
+    """A single-clip forward runs its three MRF branches on three streams (eager here: graph replay off).  25 repeats must be
     bit-identical: kernels that consume anything they did not write themselves (registers, LDS, another stream's buffer)
     show up as a few hundred samples that change from run to run.  (Round 2: a faster aa_snake variant made 9 % of the
     f16x3 BigVGAN single-clip forwards differ by up to 3e-2 around multiples of 256 samples; reverted, this test guards it.)"""
@@ -772,9 +772,9 @@ def test_single_clip_forward_is_bitwise_repeatable_across_branch_streams(model, 
     torch.cuda.synchronize()
     ref = out.clone()
     differing = 0
-    for _ in range(40):
+    for _ in range(25):
         eng(mel, out)
         torch.cuda.synchronize()
         differing += int(not torch.equal(out, ref))
     eng.close()
-    assert differing == 0, f"{differing} of 40 repeats differ from the first run"
+    assert differing == 0, f"{differing} of 25 repeats differ from the first run"
