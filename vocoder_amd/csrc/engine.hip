@@ -10,6 +10,7 @@
 //                                       + generators/vocos.py:43-69 (Vocos)
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -778,6 +779,11 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                     launch_noise_conv_add(cur_template, stg->d_nw, stg->d_nb, S, B, ch, t, Ta, stg->nk, stg->nstride, stg->npad, s));
         }
         if (multi) FV_HIP_CHECK(hipEventRecord(bev_fork[stage_idx], s));
+        // debugging knob: FV_DEBUG_STOP = stage * 100 + pair * 10 + half stops the forward after that stage's dilation pair (half 0:
+        // after c1, 1: after c2) with the branch buffers left in the workspace for inspection (tools/probe_f16_locate.py)
+        static const int dbg_stop = std::getenv("FV_DEBUG_STOP") ? std::atoi(std::getenv("FV_DEBUG_STOP")) : -1;
+        const bool dbg_here = dbg_stop >= 0 && dbg_stop / 100 == stage_idx;
+        const int dbg_pair = (dbg_stop / 10) % 10, dbg_half = dbg_stop % 10;
         // ParralelBlock / stack-mean of the three ResBlock1 / AMPBlock branches (hifigan.py:132-133, bigvgan.py:358-365)
         for (int j = 0; j < nk; ++j) {
             ResBranch& br = *stg->branches[j];
@@ -822,6 +828,7 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 continue;
             }
             for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
+                if (dbg_here && n > dbg_pair) break;
                 const float* src = n == 0 ? S : XB(bj);
                 const bool last = n == FV_MAX_DILATIONS - 1;
                 const float* c1_in = src;
@@ -840,6 +847,7 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 r.pre_act = ups.bigvgan ? FV_ACT_NONE : FV_ACT_SILU;
                 r.post_act = ups.bigvgan ? FV_ACT_NONE : FV_ACT_SILU;
                 if ((st = conv_layer_run(br.c1[n], r, bs))) return st;
+                if (dbg_here && n == dbg_pair && dbg_half == 0) break;
                 const float* c2_in = XT(bj);
                 if (ups.bigvgan) {
                     FV_PROF(bs, "aa_snake", 60.0 * B * ch * t, 8.0 * B * ch * t,
@@ -867,6 +875,11 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
         }
         // join: the last branch's final kernel is ordered after every other branch's
         if (multi) FV_HIP_CHECK(hipStreamWaitEvent(s, bev_last[stage_idx * nk + nk - 1], 0));
+        if (dbg_here) {
+            std::fprintf(stderr, "FV_DEBUG_STOP: stage %d ch=%d t=%d me=%lld S=%lld Y=%lld\n", stage_idx, ch, t, (long long)me,
+                         (long long)(S - ws), (long long)(Y - ws));
+            return FV_OK;
+        }
         std::swap(cur, Y);
         ++stage_idx;
     }
