@@ -203,6 +203,10 @@ void conv_layer_destroy(ConvLayer& L) {
     L.d_bias = nullptr;
 }
 
+#ifdef FV_X_SPLITK_TS
+static long long* g_sk_ts = nullptr;
+extern "C" __attribute__((visibility("default"))) void fv_debug_set_splitk_timestamps(void* device_buffer) { g_sk_ts = (long long*)device_buffer; }
+#endif
 static int choose_tile(int M, long long N, int batch) {
     int big, small;
     if (M <= 32) {
@@ -227,9 +231,15 @@ static int choose_tile(int M, long long N, int batch) {
         // still fewer workgroups than CUs: 32 x 64 tiles with K split across the four waves (latency variant)
         const long long blocks_small = tiles_small * m_blks * batch;
         if (blocks_small < 200) {
-            // 32 x 64 tiles: 4x the workgroups of 128 x 64 / 2x those of 32 x 128; still under half the CUs -> 32 x 32
-            const long long blocks_sk = ((M + 31) / 32) * ((N + 63) / 64) * batch;
-            return blocks_sk < 128 ? TILE_SPLITK_32x32 : TILE_SPLITK_32x64;
+            // 32 x 64 tiles: 4x the workgroups of 128 x 64 / 2x those of 32 x 128.  Workgroups are dealt out one per CU and
+            // round, and a workgroup's time is its MFMA chain (proportional to the tile width): the busiest CU decides, so
+            // take 32 x 32 tiles when their rounds are shorter in total (344 tiles of 32 x 64 = 2 rounds of 2 units against
+            // 688 of 32 x 32 = 3 rounds of 1; the narrow tile re-stages the halo and reuses each weight fragment half as often)
+            const long long cus = num_cus();
+            const long long blocks_64 = ((M + 31) / 32) * ((N + 63) / 64) * batch, blocks_32 = ((M + 31) / 32) * ((N + 31) / 32) * batch;
+            const double cost_64 = (double)((blocks_64 + cus - 1) / cus) * 2.0, cost_32 = (double)((blocks_32 + cus - 1) / cus) * 1.1;
+            if (const char* v = std::getenv("FV_SPLITK")) return v[0] == '3' ? TILE_SPLITK_32x32 : TILE_SPLITK_32x64;   // experiments
+            return cost_32 < cost_64 ? TILE_SPLITK_32x32 : TILE_SPLITK_32x64;
         }
         return small;
     }
@@ -435,6 +445,9 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         }
     }
 
+#ifdef FV_X_SPLITK_TS
+    p.dbg_ts = g_sk_ts;
+#endif
     int cfg = choose_tile(L.M, p.N, r.batch);
     // pointwise convs have no halo, so batch and time flatten into one GEMM column axis: no per-item partial tiles
     // (Vocos: T = 94 frames per clip would waste 27 % of a 128-column tile)

@@ -27,6 +27,7 @@ namespace fv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -412,21 +413,24 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 }
 
 // Latency variant for launches that cannot fill the chip with regular tiles (small batch x short T): the workgroup
-// owns a 32 x 64 (or 32 x 32) output tile and its four waves split K between them — wave w takes channel pair w of every
-// 8-channel chunk (an eight-wave version over 16-channel chunks spilled and measured slower) (k-steps stay whole, the staged window and the B-fragment reads are shared, each wave fetches only
-// its own dword of the packed weights).  Partial accumulators are reduced through LDS and wave 0 runs the epilogue.
-// 16x more workgroups than the 128 x 128 tile for the same problem.
-template <int KS, int DIL, int NT, int NW>
-#ifndef FV_X_SPLITK_MINW
-#define FV_X_SPLITK_MINW 4
+// owns a 32 x 64 (or 32 x 32) output tile and its four waves split K between them — wave w takes the w-th 8-channel
+// sub-chunk of every 32-channel LDS chunk, so its weights for one tap are the whole float4 of the packed layout: one
+// coalesced 16-byte load per lane and tap feeds four MFMAs.  (The first version gave wave w dword w of every float4 —
+// four times the load instructions, each at a 16-byte lane stride; on a single-clip forward those loads cost as much as the
+// MFMA chain itself.  An eight-wave version spilled and measured slower.)  The staged window and the barriers are shared,
+// partial accumulators are reduced through LDS and wave 0 runs the epilogue.  16x more workgroups than the 128 x 128 tile
+// for the same problem.
+#ifdef FV_X_SPLITK_TS
+#define FV_SK_STAMP(i) do { if (p.dbg_ts && threadIdx.x == 0) p.dbg_ts[(long long)blockIdx.x * 8 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define FV_SK_STAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(NW * 64, (KS == 2 && NT == 2) ? 2 : FV_X_SPLITK_MINW) void conv_mfma_splitk_kernel(const ConvParams p) {   // (the 2-tap, two-n-tile instance needs more registers than four waves per SIMD leave)
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves split K");
+template <int KS, int DIL, int NT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_splitk_kernel(const ConvParams p) {
+    FV_SK_STAMP(0);
+    static_assert(NW == 4, "four waves split K: one 8-channel sub-chunk of the 32-channel LDS chunk each");
     constexpr int THREADS = NW * 64;
-    // 8-channel sub-chunks per LDS chunk (= per barrier): short kernels stage more channels at a time, otherwise a chunk is
-    // only KS * NT MFMAs per wave against a write -> barrier -> read round trip through LDS
-    constexpr int SUBK = KS <= 2 ? 4 : ((KS <= 4 || NT == 1) ? 2 : 1);   // (two sub-chunks spill the 32 x 64 tile at KS >= 7)
-    constexpr int CHW = 2 * NW * SUBK;       // channels per LDS chunk: one channel pair (= one MFMA k-step per tap) per wave and sub-chunk
+    constexpr int CHW = 8 * NW;              // channels per LDS chunk (= per barrier): rows 8w .. 8w + 7 belong to wave w
     constexpr int N_BLK = NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
     constexpr int W = N_BLK + SPAN;
@@ -453,10 +457,13 @@ __global__ __launch_bounds__(NW * 64, (KS == 2 && NT == 2) ? 2 : FV_X_SPLITK_MIN
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
 
+    // (every index into the per-thread staging arrays below is a compile-time constant — static_for, not unrolled loops — and
+    //  the helper lambdas are always_inline: with 11+ elements per thread hipcc otherwise outlines store_chunk, which leaves the
+    //  arrays in scratch memory and makes every window load synchronous: a 4x slower kernel)
     unsigned st_voff[NE];   // byte offset inside the chunk's rows, 0xFFFFFFFF outside [0, Tin) (see conv_mfma_kernel)
     const int tbase = n0 - p.pad_l;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
+    static_for<NE>([&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
         int e = tid + i * THREADS;
         const bool in_tile = e < TOT;
         e = in_tile ? e : TOT - 1;
@@ -465,97 +472,123 @@ __global__ __launch_bounds__(NW * 64, (KS == 2 && NT == 2) ? 2 : FV_X_SPLITK_MIN
         const int t = tbase + col;
         const bool ok = in_tile && t >= 0 && t < p.Tin;
         st_voff[i] = ok ? (unsigned)(r * p.Tin + t) * 4u : 0xFFFFFFFFu;
-    }
-    // Prefetch distance in LDS chunks for both operands: a chunk holds only KS * NT MFMAs per wave (256 cycles at KS = 2), far
-    // less than one L2 / HBM round trip, so short kernels keep several chunks of weights and window elements in flight
-    // (one chunk ahead left the transposed convs of a single-clip forward waiting ~1 us per chunk).
+    });
+    // Prefetch distance in LDS chunks for both operands: a chunk holds 4 * KS * NT MFMAs per wave (0.33 us at KS = 3, NT = 1;
+    // 1.2 us at KS = 11) against a round trip to L2 / HBM of 1 ... 2 us, and a single-clip launch has no other wave to
+    // cover it.  The operand rings have PF + 1 slots addressed by compile-time indices (the chunk loop is unrolled by the
+    // ring size): shifting the rings instead — registers with loads still in flight — made every chunk end wait for the
+    // loads it had just issued, which pinned the real distance at one chunk whatever PF said.
 #ifndef FV_X_SPLITK_PF_LONG
 #define FV_X_SPLITK_PF_LONG 1
 #endif
-#ifndef FV_X_SPLITK_PF_SHORT
-#define FV_X_SPLITK_PF_SHORT 2
+#ifndef FV_X_SPLITK_PF_MID
+#define FV_X_SPLITK_PF_MID 2
 #endif
-    constexpr int PF = KS >= 8 ? FV_X_SPLITK_PF_LONG : FV_X_SPLITK_PF_SHORT;
-    float stage[PF][NE];
-    auto load_chunk = [&](float (&dst)[NE], int c) {
+#ifndef FV_X_SPLITK_PF_SHORT
+#define FV_X_SPLITK_PF_SHORT 3
+#endif
+    constexpr int PF = KS >= 8 ? FV_X_SPLITK_PF_LONG : (KS >= 5 ? FV_X_SPLITK_PF_MID : FV_X_SPLITK_PF_SHORT);
+    constexpr int RING = PF + 1;
+    float stage[RING][NE];
+    auto load_chunk = [&](float (&dst)[NE], int c) __attribute__((always_inline)) {
         const int cbase = c * CHW;
         // chunks past the last one (prefetch overrun) get an empty descriptor: every load returns 0
         const int rows = p.Cin - cbase > 0 ? p.Cin - cbase : 0;
         const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)(rows ? cbase : 0) * p.Tin, (unsigned)(rows * p.Tin) * 4u);
-#pragma unroll
-        for (int i = 0; i < NE; ++i) dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_voff[i], 0, 0));
+        static_for<NE>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_voff[i], 0, 0));
+        });
     };
-    auto store_chunk = [&](float* dst, const float (&src)[NE]) {
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
+    auto store_chunk = [&](float* dst, const float (&src)[NE]) __attribute__((always_inline)) {
+        static_for<NE>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
             const int e = tid + i * THREADS;
             if (e < TOT) dst[e] = act_apply(src[i], p.pre_act, p.slope);
-        }
+        });
     };
 
-    // this wave's dword of the packed float4s: 8-channel sub-chunk (wave >> 2) of the LDS chunk, channel pair (wave & 3), by
-    // raw buffer loads (SGPR base + constant VGPR part).  The packed buffer is zero-padded to whole groups of four sub-chunks
-    // plus eight k-steps, and the descriptor is unbounded, so a prefetch past the last chunk reads harmless data.
+    // this wave's float4s of the packed weights: 8-channel sub-chunk 4c + wave, one float4 (four k-steps) per lane and tap,
+    // by raw buffer loads (SGPR base + constant VGPR part).  The packed buffer is zero-padded to whole groups of four
+    // sub-chunks plus eight k-steps, and the descriptor is unbounded, so nothing a prefetch touches is out of bounds.
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
-    const int wvoff = lane * 16 + (wave & 3) * 4;
+    const int wvoff = lane * 16;
     const int wtile_b = __builtin_amdgcn_readfirstlane(m_blk * p.nchunk * KS * 1024);
-    auto load_a = [&](int c, int sj) {   // sj = sub * KS + tap inside LDS chunk c
-        const int sub = sj / KS, j = sj - sub * KS;
-        const int soff = __builtin_amdgcn_readfirstlane(wtile_b + (((c * SUBK + sub) * (NW / 4) + (wave >> 2)) * KS + j) * 1024);
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, wvoff, soff, 0));
+    auto load_a = [&](int c, int j) __attribute__((always_inline)) {
+        const int soff = __builtin_amdgcn_readfirstlane(wtile_b + ((c * NW + wave) * KS + j) * 1024);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, soff, 0));
     };
-    const int b_lane = (2 * wave + (lane >> 5)) * W + (lane & 31);
-    auto load_b = [&](float (&dst)[NT], const float* xsb, int sj) {
-        const int sub = sj / KS, j = sj - sub * KS;
+    // k-step q of the wave's sub-chunk: lanes 0..31 supply channel 8w + 2q, lanes 32..63 channel 8w + 2q + 1
+    const int b_lane = (8 * wave + (lane >> 5)) * W + (lane & 31);
+    auto load_b = [&](float (&dst)[NT], const float* xsb, int sj) __attribute__((always_inline)) {   // sj = tap * 4 + q
+        const int j = sj >> 2, q = sj & 3;
 #pragma unroll
-        for (int jn = 0; jn < NT; ++jn) dst[jn] = xsb[sub * (2 * NW) * W + b_lane + jn * 32 + j * DIL];
+        for (int jn = 0; jn < NT; ++jn) dst[jn] = xsb[b_lane + 2 * q * W + jn * 32 + j * DIL];
     };
 
-    constexpr int KSS = SUBK * KS;   // k-steps per wave and LDS chunk
-    float aq[PF + 1][KSS];
-    float b_cur[NT], b_nxt[NT];
+    constexpr int KSS = 4 * KS;   // k-steps per wave and LDS chunk
+    // B fragments are requested DB k-steps ahead: a single-clip launch has one wave per SIMD, so nothing else covers the
+    // LDS round trip (~120 cycles against 64 per MFMA: one step ahead left every MFMA waiting for its operand — the K loop
+    // ran at 115 cycles per MFMA)
+#ifndef FV_X_SPLITK_DB
+#define FV_X_SPLITK_DB 3
+#endif
+    constexpr int DB = FV_X_SPLITK_DB < KSS ? FV_X_SPLITK_DB : KSS - 1;
+    f32x4 aq[RING][KS];
+    float bq[DB + 1][NT];
     const int nchunks = (p.Cin + CHW - 1) / CHW;
     const int last = nchunks - 1;
-#pragma unroll
-    for (int d = 0; d < PF; ++d) {
+    static_for<PF>([&](auto d_c) {
+        constexpr int d = decltype(d_c)::value;
         load_chunk(stage[d], d);
 #pragma unroll
-        for (int j = 0; j < KSS; ++j) aq[d][j] = load_a(d <= last ? d : last, j);
-    }
-    for (int c = 0; c < nchunks; ++c) {
-        float* xsb = xs[c & 1];
-        store_chunk(xsb, stage[0]);
-        __syncthreads();
-        // shift the window ring and request chunk c + PF
+        for (int j = 0; j < KS; ++j) aq[d][j] = load_a(d <= last ? d : last, j);
+    });
+    for (int c0 = 0; c0 < nchunks; c0 += RING) {
+        static_for<RING>([&](auto slot_c) __attribute__((always_inline)) {
+            constexpr int S = decltype(slot_c)::value;        // ring slot of chunk c
+            constexpr int SN = (S + PF) % RING;               // slot of chunk c + PF (the one chunk c - 1 used)
+            const int c = c0 + S;
+            if (c < nchunks) {
+                float* xsb = xs[c & 1];
+                store_chunk(xsb, stage[S]);
+                __syncthreads();
+                if (c == 0) FV_SK_STAMP(1);
+                // The NL loads of chunk c + PF are issued one at a time BETWEEN the MFMAs, window elements first: a wave issues
+                // in order, and a burst of 17 loads ahead of the first MFMA (x 4 waves into one CU's address path) held
+                // every chunk's MFMA chain back by ~0.8 us
+                const int cx = c + PF;
+                const int cbase = cx * CHW;
+                const int rows = p.Cin - cbase > 0 ? p.Cin - cbase : 0;   // past the last chunk: empty descriptor, loads return 0
+                const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)(rows ? cbase : 0) * p.Tin, (unsigned)(rows * p.Tin) * 4u);
+                const int cn = cx <= last ? cx : last;
+                constexpr int NL = NE + KS;
+                constexpr int LSTEP = KSS / NL > 0 ? KSS / NL : 1;
+                auto issue_load = [&](auto idx_c) __attribute__((always_inline)) {   // compile-time index: the rings must stay in registers
+                    constexpr int idx = decltype(idx_c)::value;
+                    if constexpr (idx < NE) stage[SN][idx] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_voff[idx], 0, 0));
+                    else if constexpr (idx < NL) aq[SN][idx - NE] = load_a(cn, idx - NE);
+                };
 #pragma unroll
-        for (int d = 0; d + 1 < PF; ++d)
+                for (int d = 0; d < DB; ++d) load_b(bq[d], xsb, d);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<KSS>([&](auto sj_c) __attribute__((always_inline)) {
+                    constexpr int sj = decltype(sj_c)::value;
+                    if constexpr (sj + DB < KSS) load_b(bq[(sj + DB) % (DB + 1)], xsb, sj + DB);
+                    if constexpr (sj % LSTEP == 0) issue_load(std::integral_constant<int, sj / LSTEP>{});
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < NE; ++i) stage[d][i] = stage[d + 1][i];
-        load_chunk(stage[PF - 1], c + PF);
-        const int cn = c + PF <= last ? c + PF : last;
-#pragma unroll
-        for (int j = 0; j < KSS; ++j) aq[PF][j] = load_a(cn, j);
-        load_b(b_cur, xsb, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < KSS; ++j) {
-            if (j + 1 < KSS) load_b(b_nxt, xsb, j + 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int jn = 0; jn < NT; ++jn)
-                acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0][j], b_cur[jn], acc[0][jn], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (j + 1 < KSS) {
-#pragma unroll
-                for (int jn = 0; jn < NT; ++jn) b_cur[jn] = b_nxt[jn];
+                    for (int jn = 0; jn < NT; ++jn)
+                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[S][sj >> 2][sj & 3], bq[sj % (DB + 1)][jn], acc[0][jn], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                constexpr int ISSUED = (KSS + LSTEP - 1) / LSTEP;
+                static_for<(NL > ISSUED ? NL - ISSUED : 0)>([&](auto k_c) { issue_load(std::integral_constant<int, ISSUED + decltype(k_c)::value>{}); });
             }
-        }
-#pragma unroll
-        for (int d = 0; d < PF; ++d)
-#pragma unroll
-            for (int j = 0; j < KSS; ++j) aq[d][j] = aq[d + 1][j];
+        });
     }
 
+    FV_SK_STAMP(2);
     // reduce the partial tiles
     if (wave > 0) {
 #pragma unroll
@@ -564,6 +597,7 @@ __global__ __launch_bounds__(NW * 64, (KS == 2 && NT == 2) ? 2 : FV_X_SPLITK_MIN
             for (int r = 0; r < 16; ++r) red[wave - 1][jn * 16 + r][lane] = acc[0][jn][r];
     }
     __syncthreads();
+    FV_SK_STAMP(3);
     if (wave == 0) {
 #pragma unroll
         for (int w = 0; w < NW - 1; ++w)
@@ -571,7 +605,13 @@ __global__ __launch_bounds__(NW * 64, (KS == 2 && NT == 2) ? 2 : FV_X_SPLITK_MIN
             for (int jn = 0; jn < NT; ++jn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][jn][r] += red[w][jn * 16 + r][lane];
+        // (requesting the residual / accumulate / bias operands of the whole tile at once, or before the K loop, instead of
+        //  conv_epilogue's four load -> compute -> store groups changed nothing, or cost a wave of occupancy)
         conv_epilogue<1, NT>(p, acc, b, m_blk, n0 + (lane & 31), lane);
+#ifdef FV_X_SPLITK_TS
+        __builtin_amdgcn_s_waitcnt(0);   // stores issued and loads returned
+#endif
+        FV_SK_STAMP(4);
     }
 }
 
