@@ -50,6 +50,10 @@ CONV_CASES = [
     (100, 512, 1, 1, 40, 94), (512, 128, 1, 1, 70, 47), (128, 256, 1, 1, 64, 50), (64, 1026, 1, 1, 33, 98),
     (96, 2048, 1, 1, 48, 94), (72, 1280, 1, 1, 60, 47),   # 256 x 64 tiles (an even number of 128-row blocks)
     (256, 512, 1, 1, 70, 94), (40, 768, 1, 1, 35, 63),     # 256 x 32 tiles
+    # single-clip latency kernel (K split over the four waves of a 32-row tile): a partial 32-channel chunk (40, 72, 200
+    # channels), three row blocks, ragged last column tile; lengths that take the 32 x 64 tile instead of 32 x 32
+    (40, 64, 3, 1, 1, 200), (72, 96, 7, 3, 1, 150), (200, 200, 11, 5, 1, 97),
+    (128, 128, 7, 3, 1, 3000), (64, 64, 11, 5, 1, 5000), (128, 128, 3, 1, 1, 2500),
 ]
 
 

@@ -230,7 +230,8 @@ static int choose_tile(int M, long long N, int batch) {
     if (blocks_big < 512 || cols_small < cols_big) {
         // still fewer workgroups than CUs: 32 x 64 tiles with K split across the four waves (latency variant)
         const long long blocks_small = tiles_small * m_blks * batch;
-        if (blocks_small < 200) {
+        static const long long sk_max = std::getenv("FV_SPLITK_MAX") ? std::atoll(std::getenv("FV_SPLITK_MAX")) : 200;   // experiments
+        if (blocks_small < sk_max) {
             // 32 x 64 tiles: 4x the workgroups of 128 x 64 / 2x those of 32 x 128.  Workgroups are dealt out one per CU and
             // round, and a workgroup's time is its MFMA chain (proportional to the tile width): the busiest CU decides, so
             // take 32 x 32 tiles when their rounds are shorter in total (344 tiles of 32 x 64 = 2 rounds of 2 units against
