@@ -239,7 +239,8 @@ static int choose_tile(int M, long long N, int batch) {
             const long long cus = num_cus();
             const long long blocks_64 = ((M + 31) / 32) * ((N + 63) / 64) * batch, blocks_32 = ((M + 31) / 32) * ((N + 31) / 32) * batch;
             const double cost_64 = (double)((blocks_64 + cus - 1) / cus) * 2.0, cost_32 = (double)((blocks_32 + cus - 1) / cus) * 1.1;
-            if (const char* v = std::getenv("FV_SPLITK")) return v[0] == '3' ? TILE_SPLITK_32x32 : TILE_SPLITK_32x64;   // experiments
+            static const char* const force = std::getenv("FV_SPLITK");   // experiments: "32" / "64"
+            if (force) return force[0] == '3' ? TILE_SPLITK_32x32 : TILE_SPLITK_32x64;
             return cost_32 < cost_64 ? TILE_SPLITK_32x32 : TILE_SPLITK_32x64;
         }
         return small;
