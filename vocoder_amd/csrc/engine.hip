@@ -785,6 +785,14 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
         const bool dbg_here = dbg_stop >= 0 && dbg_stop / 100 == stage_idx;
         const int dbg_pair = (dbg_stop / 10) % 10, dbg_half = dbg_stop % 10;
         // ParralelBlock / stack-mean of the three ResBlock1 / AMPBlock branches (hifigan.py:132-133, bigvgan.py:358-365)
+        // Small launches (single clips): the ordered accumulate makes each branch's last kernel wait for the previous branch's,
+        // 20-65 us per stage of cross-queue dependencies on a 1.1 ms forward (tools/latency_timeline.py).  There the branches
+        // keep their own outputs and one small kernel forms the mean after the join (B = 1: 1.07 -> 1.02 ms per forward, still
+        // ahead at B = 12); large batches keep the accumulate (B = 32: the extra pass costs 0.1 ms per step).  Sharing one stream
+        // between the two shorter branches, putting the longest branch on the caller's stream, or waking the side queues with an
+        // empty kernel at the start of the forward all measured the same or worse.
+        static const long long tree_max = std::getenv("FV_TREE_MAX") ? std::atoll(std::getenv("FV_TREE_MAX")) : (1LL << 22);   // elements
+        const bool tree = multi && nk == 3 && (long long)B * ch * t <= tree_max;
         for (int j = 0; j < nk; ++j) {
             ResBranch& br = *stg->branches[j];
             hipStream_t bs = (multi && j > 0) ? bstreams[j - 1] : s;
@@ -792,7 +800,7 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
             const int bj = multi ? j : 0;   // single-stream: branches run back to back and share one buffer set
             // ordering of the accumulate into Y: branch j's last kernel runs after branch j-1's
             auto before_last = [&]() -> fv_status {
-                if (multi && j > 0) FV_HIP_CHECK(hipStreamWaitEvent(bs, bev_last[stage_idx * nk + j - 1], 0));
+                if (multi && j > 0 && !tree) FV_HIP_CHECK(hipStreamWaitEvent(bs, bev_last[stage_idx * nk + j - 1], 0));
                 return FV_OK;
             };
             auto after_last = [&]() -> fv_status {
@@ -801,10 +809,11 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
             };
             int mode_last = OUT_SET;
             float scale_last = 1.0f;
-            if (nk > 1) {
+            if (nk > 1 && !tree) {
                 mode_last = j == 0 ? OUT_SET : OUT_ACCUM;
                 scale_last = (j == nk - 1) ? 1.0f / (float)nk : 1.0f;
             }
+            float* const y_last = tree ? XB(bj) : Y;   // tree: the branch keeps its own output, summed after the join
             // HiFiGAN narrow stages: the whole (c1, c2) pair in one kernel, intermediate kept in LDS.  Not in place
             // (workgroups read their neighbours' halo), so the branch ping-pongs S -> XB -> XT -> Y.
             const bool fuse_narrow = pair_supported(ch, br.k, br.dil[0]) && pair_supported(ch, br.k, br.dil[1]) &&
@@ -817,7 +826,7 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 const float* src = S;
                 for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
                     const bool last = n == FV_MAX_DILATIONS - 1;
-                    float* dst = last ? Y : (n == 0 ? XB(bj) : XT(bj));
+                    float* dst = last ? y_last : (n == 0 ? XB(bj) : XT(bj));
                     if (last && (st = before_last())) return st;
                     if ((st = conv_pair_run(br.c1[n], br.c2[n], src, dst, B, t, last ? mode_last : OUT_SET,
                                             last ? scale_last : 1.0f, bs)))
@@ -864,7 +873,7 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 if (!last) {
                     r.y = XB(bj);
                 } else {
-                    r.y = Y;
+                    r.y = y_last;
                     r.out_mode = mode_last;
                     r.out_scale = scale_last;
                     if ((st = before_last())) return st;
@@ -873,8 +882,14 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
             }
             if ((st = after_last())) return st;
         }
-        // join: the last branch's final kernel is ordered after every other branch's
-        if (multi) FV_HIP_CHECK(hipStreamWaitEvent(s, bev_last[stage_idx * nk + nk - 1], 0));
+        if (tree) {
+            // join all three, then Y = ((y0 + y1) + y2) / 3 — the same additions in the same order as the accumulate chain
+            for (int j = 1; j < nk; ++j) FV_HIP_CHECK(hipStreamWaitEvent(s, bev_last[stage_idx * nk + j], 0));
+            if ((st = launch_mean_of_three(XB(0), XB(1), XB(2), Y, (long long)B * ch * t, s))) return st;
+        } else if (multi) {
+            // join: the last branch's final kernel is ordered after every other branch's
+            FV_HIP_CHECK(hipStreamWaitEvent(s, bev_last[stage_idx * nk + nk - 1], 0));
+        }
         if (dbg_here) {
             std::fprintf(stderr, "FV_DEBUG_STOP: stage %d ch=%d t=%d me=%lld S=%lld Y=%lld\n", stage_idx, ch, t, (long long)me,
                          (long long)(S - ws), (long long)(Y - ws));

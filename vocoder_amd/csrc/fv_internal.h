@@ -249,6 +249,7 @@ fv_status launch_istft_ola(const float* frames, const float* inv_env, float* y, 
 fv_status launch_leaky_interp(const float* x, float* y, int B, int C, int Lin, int Lout, float scale, int leaky, float slope,
                               int ctot, int coff, hipStream_t s);
 fv_status launch_copy_channels(const float* x, float* y, int B, int C, int T, int ctot, int coff, hipStream_t s);
+fv_status launch_mean_of_three(const float* a, const float* b, const float* c, float* y, long long n, hipStream_t s);   // ((a + b) + c) / 3
 fv_status launch_adain(const float* x, const float* noise, const float* w, float* y, int B, int C, int T, float slope,
                        int accumulate, float scale, hipStream_t s);
 

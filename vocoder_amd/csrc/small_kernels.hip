@@ -863,6 +863,21 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restr
     if (t < T) y[((long long)b * ctot + coff + c) * T + t] = x[((long long)b * C + c) * T + t];
 }
 
+// y = ((a + b) + c) * (1/3): the stack-mean of the three ResBlock branches when they keep separate outputs (single clips,
+// engine.hip) — the additions and the final scale of the ordered accumulate epilogue, in the same order.
+__global__ __launch_bounds__(256) void mean_of_three_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ c, float* __restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const float third = 1.0f / 3.0f;
+    if (i < n) y[i] = ((a[i] + b[i]) + c[i]) * third;
+}
+
+fv_status launch_mean_of_three(const float* a, const float* b, const float* c, float* y, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(mean_of_three_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, c, y, n);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
 fv_status launch_copy_channels(const float* x, float* y, int B, int C, int T, int ctot, int coff, hipStream_t s) {
     hipLaunchKernelGGL(copy_channels_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, s, x, y, C, T, ctot, coff);
     FV_HIP_CHECK(hipGetLastError());
