@@ -456,7 +456,7 @@ __global__ __launch_bounds__(NG * 32) void dwconv_ln_tile_kernel(const float* __
                                                              const float* __restrict__ dw_b,
                                                              const float* __restrict__ ln_w,
                                                              const float* __restrict__ ln_b, float* __restrict__ y, int C,
-                                                             int T, float eps, int n_tiles) {
+                                                             int T, float eps, int n_tiles, int n_items, int xcd_map) {
     constexpr int WE = DWT_TT + K - 1;                    // staged columns per channel row
     constexpr int NEL = DWT_CH * WE;
     constexpr int NTH = NG * 32;                          // threads per workgroup
@@ -472,7 +472,13 @@ __global__ __launch_bounds__(NG * 32) void dwconv_ln_tile_kernel(const float* __
     __shared__ float red[NG][33];
     const int tid = threadIdx.x;
     const int col = tid & 31, cg = tid >> 5;
-    const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
+    // Workgroup b goes to XCD b % 8.  The column tiles of one clip share cache lines (rows of T = 94 floats are not line
+    // aligned, and every tile reads a 3-column halo of its neighbours): handing neighbouring tiles to the SAME XCD lets its L2
+    // serve those lines once — dealt round-robin, every XCD fetched them from HBM for itself (measured 2x the algorithmic
+    // read traffic).  Logical id = (b % 8) * (grid / 8) + b / 8; the launch rounds the grid up to a multiple of 8.
+    const int lid = xcd_map ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (lid >= n_items * n_tiles) return;
+    const int tile = lid % n_tiles, b = lid / n_tiles;
     const int t0 = tile * DWT_TT;
     const int t = t0 + col;
     const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(x + (long long)b * C * T, (unsigned)((long long)C * T * 4));
@@ -498,7 +504,10 @@ __global__ __launch_bounds__(NG * 32) void dwconv_ln_tile_kernel(const float* __
     // Requests run PF - 1 chunks ahead of the chunk being computed (register ring st[PF]): a chunk is only 8 rows x K taps of
     // FMAs per thread, far less than one HBM round trip, and with T = 94 frames per clip a launch has ~1.5 workgroups per CU
     // — nothing else hides the latency (one chunk ahead: 22 us per launch of the 512-channel stage, 2.2 TB/s).
-    constexpr int PF = NCHUNK >= 4 ? 4 : (NCHUNK > 1 ? NCHUNK : 2);
+#ifndef FV_X_DWLN_PF
+#define FV_X_DWLN_PF 4
+#endif
+    constexpr int PF = NCHUNK >= FV_X_DWLN_PF ? FV_X_DWLN_PF : (NCHUNK > 1 ? NCHUNK : 2);
     float st[PF][NLD], stw[PF][NWT];
     auto issue = [&](int SL, int ch) {   // SL: ring slot (a constant after unrolling)
         const unsigned base = (unsigned)(ch * DWT_CH * T) * 4u;   // rows past C fall outside the descriptor -> 0
@@ -598,13 +607,14 @@ template <int K>
 static bool launch_dwconv_ln_tile(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                                   float* y, int B, int C, int T, float eps, hipStream_t s) {
     const int n_tiles = (T + DWT_TT - 1) / DWT_TT;
-    const dim3 grid(B * n_tiles);
+    const dim3 grid((B * n_tiles + 7) / 8 * 8);   // whole groups of 8: see the XCD mapping in the kernel
     const bool wide = getenv("FV_DWLN_NG8") == nullptr;   // 16 channel groups (512 threads) for C > 256
-    if (C <= 256) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 256, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
-    else if (C <= 512 && wide) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512, 16>), grid, dim3(512), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
-    else if (C <= 512) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
-    else if (C <= 1024 && wide) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 1024, 16>), grid, dim3(512), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
-    else if (C <= 1024) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 1024, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles);
+    const int xcd_map = getenv("FV_DWLN_RR") == nullptr;   // experiments: round-robin tiles (the old mapping)
+    if (C <= 256) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 256, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles, B, xcd_map);
+    else if (C <= 512 && wide) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512, 16>), grid, dim3(512), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles, B, xcd_map);
+    else if (C <= 512) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles, B, xcd_map);
+    else if (C <= 1024 && wide) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 1024, 16>), grid, dim3(512), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles, B, xcd_map);
+    else if (C <= 1024) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 1024, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles, B, xcd_map);
     else return false;
     return true;
 }
