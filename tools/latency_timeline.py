@@ -13,7 +13,7 @@ for r in rows[1:]:
     else:
         cur.append(r)
 bursts.append(cur)
-b = [x for x in bursts if len(x) == n][-1]
+b = [x for x in bursts if len(x) % n == 0 and len(x) <= 40 * n][-1][-n:]   # back-to-back forwards merge into one burst: take the last
 t0 = b[0][0]
 end = t0
 for s, e, q, name, grid in b:
