@@ -3,7 +3,7 @@
 tools/probe_forward.py into profiles/traffic.json: HBM bytes per launch for every engine kernel, keyed like bench.py's
 roofline key.  Correction per MI355X_MICROARCH.md §HBM, re-calibrated here with tools/pmc_calib.hip (2 GiB streams, 4 B and
 16 B per lane): FETCH_SIZE counts exactly 1/2 of the bytes read, WRITE_SIZE is exact; both are in KB.
-usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> [out.json]"""
+usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> [out.json] [--merge] [--build NAME]"""
 import collections, csv, glob, json, os, re, sys
 
 
@@ -78,5 +78,8 @@ if __name__ == "__main__":
         old = json.load(open(out))
         old.update(res)
         res = old
+    for i, a in enumerate(sys.argv):   # --build NAME: recorded as "_build" (bench.py quotes it in roofline.traffic_source)
+        if a == "--build" and i + 1 < len(sys.argv):
+            res["_build"] = sys.argv[i + 1]
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(f"{len(res)} kernels -> {out}")
