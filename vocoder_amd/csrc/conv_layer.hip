@@ -203,7 +203,7 @@ void conv_layer_destroy(ConvLayer& L) {
     L.d_bias = nullptr;
 }
 
-#ifdef FV_X_SPLITK_TS
+#if defined(FV_X_SPLITK_TS) || defined(FV_X_CONV_TS)
 static long long* g_sk_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void fv_debug_set_splitk_timestamps(void* device_buffer) { g_sk_ts = (long long*)device_buffer; }
 #endif
@@ -447,7 +447,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         }
     }
 
-#ifdef FV_X_SPLITK_TS
+#if defined(FV_X_SPLITK_TS) || defined(FV_X_CONV_TS)
     p.dbg_ts = g_sk_ts;
 #endif
     int cfg = choose_tile(L.M, p.N, r.batch);

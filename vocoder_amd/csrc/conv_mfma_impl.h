@@ -96,15 +96,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             cok[jn] = n < p.N;
         }
     }
+#ifndef FV_X_EPI_ROWS
+#define FV_X_EPI_ROWS 8
+#endif
+    // RG row groups of 4 accumulator registers are processed together: their residual / accumulate operands are requested up
+    // front, so an m-tile costs 16 / (4 RG) round trips to L2 / HBM instead of four.  Two groups (8 rows) fit the register
+    // budget of three workgroups per CU; four (the whole m-tile) spill and measured +1.2 % on the headline step.  The gain of
+    // two is small (-0.2 %): tools/probe_conv_timeline.py shows a 128 x 128 workgroup ~20 us in this function (12 us without a
+    // residual), but that is bandwidth, not latency — every CU's workgroups start together, so the whole chip reads its
+    // residual tiles and stores its outputs (2 x 49 MB at B = 32) in the same few microseconds, twice per launch.
+    constexpr int RG = FV_X_EPI_ROWS / 4;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            // 4 rows (r & 3) x NT columns at a time: issue all residual / accumulate loads, then compute, then store
-            unsigned off[4 * NT];
-            float val[4 * NT], rv[4 * NT], yo[4 * NT];
+        for (int rq0 = 0; rq0 < 4; rq0 += RG) {
+            unsigned off[4 * RG * NT];
+            float val[4 * RG * NT], rv[4 * RG * NT], yo[4 * RG * NT];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
+            for (int rr4 = 0; rr4 < 4 * RG; ++rr4) {
+                const int rq = rq0 + rr4 / 4, rr = rr4 % 4;
                 const int m = (mt0 + i) * 32 + rr + 8 * rq + 4 * (lane >> 5);
                 const bool mok = m < p.M;
                 const int mc = mok ? m : 0;
@@ -123,29 +133,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     const int t = coff[jn] + ph;
                     bool ok = mok && cok[jn];
                     if (p.convt) ok = ok && t >= 0 && t < p.Tout;
-                    off[rr * NT + jn] = ok ? (unsigned)(row_off + t) * 4u : 0xFFFFFFFFu;
-                    val[rr * NT + jn] = fmaf(acc[i][jn][rq * 4 + rr], p.acc_scale, bias) * gm;   // acc_scale == 1: exact
+                    off[rr4 * NT + jn] = ok ? (unsigned)(row_off + t) * 4u : 0xFFFFFFFFu;
+                    val[rr4 * NT + jn] = fmaf(acc[i][jn][rq * 4 + rr], p.acc_scale, bias) * gm;   // acc_scale == 1: exact
                 }
             }
             if (has_res) {
 #pragma unroll
-                for (int q = 0; q < 4 * NT; ++q) rv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, off[q], 0, 0));
+                for (int q = 0; q < 4 * RG * NT; ++q) rv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, off[q], 0, 0));
             }
             if (accum) {
 #pragma unroll
-                for (int q = 0; q < 4 * NT; ++q) yo[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, off[q], 0, 0));
+                for (int q = 0; q < 4 * RG * NT; ++q) yo[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, off[q], 0, 0));
             }
             if (has_res) {
 #pragma unroll
-                for (int q = 0; q < 4 * NT; ++q) val[q] += rv[q];
+                for (int q = 0; q < 4 * RG * NT; ++q) val[q] += rv[q];
             }
             act_apply_all(val, p.post_act, p.slope);
             if (accum) {
 #pragma unroll
-                for (int q = 0; q < 4 * NT; ++q) val[q] = (yo[q] + val[q]) * p.out_scale;
+                for (int q = 0; q < 4 * RG * NT; ++q) val[q] = (yo[q] + val[q]) * p.out_scale;
             }
 #pragma unroll
-            for (int q = 0; q < 4 * NT; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[q]), yrs, off[q], 0, 0);
+            for (int q = 0; q < 4 * RG * NT; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[q]), yrs, off[q], 0, 0);
         }
     }
 }
@@ -195,6 +205,13 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
     const bool flat = KS == 1 && p.flat;
 
+#ifdef FV_X_CONV_TS
+#define FV_CV_STAMP(i) do { if (p.dbg_ts && threadIdx.x == 0) p.dbg_ts[(long long)blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
+    if (p.dbg_ts && threadIdx.x == 0) p.dbg_ts[(long long)blockIdx.x * 16 + 15] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);   // HW_ID, XCC_ID
+#else
+#define FV_CV_STAMP(i) do { } while (0)
+#endif
+    FV_CV_STAMP(0);
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -346,6 +363,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
         float* xsb = xs[c & 1];
         store_chunk(xsb, c);
         __syncthreads();
+        if (c < 12) FV_CV_STAMP(1 + c);
         if (c + 1 < nch) load_chunk(c + 1);
         // readfirstlane: c is wave-uniform, this makes the weight offsets provably so (else hipcc wraps every buffer
         // load in a waterfall loop)
@@ -409,7 +427,12 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
         }
     }
 
+    FV_CV_STAMP(13);
     conv_epilogue<MT, NT>(p, acc, b, mt0, n0 + wn * (NT * 32) + (lane & 31), lane);
+#ifdef FV_X_CONV_TS
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    FV_CV_STAMP(14);
 }
 
 // Latency variant for launches that cannot fill the chip with regular tiles (small batch x short T): the workgroup
