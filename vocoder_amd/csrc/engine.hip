@@ -793,7 +793,12 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
         // empty kernel at the start of the forward all measured the same or worse.
         static const long long tree_max = std::getenv("FV_TREE_MAX") ? std::atoll(std::getenv("FV_TREE_MAX")) : (1LL << 22);   // elements
         const bool tree = multi && nk == 3 && (long long)B * ch * t <= tree_max;
-        for (int j = 0; j < nk; ++j) {
+        // Without the accumulate chain the host may enqueue the branches in any order: longest (largest k, the stage's critical
+        // path) first.  A replayed graph starts sibling nodes in creation order — in stage 0 the k = 11 branch used to start 53 us
+        // after the fork, behind the two shorter ones (single clip: p50 1.04 -> 1.00 ms; FV_TREE_ORDER=asc: the old order).
+        static const bool order_desc = std::getenv("FV_TREE_ORDER") == nullptr;
+        for (int jj = 0; jj < nk; ++jj) {
+            const int j = (tree && order_desc) ? nk - 1 - jj : jj;
             ResBranch& br = *stg->branches[j];
             hipStream_t bs = (multi && j > 0) ? bstreams[j - 1] : s;
             if (multi && j > 0) FV_HIP_CHECK(hipStreamWaitEvent(bs, bev_fork[stage_idx], 0));
