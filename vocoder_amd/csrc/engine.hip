@@ -785,18 +785,22 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
         const bool dbg_here = dbg_stop >= 0 && dbg_stop / 100 == stage_idx;
         const int dbg_pair = (dbg_stop / 10) % 10, dbg_half = dbg_stop % 10;
         // ParralelBlock / stack-mean of the three ResBlock1 / AMPBlock branches (hifigan.py:132-133, bigvgan.py:358-365)
-        // Small launches (single clips): the ordered accumulate makes each branch's last kernel wait for the previous branch's,
-        // 20-65 us per stage of cross-queue dependencies on a 1.1 ms forward (tools/latency_timeline.py).  There the branches
-        // keep their own outputs and one small kernel forms the mean after the join (B = 1: 1.07 -> 1.02 ms per forward, still
-        // ahead at B = 12); large batches keep the accumulate (B = 32: the extra pass costs 0.1 ms per step).  Sharing one stream
-        // between the two shorter branches, putting the longest branch on the caller's stream, or waking the side queues with an
-        // empty kernel at the start of the forward all measured the same or worse.
-        static const long long tree_max = std::getenv("FV_TREE_MAX") ? std::atoll(std::getenv("FV_TREE_MAX")) : (1LL << 22);   // elements
-        const bool tree = multi && nk == 3 && (long long)B * ch * t <= tree_max;
-        // Without the accumulate chain the host may enqueue the branches in any order: longest (largest k, the stage's critical
-        // path) first.  A replayed graph starts sibling nodes in creation order — in stage 0 the k = 11 branch used to start 53 us
-        // after the fork, behind the two shorter ones (single clip: p50 1.04 -> 1.00 ms; FV_TREE_ORDER=asc: the old order).
-        static const bool order_desc = std::getenv("FV_TREE_ORDER") == nullptr;
+        // Y = ((y0 + y1) + y2) / 3 is formed in one of two ways — the same additions in the same order, so bit-identical:
+        //   chain  y0 -> Y, (Y + y1) -> Y, (Y + y2) / 3 -> Y in the branches' last epilogues, ordered by events (single stream, other
+        //          branch counts, FV_BRANCH_MEAN=chain)
+        //   tree   the branches keep their outputs in their own buffers and mean_of_three_kernel forms Y after the join.
+        // The chain makes each branch's last kernel wait for the previous branch's: a single clip paid 20-65 us of cross-queue
+        // waits per stage (tools/latency_timeline.py), and at B = 32 the k = 7 and k = 11 branches' final convs ran one after the
+        // other, alone on the chip, at the end of every stage (rocprofv3 trace).  Without it the host is also free to enqueue the
+        // branches longest first (k = 11, 7, 3): a replayed graph starts sibling nodes in creation order, and the k = 11 chain —
+        // every stage's critical path — used to start last (53 us after the fork in stage 0 of a single clip).  Tree + longest
+        // first: B = 1 1.07 -> 0.97 ms per forward, B = 32 15.12 -> 15.00 ms (the extra pass over four tensors included; with
+        // the branches enqueued shortest first the tree was 0.1 ms *slower* than the chain at B = 32).  Summing the other two
+        // outputs in the last branch's final epilogue instead of a separate kernel measured 15.02 / 1.04 ms: not kept.  Neither
+        // were: two streams, the longest branch on the caller's stream, a wake-up kernel on the side queues, stream priorities.
+        static const char* const mean_env = std::getenv("FV_BRANCH_MEAN");   // experiments: "chain"
+        const bool tree = multi && nk == 3 && !(mean_env && mean_env[0] == 'c');
+        const bool order_desc = true;
         for (int jj = 0; jj < nk; ++jj) {
             const int j = (tree && order_desc) ? nk - 1 - jj : jj;
             ResBranch& br = *stg->branches[j];
