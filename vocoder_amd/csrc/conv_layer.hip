@@ -389,6 +389,29 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.x = r.x;
+    if (r.x2 || r.x3) {
+        // input = ((x + x2) + x3) / 3: formed by the staging of the exact-fp32 polyphase transposed-conv kernels (SUM3 variants,
+        // conv_mfma_impl.h); everything else gets it from a pass of mean_of_three_kernel into the caller's scratch tensor
+        if (!r.x2 || !r.x3) {
+            set_error("conv_layer_run: x2 and x3 go together");
+            return FV_ERR_INVALID;
+        }
+        const bool f16 = L.precision == FV_PRECISION_F16X3 && L.d_wph && f16x3_per_layer_ok(L) &&
+                         (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU);
+        static const bool no_fuse = std::getenv("FV_NO_SUM3") != nullptr;   // experiments
+        if (L.transposed && conv_sum3_supported(L.ks) && L.dil == 1 && !f16 && !no_fuse) {
+            p.x2 = r.x2;
+            p.x3 = r.x3;
+        } else {
+            if (!r.sum_tmp) {
+                set_error("conv_layer_run: this layer needs a scratch tensor (sum_tmp) for the three-operand input");
+                return FV_ERR_INVALID;
+            }
+            const fv_status ms = launch_mean_of_three(r.x, r.x2, r.x3, r.sum_tmp, (long long)r.batch * L.c_in * r.t_in, stream);
+            if (ms) return ms;
+            p.x = r.sum_tmp;
+        }
+    }
     p.wp = L.d_wp;
     p.bias = L.d_bias;
     p.y = r.y;
@@ -489,6 +512,10 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     const int prof_idx = prof_begin(stream);
     ok = try_launch(cfg);
     if (!ok) {
+        if (p.x2) {   // (cannot happen for the tap counts conv_sum3_supported() accepts: they all have specialised kernels)
+            set_error("conv_layer_run: no specialised kernel for (k=%d, dilation=%d) with a three-operand input", L.ks, L.dil);
+            return FV_ERR_UNSUPPORTED;
+        }
         specialised = false;
         p.flat = 0;
         launch_batch = r.batch;
@@ -516,8 +543,9 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
         if (r.res) elems += (double)L.c_out * tout;
         if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
+        if (p.x2) elems += 2.0 * L.c_in * r.t_in;   // the other two branch outputs
         char lbl[160];
-        std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d%s grid=%d", name, L.c_in, L.c_out, L.transposed ? " convT" : "",
+        std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d%s%s grid=%d", name, L.c_in, L.c_out, L.transposed ? " convT" : "", p.x2 ? " sum3" : "",
                       launch_batch * p.m_blks * p.n_tiles);
         prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
     }

@@ -174,8 +174,11 @@ constexpr int subs_for(int ks, int w) {
 
 // min 3 waves per SIMD for the 64-accumulator tiles, 4 for the smaller ones: caps VGPR+AGPR so that several workgroups
 // stay resident per CU (their MFMA phases cover each other's staging / barrier phases)
-template <int KS, int DIL, int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void conv_mfma_kernel(const ConvParams p) {
+// SUM3: the input is ((x + x2) + x3) / 3 — the stack-mean of the three ResBlock branches of the previous stage, formed here on
+// the way into LDS instead of by a pass of its own (mean_of_three_kernel: 4 tensors of HBM traffic, 65 us per wide stage at B = 32,
+// ~10 us of launch + dependency per stage for a single clip).  Two more staging register sets: two workgroups per CU.
+template <int KS, int DIL, int WM, int WN, int MT, int NT, bool SUM3 = false>
+__global__ __launch_bounds__(256, (SUM3 || NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void conv_mfma_kernel(const ConvParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int N_BLK = WN * NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
     // Staging is split in two halves one chunk apart: load_chunk only ISSUES the loads (no dependent ALU, so no wait),
     // store_chunk — one chunk of MFMAs later — applies the activation and writes LDS (act(0) == 0 keeps the padding).
     float stage[NE];
+    float stage2[SUM3 ? NE : 1], stage3[SUM3 ? NE : 1];
     const long long x_items = flat ? (long long)(p.n_total / p.N) : 1;   // batch items spanned by the descriptor
     auto load_chunk = [&](int c) {
         const int cbase = c * CH;
@@ -296,6 +300,16 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
             if (KS == 1 && flat) off = st_row[KS == 1 ? i : 0] < p.Cin - cbase ? off : 0xFFFFFFFFu;
             stage[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
         }
+        if constexpr (SUM3) {   // (never flat: the transposed convs that use it have a halo)
+            const unsigned bytes = (unsigned)((rows < span ? rows : span) * 4);
+            const long long boff = (long long)b * p.x_bstride + (long long)cbase * p.Tin;
+            const __amdgpu_buffer_rsrc_t xrs2 = uniform_rsrc(p.x2 + boff, bytes), xrs3 = uniform_rsrc(p.x3 + boff, bytes);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                stage2[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs2, st_voff[i], 0, 0));
+                stage3[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs3, st_voff[i], 0, 0));
+            }
+        }
     };
     auto act_in = [&](float v) {
         if (p.pre_act == FV_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
@@ -314,7 +328,9 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int e = sid + i * NTHR;
-            const float v = act_in(stage[i]);
+            float v = stage[i];
+            if constexpr (SUM3) v = ((v + stage2[i]) + stage3[i]) * (1.0f / 3.0f);   // the additions and the scale of the accumulate chain
+            v = act_in(v);
             if (e < TOT) dst[e] = v;
         }
     };
@@ -448,7 +464,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void c
 #else
 #define FV_SK_STAMP(i) do { } while (0)
 #endif
-template <int KS, int DIL, int NT, int NW>
+template <int KS, int DIL, int NT, int NW, bool SUM3 = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_splitk_kernel(const ConvParams p) {
     FV_SK_STAMP(0);
     static_assert(NW == 4, "four waves split K: one 8-channel sub-chunk of the 32-channel LDS chunk each");
@@ -513,21 +529,41 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_splitk_kernel(const Conv
     constexpr int PF = KS >= 8 ? FV_X_SPLITK_PF_LONG : (KS >= 5 ? FV_X_SPLITK_PF_MID : FV_X_SPLITK_PF_SHORT);
     constexpr int RING = PF + 1;
     float stage[RING][NE];
-    auto load_chunk = [&](float (&dst)[NE], int c) __attribute__((always_inline)) {
+    float stage2[SUM3 ? RING : 1][SUM3 ? NE : 1], stage3[SUM3 ? RING : 1][SUM3 ? NE : 1];   // SUM3: see conv_mfma_kernel
+    const float* __restrict__ xb2 = SUM3 ? p.x2 + (long long)b * p.x_bstride : nullptr;
+    const float* __restrict__ xb3 = SUM3 ? p.x3 + (long long)b * p.x_bstride : nullptr;
+    auto load_from = [&](const float* __restrict__ base, float (&dst)[SUM3 ? NE : 1], int c) __attribute__((always_inline)) {   // SUM3 operands
+        const int cbase = c * CHW;
+        const int rows = p.Cin - cbase > 0 ? p.Cin - cbase : 0;
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(base + (long long)(rows ? cbase : 0) * p.Tin, (unsigned)(rows * p.Tin) * 4u);
+        static_for<(SUM3 ? NE : 1)>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, st_voff[i], 0, 0));
+        });
+    };
+    auto load_chunk = [&](auto slot_c, int c) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slot_c)::value;
         const int cbase = c * CHW;
         // chunks past the last one (prefetch overrun) get an empty descriptor: every load returns 0
         const int rows = p.Cin - cbase > 0 ? p.Cin - cbase : 0;
         const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)(rows ? cbase : 0) * p.Tin, (unsigned)(rows * p.Tin) * 4u);
         static_for<NE>([&](auto i_c) {
             constexpr int i = decltype(i_c)::value;
-            dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_voff[i], 0, 0));
+            stage[SL][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_voff[i], 0, 0));
         });
+        if constexpr (SUM3) {
+            load_from(xb2, stage2[SL], c);
+            load_from(xb3, stage3[SL], c);
+        }
     };
-    auto store_chunk = [&](float* dst, const float (&src)[NE]) __attribute__((always_inline)) {
+    auto store_chunk = [&](float* dst, auto slot_c) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slot_c)::value;
         static_for<NE>([&](auto i_c) {
             constexpr int i = decltype(i_c)::value;
             const int e = tid + i * THREADS;
-            if (e < TOT) dst[e] = act_apply(src[i], p.pre_act, p.slope);
+            float v = stage[SL][i];
+            if constexpr (SUM3) v = ((v + stage2[SL][i]) + stage3[SL][i]) * (1.0f / 3.0f);
+            if (e < TOT) dst[e] = act_apply(v, p.pre_act, p.slope);
         });
     };
 
@@ -563,7 +599,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_splitk_kernel(const Conv
     const int last = nchunks - 1;
     static_for<PF>([&](auto d_c) {
         constexpr int d = decltype(d_c)::value;
-        load_chunk(stage[d], d);
+        load_chunk(d_c, d);
 #pragma unroll
         for (int j = 0; j < KS; ++j) aq[d][j] = load_a(d <= last ? d : last, j);
     });
@@ -574,7 +610,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_splitk_kernel(const Conv
             const int c = c0 + S;
             if (c < nchunks) {
                 float* xsb = xs[c & 1];
-                store_chunk(xsb, stage[S]);
+                store_chunk(xsb, slot_c);
                 __syncthreads();
                 if (c == 0) FV_SK_STAMP(1);
                 // The NL loads of chunk c + PF are issued one at a time BETWEEN the MFMAs, window elements first: a wave issues
@@ -584,13 +620,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_splitk_kernel(const Conv
                 const int cbase = cx * CHW;
                 const int rows = p.Cin - cbase > 0 ? p.Cin - cbase : 0;   // past the last chunk: empty descriptor, loads return 0
                 const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)(rows ? cbase : 0) * p.Tin, (unsigned)(rows * p.Tin) * 4u);
+                const __amdgpu_buffer_rsrc_t xrs2 = uniform_rsrc((SUM3 ? xb2 : xb) + (long long)(rows ? cbase : 0) * p.Tin, (unsigned)(rows * p.Tin) * 4u);
+                const __amdgpu_buffer_rsrc_t xrs3 = uniform_rsrc((SUM3 ? xb3 : xb) + (long long)(rows ? cbase : 0) * p.Tin, (unsigned)(rows * p.Tin) * 4u);
                 const int cn = cx <= last ? cx : last;
                 constexpr int NL = NE + KS;
                 constexpr int LSTEP = KSS / NL > 0 ? KSS / NL : 1;
                 auto issue_load = [&](auto idx_c) __attribute__((always_inline)) {   // compile-time index: the rings must stay in registers
                     constexpr int idx = decltype(idx_c)::value;
-                    if constexpr (idx < NE) stage[SN][idx] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_voff[idx], 0, 0));
-                    else if constexpr (idx < NL) aq[SN][idx - NE] = load_a(cn, idx - NE);
+                    if constexpr (idx < NE) {
+                        stage[SN][idx] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, st_voff[idx], 0, 0));
+                        if constexpr (SUM3) {
+                            stage2[SN][idx] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs2, st_voff[idx], 0, 0));
+                            stage3[SN][idx] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs3, st_voff[idx], 0, 0));
+                        }
+                    } else if constexpr (idx < NL) {
+                        aq[SN][idx - NE] = load_a(cn, idx - NE);
+                    }
                 };
 #pragma unroll
                 for (int d = 0; d < DB; ++d) load_b(bq[d], xsb, d);
@@ -641,6 +686,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_splitk_kernel(const Conv
 template <int KS, int DIL, int WM, int WN, int MT, int NT>
 inline void launch_one(const ConvParams& p, int batch, hipStream_t s) {
     const int grid = batch * p.m_blks * p.n_tiles;
+    if constexpr (KS == 1 || KS == 2 || KS == 4) {   // tap counts of the polyphase transposed convs (the upsamplers): SUM3 variants
+        if (p.x2) {
+            hipLaunchKernelGGL((conv_mfma_kernel<KS, DIL, WM, WN, MT, NT, true>), dim3(grid), dim3(256), 0, s, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((conv_mfma_kernel<KS, DIL, WM, WN, MT, NT>), dim3(grid), dim3(256), 0, s, p);
 }
 
@@ -660,9 +711,21 @@ inline bool launch_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
             if constexpr (KS == 1) { launch_one<KS, DIL, 4, 1, 2, 2>(p, batch, s); return true; }
             return false;
         case TILE_SPLITK_32x64:
+            if constexpr (KS == 1 || KS == 2 || KS == 4) {
+                if (p.x2) {
+                    hipLaunchKernelGGL((conv_mfma_splitk_kernel<KS, DIL, 2, 4, true>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
+                    return true;
+                }
+            }
             hipLaunchKernelGGL((conv_mfma_splitk_kernel<KS, DIL, 2, 4>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
             return true;
         case TILE_SPLITK_32x32:
+            if constexpr (KS == 1 || KS == 2 || KS == 4) {
+                if (p.x2) {
+                    hipLaunchKernelGGL((conv_mfma_splitk_kernel<KS, DIL, 1, 4, true>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
+                    return true;
+                }
+            }
             hipLaunchKernelGGL((conv_mfma_splitk_kernel<KS, DIL, 1, 4>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
             return true;
         default: return false;

@@ -762,11 +762,20 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
     if ((st = conv_layer_run(ups.conv_pre, r, s))) return st;
     int t = (int)ups.conv_pre.out_len(T);
     int stage_idx = 0;
+    bool sum_pending = false;   // tree mode: the stage output is still three branch buffers (XB(0..2))
+    const int n_stages = (int)ups.stages.size();
     for (auto& stg : ups.stages) {
         // x = ups[i](silu(x))  — HiFiGAN (hifigan.py:230-231); BigVGAN has no pre-activation (bigvgan.py:355-356)
         r = ConvRun();
         r.batch = B;
         r.x = cur;
+        if (sum_pending) {   // the previous stage left its three branch outputs: the upsampler conv forms their mean itself
+            r.x = XB(0);
+            r.x2 = XB(1);
+            r.x3 = XB(2);
+            r.sum_tmp = cur;   // (kernels without the three-operand staging form it here first)
+            sum_pending = false;
+        }
         r.y = S;
         r.t_in = t;
         r.pre_act = ups.bigvgan ? FV_ACT_NONE : FV_ACT_SILU;
@@ -894,7 +903,14 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
         if (tree) {
             // join all three, then Y = ((y0 + y1) + y2) / 3 — the same additions in the same order as the accumulate chain
             for (int j = 1; j < nk; ++j) FV_HIP_CHECK(hipStreamWaitEvent(s, bev_last[stage_idx * nk + j], 0));
-            if ((st = launch_mean_of_three(XB(0), XB(1), XB(2), Y, (long long)B * ch * t, s))) return st;
+            // the next stage's upsampler conv forms the mean while staging its input (conv_mfma_impl.h, SUM3); the last stage's
+            // output goes through mean_of_three_kernel (its consumers are the narrow post kernels)
+            static const bool fuse_mean = std::getenv("FV_NO_SUM3") == nullptr;
+            if (stage_idx + 1 < n_stages && fuse_mean && !dbg_here) {
+                sum_pending = true;
+            } else if ((st = launch_mean_of_three(XB(0), XB(1), XB(2), Y, (long long)B * ch * t, s))) {
+                return st;
+            }
         } else if (multi) {
             // join: the last branch's final kernel is ordered after every other branch's
             FV_HIP_CHECK(hipStreamWaitEvent(s, bev_last[stage_idx * nk + nk - 1], 0));

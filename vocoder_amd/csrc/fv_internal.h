@@ -82,6 +82,8 @@ enum OutMode : int { OUT_SET = 0, OUT_ACCUM = 1 };  // OUT_ACCUM: y = (y_old + v
 
 struct ConvParams {
     const float* x;      // (B, Cin, Tin)
+    const float* x2;     // SUM3 kernels: the input is ((x + x2) + x3) / 3 — the stack-mean of three ResBlock branches formed while
+    const float* x3;     //   staging (same layout as x); NULL otherwise
     const float4* wp;    // packed weights, see pack_conv_weights()
     const float* bias;   // (m_pad) zero padded, never NULL
     float* y;
@@ -148,8 +150,17 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
                             int stride, const float* host_w, const float* host_bias, bool with_f16x3 = false);
 void conv_layer_destroy(ConvLayer& L);
 
+// do the specialised kernels of this tap count form the three-operand input mean themselves (ConvParams::x2 / x3)?  The tap counts
+// of the polyphase transposed convs (the upsamplers): conv_mfma_impl.h instantiates SUM3 variants for exactly these
+constexpr bool conv_sum3_supported(int ks) { return ks == 1 || ks == 2 || ks == 4; }
+
 struct ConvRun {
     const float* x = nullptr;
+    // the input is ((x + x2) + x3) / 3 when x2 / x3 are given (stack-mean of three branch outputs, formed by the conv's staging
+    // where the kernel supports it, otherwise by mean_of_three_kernel into sum_tmp first)
+    const float* x2 = nullptr;
+    const float* x3 = nullptr;
+    float* sum_tmp = nullptr;
     float* y = nullptr;
     const float* res = nullptr;
     const float* gamma = nullptr;
