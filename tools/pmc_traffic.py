@@ -9,11 +9,11 @@ import collections, csv, glob, json, os, re, sys
 
 def key_of(kernel_name: str, grid_threads: int):
     blocks = grid_threads // 256
-    m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", kernel_name)
+    m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", kernel_name)
     if m:
         ks, dil, wm, wn, mt, nt = map(int, m.groups())
         return f"conv_mfma k={ks} d={dil} tile={wm * mt * 32}x{wn * nt * 32} grid={blocks}"
-    m = re.search(r"conv_mfma_splitk_kernel<(\d+), (\d+), (\d+), (\d+)>", kernel_name)
+    m = re.search(r"conv_mfma_splitk_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", kernel_name)
     if m:
         return f"conv_mfma k={m.group(1)} d={m.group(2)} tile=splitK32x{32 * int(m.group(3))} grid={blocks}"
     m = re.search(r"conv_f16x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", kernel_name)
