@@ -248,6 +248,30 @@ def test_graph_replay_and_branch_streams_match_first_eager_call():
     assert np.abs(out.cpu().numpy() - ref_b).max() <= TOL
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_branch_mean_in_the_next_upsampler_is_bit_identical_to_the_ordered_accumulate(prec, monkeypatch):
+    """With branch streams the three ResBlock branches keep their own outputs and the next stage's upsampler conv (the last
+    stage: mean_of_three_kernel) forms ((y0 + y1) + y2) / 3; on one stream the branches accumulate into the stage output in
+    order.  Same additions, same order: the two engines must agree to the last bit, single clip and full batch."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, upsampler_config
+    for kind, cfg, sdf, shapes in ((_lib.FV_MODEL_HIFIGAN, dict(syn.HIFIGAN_V1_44K), syn.hifigan_state_dict, ((1, 86), (32, 86), (5, 33))),
+                                   (_lib.FV_MODEL_BIGVGAN, dict(syn.BIGVGAN_24K), syn.bigvgan_state_dict, ((1, 94), (9, 40)))):
+        sd = sdf(cfg, 3)
+        monkeypatch.setenv("FV_SINGLE_STREAM", "1")
+        chain = Engine(kind, ups=upsampler_config(**cfg), state_dict=sd, precision=prec)
+        monkeypatch.delenv("FV_SINGLE_STREAM")
+        tree = Engine(kind, ups=upsampler_config(**cfg), state_dict=sd, precision=prec)
+        for B, T in shapes:
+            mel = torch.from_numpy(syn.synthetic_mel(B, cfg["num_mels"], T, seed=B + T)).to(_dev())
+            ya = chain(mel).clone()
+            yb = tree(mel).clone()
+            yb2 = tree(mel).clone()   # (second call: captured)
+            yb3 = tree(mel).clone()   # (third: replayed)
+            torch.cuda.synchronize()
+            assert torch.equal(ya, yb) and torch.equal(ya, yb2) and torch.equal(ya, yb3), (kind, prec, B, T, float((ya - yb).abs().max()))
+
+
 def test_long_clip_and_odd_lengths_vs_oracle():
     """A 35 s clip at hop 16 (T_mel = 1501, prime-ish) and a 2-frame clip through the tiny config: exercises many tiles,
     ragged last tiles in every stage and the fused-pair kernels' halo logic at both ends."""
