@@ -165,7 +165,7 @@ def test_f16x3_vocos_and_convnext_match_oracle():
                  state_dict=sd, precision="f16x3")
     x = torch.from_numpy(mel).to(_dev())
     y = eng(x).cpu().numpy()
-    assert np.abs(y - ref).max() <= 1e-4, np.abs(y - ref).max()
+    assert np.abs(y - ref).max() <= 1e-4 * float(np.abs(ref).max()), (np.abs(y - ref).max(), np.abs(ref).max())   # of the waveform's own peak
     prof = eng.profile(x)
     assert any(r["kernel"].startswith("conv_f16x3<k=1") for r in prof), [r["kernel"] for r in prof][:8]
 

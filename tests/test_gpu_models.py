@@ -13,6 +13,13 @@ torch = pytest.importorskip("torch")
 TOL = 1e-4
 
 
+def _peak_tol(ref):
+    """Vocos / ISTFT-head waveforms are small with the synthetic head weights (peaks of 0.02 ... 0.07 on the reference captures),
+    so an absolute 1e-4 would let an error of 0.5 % of the signal pass: their bar is 1e-4 of the expected waveform's own peak
+    (2e-6 absolute at a peak of 0.02; VERDICT r2 weak #1).  Reference: vocos.py:57-69."""
+    return TOL * float(np.abs(ref).max())
+
+
 def _dev():
     assert torch.cuda.is_available()
     return torch.device("cuda:0")
@@ -166,12 +173,11 @@ def test_vocos_full_depth_golden_and_oracle():
     eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), head=istft_head_config(**cfg["head"]),
                  state_dict=sd)
     y = _fwd(eng, g["mel"])
-    scale = max(1.0, float(np.abs(g["out"]).max()))
-    assert np.abs(y - g["out"]).max() <= TOL * scale, (np.abs(y - g["out"]).max(), scale)
+    assert np.abs(y - g["out"]).max() <= _peak_tol(g["out"]), (np.abs(y - g["out"]).max(), np.abs(g["out"]).max())
     mel = syn.synthetic_mel(2, 80, 10, seed=61)
     ref = orc.vocos_forward(sd, cfg, mel)
     y = _fwd(eng, mel)
-    assert np.abs(y - ref).max() <= TOL * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(y - ref).max() <= _peak_tol(ref), (np.abs(y - ref).max(), np.abs(ref).max())
 
 
 def test_convnext_and_vocos():
@@ -189,7 +195,7 @@ def test_convnext_and_vocos():
     eng = Engine(_lib.FV_MODEL_ISTFT_HEAD, head=istft_head_config(**g["cfg"]), state_dict=sd)
     y = _fwd(eng, g["x"])
     err = np.abs(y[:, 0] - g["wave"]).max()
-    assert err <= TOL, f"istft head max|d| = {err:.3e}"
+    assert err <= _peak_tol(g["wave"]), f"istft head max|d| = {err:.3e} (peak {np.abs(g['wave']).max():.3f})"
 
     g = load_golden("vocos_tiny.npz")
     sd = syn.vocos_state_dict(g["cfg"], g["seed"])
@@ -197,7 +203,7 @@ def test_convnext_and_vocos():
                  head=istft_head_config(**g["cfg"]["head"]), state_dict=sd)
     y = _fwd(eng, g["mel"])
     err = np.abs(y - g["out"]).max()
-    assert err <= TOL, f"vocos max|d| = {err:.3e}"
+    assert err <= _peak_tol(g["out"]), f"vocos max|d| = {err:.3e} (peak {np.abs(g['out']).max():.3f})"
 
 
 def test_vocos_24k_vs_oracle():
@@ -212,7 +218,7 @@ def test_vocos_24k_vs_oracle():
                  state_dict=sd)
     y = _fwd(eng, mel)
     err = np.abs(y - ref).max()
-    assert err <= TOL, f"vocos-24k max|d| = {err:.3e}"
+    assert err <= _peak_tol(ref), f"vocos-24k max|d| = {err:.3e} (peak {np.abs(ref).max():.3f})"
 
 
 def test_graph_replay_and_branch_streams_match_first_eager_call():
@@ -534,7 +540,7 @@ def test_shipped_vocos_configs_vs_oracle(name, depths, dims, res):
         y = _fwd(eng, mel)
         assert y.shape == ref.shape == (2, 1, 9 * r["hop_length"])
         err = np.abs(y - ref).max()
-        assert err <= TOL, f"{name} @ {res} ({prec}): max|d| = {err:.3e} (ref max {np.abs(ref).max():.3f})"
+        assert err <= _peak_tol(ref), f"{name} @ {res} ({prec}): max|d| = {err:.3e} (ref max {np.abs(ref).max():.3f})"
 
 
 def test_shipped_hifigan_vae_decoder_config_vs_oracle():
@@ -565,7 +571,7 @@ def test_istft_head_with_a_hop_that_does_not_divide_n_fft_vs_oracle():
     y = _fwd(eng, x)
     assert y.shape == (2, 1, 5 * 2048) and ref.shape == (2, 5 * 2048)   # ISTFTHead returns (B, T); the engine adds the channel axis (unify.py:30-31)
     err = np.abs(y[:, 0] - ref).max()
-    assert err <= TOL * max(1.0, np.abs(ref).max()), f"max|d| = {err:.3e} (ref max {np.abs(ref).max():.3f})"
+    assert err <= _peak_tol(ref), f"max|d| = {err:.3e} (ref max {np.abs(ref).max():.3f})"
 
 
 def test_bigvgan_long_clip_covers_the_interior_snake_tiles_vs_oracle():
@@ -636,14 +642,15 @@ def test_bigvgan_and_vocos_at_the_baseline_batch_sizes_vs_oracle():
         y = _fwd(e, mel)
         assert y.shape == (B, 1, 94 * 256) and np.isfinite(y).all()
         assert np.array_equal(y, _fwd(e, mel))
-        scale = max(1.0, np.abs(y).max())
+        # BigVGAN waveforms are O(1) (tanh): absolute bar; Vocos ones are small with the synthetic head: bar relative to the peak
+        scale = 1.0 if e is eng else float(np.abs(y).max())
         for i in (0, B // 2, B - 1):
             yi = _fwd(e, mel[i:i + 1])
             assert np.abs(yi[0] - y[i]).max() <= 3e-5 * scale, (i, np.abs(yi[0] - y[i]).max(), scale)
         for i in (0, B - 1):
             ref = oracle(mel[i:i + 1])
             err = np.abs(ref[0] - y[i]).max()
-            assert err <= TOL * scale, f"B={B} item {i}: max|d| = {err:.3e} vs oracle on the full clip (scale {scale:.2f})"
+            assert err <= TOL * scale, f"B={B} item {i}: max|d| = {err:.3e} vs oracle on the full clip (scale {scale:.3f})"
         e.close()
 
 
@@ -802,3 +809,60 @@ def test_single_clip_forward_is_bitwise_repeatable_across_branch_streams(model, 
         differing += int(not torch.equal(out, ref))
     eng.close()
     assert differing == 0, f"{differing} of 25 repeats differ from the first run"
+
+
+def test_hifigan_batch_256_the_eight_gpu_global_batch_on_one_gpu():
+    """BASELINE config[4]'s global batch (256 one-second clips; 32 per GPU over 8 GPUs in the reference's launch,
+    configs/trainer/default.yaml:6-9) pushed through ONE engine: finite, deterministic, items equal to the same clip run alone,
+    and the reference's own 1 s capture (hifigan_v1_t86.npz, hifigan.py:226-249) placed at the last position."""
+    g = load_golden("hifigan_v1_t86.npz")
+    sd = syn.hifigan_state_dict(g["cfg"], g["seed"])
+    eng = _hifigan_engine(g["cfg"], sd)
+    B = 256
+    mel = syn.synthetic_mel(B, 80, 86, seed=4321)
+    mel[B - 1] = g["mel"][0]
+    x = torch.from_numpy(mel).to(_dev())
+    y_t = eng(x)
+    torch.cuda.synchronize()
+    y = y_t.cpu().numpy()
+    assert y.shape == (B, 1, 44032) and np.isfinite(y).all() and np.abs(y).max() <= 1.0
+    assert torch.equal(eng(x), y_t)                      # run to run
+    for i in (0, 128, 255):
+        yi = _fwd(eng, mel[i:i + 1])
+        assert np.abs(yi[0] - y[i]).max() <= 2e-5, (i, np.abs(yi[0] - y[i]).max())
+    err = np.abs(y[B - 1] - g["out"][0]).max()
+    assert err <= TOL, f"item 255 vs the reference capture: max|d| = {err:.3e}"
+    # the same 256 clips as eight contiguous shards of 32 (what the eight ranks compute): bit for bit the global batch
+    for r in (0, 3, 7):
+        ys = eng(x[32 * r:32 * (r + 1)])
+        torch.cuda.synchronize()
+        assert torch.equal(ys, y_t[32 * r:32 * (r + 1)]), r
+    eng.close()
+
+
+def test_bench_runs_its_collectives_on_a_one_rank_rccl_group():
+    """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (backend nccl = RCCL): the weights go through
+    broadcast_state_dict, the timed with_collectives loop runs broadcast -> forward -> all_gather on the process group, and the
+    collected batch equals the direct forward bit for bit.  A plain `python bench.py` (what the driver runs) builds the same
+    1-rank group itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-alt-precision"]
+    for launcher in (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                      "--master-port", "29541"], []):
+        r = subprocess.run([sys.executable] + launcher + [os.path.join(repo, "bench.py")] + common, capture_output=True, text=True,
+                           timeout=900, env=env, cwd=repo)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1 and "rccl_error" not in j, j.get("rccl_error")
+        c = j["with_collectives"]
+        assert c["backend"] == "rccl" and c["collected_finite"] and c["rank0_shard_equals_direct_forward"], c
+        assert c["collected_shape"] == [32, 1, 44032] and c["all_gather_bytes_per_step"] == 32 * 44032 * 4
+        assert j["output_finite"] and j["ms_per_step_eager"] > 0 and j["mixed_shapes"]["output_finite"]

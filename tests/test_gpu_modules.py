@@ -50,7 +50,7 @@ def test_bigvgan_and_vocos_and_firefly_modules():
     u.load_state_dict(_t(syn.vocos_state_dict(g["cfg"], g["seed"])), strict=True)
     y = u.eval().cuda()(torch.from_numpy(g["mel"]).cuda())
     assert y.shape == g["out"].shape
-    assert np.abs(y.cpu().numpy() - g["out"]).max() <= TOL
+    assert np.abs(y.cpu().numpy() - g["out"]).max() <= TOL * float(np.abs(g["out"]).max())   # relative to the capture's peak (0.06)
 
     # Firefly-GAN composition (f3): ConvNeXt backbone -> HiFiGAN head with k=13 pre/post convs, vs the oracle
     from oracle import oracle as orc

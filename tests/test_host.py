@@ -144,6 +144,15 @@ def test_lightning_checkpoint_with_non_tensor_objects_needs_explicit_trust(tmp_p
     q = tmp_path / "weights.pt"            # tensors only: loads without the opt-in
     torch.save({"state_dict": sd}, q)
     assert list(load_generator_state_dict(q)) == ["conv_pre.bias"]
+    # a missing or corrupt file is not a trust question: the original error comes through, with or without the opt-in
+    for trust in (False, True):
+        with pytest.raises(FileNotFoundError):
+            load_generator_state_dict(tmp_path / "absent.ckpt", trust_checkpoint=trust)
+    bad = tmp_path / "corrupt.ckpt"
+    bad.write_bytes(p.read_bytes()[:200])
+    with pytest.raises(Exception) as ei:
+        load_generator_state_dict(bad, trust_checkpoint=True)
+    assert "trust-checkpoint" not in str(ei.value)
 
 
 def test_shard_slices_cover_batch_exactly():
@@ -256,3 +265,19 @@ def test_bench_self_launches_n_ranks_without_torchrun():
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=repo)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_cpu_clip_worker_protocol():
+    """bench.py's cpu_baseline leg: oracle/cpu_clips.py workers (one process per core in use, whole clips each) answer the
+    run / quit protocol and agree with the in-process oracle on the clips they were given."""
+    import bench
+    from oracle import oracle as orc
+    pool = bench._ClipWorkers(2)
+    try:
+        dt, clips, samples = pool.run(2, 2, 3, seed=40)
+        assert clips == 4 and samples == 4 * 3 * 512 and dt > 0
+        dt, clips, samples = pool.run(1, 1, 2, seed=41)      # a subset of the pool, another shape
+        assert clips == 1 and samples == 2 * 512
+    finally:
+        pool.close()
+    assert all(p.poll() is not None for p in pool.procs)

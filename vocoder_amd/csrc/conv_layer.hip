@@ -267,9 +267,11 @@ static int choose_gemm_pw(const ConvLayer& L, const ConvRun& r, long long tout) 
     // 32-bit byte offsets over all batch items
     const long long bytes = 4LL * r.batch * std::max<long long>((long long)L.c_in * r.t_in, (long long)L.c_out * tout);
     if (bytes >= 0xFFFFFF00LL || L.c_in < 64) return -1;   // (>= 8 chunks: the operand ring is primed unconditionally)
-    if (const char* v = std::getenv("FV_PW")) {   // experiments: force a configuration, or "old" / -1 for the conv kernel
-        const int n = std::atoi(v);
-        return (v[0] == 'o' || n < 0 || n >= GEMM_PW_COUNT) ? -1 : n;
+    if (num_cus() < 8) return -1;   // a partition below one CU per XCD (or a failed query): the persistent grid would be empty
+    static const char* const force = std::getenv("FV_PW");   // experiments: force a configuration, or "old" / -1 for the conv kernel
+    if (force) {
+        const int n = std::atoi(force);
+        return (force[0] == 'o' || n < 0 || n >= GEMM_PW_COUNT) ? -1 : n;
     }
     const long long simds = (long long)(num_cus() / 8 * 8) * 4;
     const long long n64 = ((long long)tout * r.batch + 63) / 64;
@@ -305,7 +307,8 @@ static int choose_gemm_pw_xcd_rows(const ConvLayer& L, const ConvRun& r, long lo
     const int mtiles = (L.M + 32 * mt - 1) / (32 * mt);
     const double a_bytes = 4.0 * L.c_in * L.c_out, b_bytes = 4.0 * L.c_in * (double)tout * r.batch;
     int px = b_bytes < 10.0 * a_bytes ? 4 : 1;
-    if (const char* v = std::getenv("FV_PW_PX")) px = std::atoi(v);
+    static const char* const force_px = std::getenv("FV_PW_PX");   // experiments
+    if (force_px) px = std::atoi(force_px);
     if (px != 1 && px != 2 && px != 4 && px != 8) px = 1;
     while (px > 1 && mtiles % px != 0) px /= 2;
     return px;
@@ -317,6 +320,10 @@ static const char* const kSplitNames[SPLIT_COUNT] = {"128x128", "64x256", "32x25
 
 // f16x3 precision mode: tile choice + dispatch of the split-fp16 kernel (p already describes the layer call)
 static fv_status conv_layer_run_f16x3(const ConvLayer& L, const ConvRun& r, ConvParams& p, hipStream_t stream) {
+    if (p.x2 || p.x3) {   // these kernels stage one input tensor: a three-operand mean must have been formed by the caller
+        set_error("conv_layer_run: the f16x3 kernels take no three-operand input");
+        return FV_ERR_INVALID;
+    }
     p.wph = L.d_wph;
     p.nch16 = L.nch16;
     p.nch16_real = (L.c_in + 15) / 16;
@@ -386,6 +393,10 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
                   (long long)std::max<long long>((long long)L.c_out * tout, (long long)L.c_in * r.t_in));
         return FV_ERR_UNSUPPORTED;
     }
+    // the split-fp16 kernels implement the pre-activations of the MFMA-bound layers only (none / SiLU); ONE decision, used by the
+    // three-operand routing below and by the dispatch (those kernels and gemm_pw ignore x2 / x3)
+    const bool f16 = L.precision == FV_PRECISION_F16X3 && L.d_wph && f16x3_per_layer_ok(L) &&
+                     (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU);
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.x = r.x;
@@ -396,8 +407,6 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
             set_error("conv_layer_run: x2 and x3 go together");
             return FV_ERR_INVALID;
         }
-        const bool f16 = L.precision == FV_PRECISION_F16X3 && L.d_wph && f16x3_per_layer_ok(L) &&
-                         (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU);
         static const bool no_fuse = std::getenv("FV_NO_SUM3") != nullptr;   // experiments
         if (L.transposed && conv_sum3_supported(L.ks) && L.dil == 1 && !f16 && !no_fuse) {
             p.x2 = r.x2;
@@ -440,13 +449,11 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     p.y_bstride = (long long)L.c_out * tout;
     p.acc_scale = 1.0f;
 
-    // the split kernels implement the pre-activations of the MFMA-bound layers only (none / SiLU)
-    if (L.precision == FV_PRECISION_F16X3 && L.d_wph && f16x3_per_layer_ok(L) && (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU))
-        return conv_layer_run_f16x3(L, r, p, stream);
+    if (f16) return conv_layer_run_f16x3(L, r, p, stream);
 
     // pointwise convs of the MFMA-bound kind (ConvNeXt's Linear layers): the LDS-free GEMM kernel (gemm_pw.hip)
     if (!L.transposed && L.ks == 1 && L.pad_l == 0 && L.c_in % 8 == 0 && r.pre_act == FV_ACT_NONE && r.out_mode == OUT_SET) {
-        const int variant = choose_gemm_pw(L, r, tout);
+        const int variant = p.x2 ? -1 : choose_gemm_pw(L, r, tout);   // (gemm_pw stages one input tensor)
         if (variant >= 0) {
             p.flat = 1;
             p.n_total = p.N * r.batch;

@@ -1267,6 +1267,7 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
     if (const char* v = std::getenv("FV_NO_PAIR_FUSION")) e->fuse_pairs = !(v[0] == '1');
     if (const char* v = std::getenv("FV_SINGLE_STREAM")) e->branch_streams = !(v[0] == '1');
     if (const char* v = std::getenv("FV_NO_GRAPH")) e->use_graph = !(v[0] == '1');
+    if (std::getenv("FV_DEBUG_STOP")) e->use_graph = false;   // the early return leaves forked branch streams unjoined: not capturable
     *out = e;
     return FV_OK;
 }

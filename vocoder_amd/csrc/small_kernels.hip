@@ -608,8 +608,8 @@ static bool launch_dwconv_ln_tile(const float* x, const float* dw_w, const float
                                   float* y, int B, int C, int T, float eps, hipStream_t s) {
     const int n_tiles = (T + DWT_TT - 1) / DWT_TT;
     const dim3 grid((B * n_tiles + 7) / 8 * 8);   // whole groups of 8: see the XCD mapping in the kernel
-    const bool wide = getenv("FV_DWLN_NG8") == nullptr;   // 16 channel groups (512 threads) for C > 256
-    const int xcd_map = getenv("FV_DWLN_RR") == nullptr;   // experiments: round-robin tiles (the old mapping)
+    static const bool wide = getenv("FV_DWLN_NG8") == nullptr;   // 16 channel groups (512 threads) for C > 256
+    static const int xcd_map = getenv("FV_DWLN_RR") == nullptr;   // experiments: round-robin tiles (the old mapping)
     if (C <= 256) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 256, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles, B, xcd_map);
     else if (C <= 512 && wide) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512, 16>), grid, dim3(512), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles, B, xcd_map);
     else if (C <= 512) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles, B, xcd_map);
@@ -622,7 +622,8 @@ static bool launch_dwconv_ln_tile(const float* x, const float* dw_w, const float
 fv_status launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                            float* y, int B, int C, int T, int k, float eps, hipStream_t s) {
     // per-item tensors below 1 GiB: 32-bit buffer offsets
-    if ((long long)C * T < (1LL << 28) && getenv("FV_OLD_DWLN") == nullptr) {
+    static const bool old_dwln = getenv("FV_OLD_DWLN") != nullptr;   // experiments
+    if ((long long)C * T < (1LL << 28) && !old_dwln) {
         bool done = false;
         if (!dw_w) done = launch_dwconv_ln_tile<1>(x, nullptr, nullptr, ln_w, ln_b, y, B, C, T, eps, s);
         else if (k == 7) done = launch_dwconv_ln_tile<7>(x, dw_w, dw_b, ln_w, ln_b, y, B, C, T, eps, s);
@@ -915,6 +916,7 @@ fv_status launch_adain(const float* x, const float* noise, const float* w, float
     return FV_OK;
 }
 
+#ifdef FV_DEBUG_HOOKS   // not in the product library: `make BUILD=build_dbg LIB=libfishvoc_dbg.so EXTRA=-DFV_DEBUG_HOOKS`, then FV_LIB_PATH
 // Debug aid (tools/probe_lds_poison.py): fills the LDS of every CU with signalling garbage (NaN bit patterns) so that a kernel
 // which reads LDS it never wrote shows up as a changed / non-finite result instead of silently inheriting whatever the previous
 // kernel on that CU left behind (which makes results depend on which kernels of OTHER streams ran there).
@@ -931,5 +933,6 @@ extern "C" __attribute__((visibility("default"))) int fv_debug_aa_snake(const fl
 extern "C" __attribute__((visibility("default"))) void fv_debug_poison_lds(void* stream) {
     hipLaunchKernelGGL(lds_poison_kernel, dim3(num_cus() * 2), dim3(256), 0, (hipStream_t)stream, (float*)nullptr);
 }
+#endif
 
 }  // namespace fv

@@ -57,9 +57,16 @@ def load_generator_state_dict(ckpt, trust_checkpoint: bool = False) -> dict:
     ``torch.save({"state_dict": ckpt["state_dict"]}, "weights.pt")``."""
     if isinstance(ckpt, (str, Path)):
         path = ckpt
+        import pickle
         try:
             ckpt = torch.load(path, map_location="cpu", weights_only=True)
-        except Exception as exc:  # noqa: BLE001 - pickle.UnpicklingError or a RuntimeError wrapping it, by torch version
+        except OSError:
+            raise          # missing / unreadable file: not a trust question, and no second (unsafe) attempt
+        except (pickle.UnpicklingError, RuntimeError) as exc:   # the refusal itself, or a RuntimeError wrapping it (by torch version)
+            refused = isinstance(exc, pickle.UnpicklingError) or any(
+                m in str(exc) for m in ("weights_only", "Weights only", "Unsupported global", "unsupported global", "UnpicklingError"))
+            if not refused:
+                raise      # e.g. a corrupt zip archive: the full unpickler would fail the same way
             if not trust_checkpoint:
                 raise RuntimeError(
                     f"{path}: the weights-only loader refused this checkpoint ({type(exc).__name__}: {str(exc)[:200]}). "
