@@ -183,6 +183,11 @@ FV_API fv_status fv_set_precision(fv_engine* e, int32_t precision);
  * that never sees the same (buffers, batch, frames) twice gets.  May be called at any time.  No reference counterpart. */
 FV_API fv_status fv_set_graph_replay(fv_engine* e, int32_t enable);
 
+/* Kernel-selection knobs for experiments (FV_PW, FV_PW_PX, FV_DWLN_NG8, FV_DWLN_RR, FV_OLD_DWLN) are read from the environment
+ * ONCE per process (no getenv on the launch path); a harness that changes them afterwards calls this to re-read them.
+ * Not for production use; not thread-safe against concurrent forwards.  No reference counterpart. */
+FV_API void fv_reload_env(void);
+
 /* -------- forward: replaces `self.generator(input_spec)` (gan.py:286) -------- */
 
 /* Output length per clip for T_in input frames (T_mel * hop_length for the generators). */

@@ -195,9 +195,18 @@ PW_CASES = [
 ]
 
 
+def _reload_env_later():
+    # registered BEFORE monkeypatch's own teardown runs?  No: finalizers run last-in-first-out and monkeypatch (a fixture
+    # requested earlier) is torn down after this one — so drop the variable here ourselves, then re-read.
+    import os
+    from vocoder_amd import _lib
+    os.environ.pop("FV_PW", None)
+    _lib.reload_env()
+
+
 @pytest.mark.parametrize("cfg", ["0", "1", None])
 @pytest.mark.parametrize("cin,cout,B,T", PW_CASES)
-def test_pointwise_gemm_every_configuration_matches_oracle(cin, cout, B, T, cfg, monkeypatch):
+def test_pointwise_gemm_every_configuration_matches_oracle(cin, cout, B, T, cfg, monkeypatch, request):
     """Linear -> (+bias) [-> +residual] [-> GELU] of the ConvNeXt block (convnext.py:130-141).  cfg = forced kernel
     configuration (FV_PW), None = the host's own choice (which may be the general conv kernel for tiny launches)."""
     from vocoder_amd import _lib
@@ -205,6 +214,8 @@ def test_pointwise_gemm_every_configuration_matches_oracle(cin, cout, B, T, cfg,
         monkeypatch.delenv("FV_PW", raising=False)
     else:
         monkeypatch.setenv("FV_PW", cfg)
+    _lib.reload_env()                       # the library caches its knobs: re-read now ...
+    request.addfinalizer(_reload_env_later)  # ... and again once monkeypatch has restored the environment
     rng = np.random.default_rng(cin + 3 * cout + B + T)
     x = rng.normal(size=(B, cin, T)).astype(np.float32)
     w = (rng.normal(size=(cout, cin, 1)) / np.sqrt(cin)).astype(np.float32)
@@ -234,11 +245,13 @@ def test_fast_gelu_of_the_pointwise_gemm_against_the_exact_function():
     w = np.eye(cin, dtype=np.float32)[:, :, None]
     import os
     os.environ["FV_PW"] = "1"
+    _lib.reload_env()
     try:
         y = _run(w, np.zeros(cin, np.float32), x, post_act=_lib.FV_ACT_GELU)
         assert _lib.last_kernel().startswith("gemm_pw<"), _lib.last_kernel()
     finally:
         del os.environ["FV_PW"]
+        _lib.reload_env()
     x64 = x.astype(np.float64)
     erf = np.vectorize(math.erf)
     exact = 0.5 * x64 * (1.0 + erf(x64 / math.sqrt(2.0)))

@@ -32,7 +32,7 @@ EXPORTS = (
     "fv_conv_forward", "fv_conv_destroy", "fv_last_error", "fv_abi_version", "fv_last_kernel",
     "fv_profile_begin", "fv_profile_end", "fv_conv_pair_forward", "fv_forward_template",
     "fv_set_precision", "fv_conv_set_precision", "fv_refinegan_noise_elems", "fv_forward_refinegan",
-    "fv_set_graph_replay",
+    "fv_set_graph_replay", "fv_reload_env",
 )
 
 _i32 = ctypes.c_int32
@@ -139,6 +139,8 @@ def lib() -> ctypes.CDLL:
     L.fv_conv_pair_forward.restype = _i32
     L.fv_set_precision.argtypes = [vp, _i32]
     L.fv_set_precision.restype = _i32
+    L.fv_reload_env.argtypes = []
+    L.fv_reload_env.restype = None
     L.fv_set_graph_replay.argtypes = [vp, _i32]
     L.fv_set_graph_replay.restype = _i32
     L.fv_conv_set_precision.argtypes = [vp, _i32]
@@ -167,6 +169,11 @@ class FishVocError(RuntimeError):
 def check(status: int) -> None:
     if status != 0:
         raise FishVocError(status, lib().fv_last_error().decode("utf-8", "replace"))
+
+
+def reload_env() -> None:
+    """Re-read the experiment knobs (FV_PW ...) that the library caches at first use (fv_reload_env)."""
+    lib().fv_reload_env()
 
 
 def last_kernel() -> str:

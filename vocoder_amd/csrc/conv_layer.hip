@@ -268,11 +268,7 @@ static int choose_gemm_pw(const ConvLayer& L, const ConvRun& r, long long tout) 
     const long long bytes = 4LL * r.batch * std::max<long long>((long long)L.c_in * r.t_in, (long long)L.c_out * tout);
     if (bytes >= 0xFFFFFF00LL || L.c_in < 64) return -1;   // (>= 8 chunks: the operand ring is primed unconditionally)
     if (num_cus() < 8) return -1;   // a partition below one CU per XCD (or a failed query): the persistent grid would be empty
-    static const char* const force = std::getenv("FV_PW");   // experiments: force a configuration, or "old" / -1 for the conv kernel
-    if (force) {
-        const int n = std::atoi(force);
-        return (force[0] == 'o' || n < 0 || n >= GEMM_PW_COUNT) ? -1 : n;
-    }
+    if (knobs().pw != -2) return knobs().pw;   // experiments (FV_PW): force a configuration, or "old" / -1 for the conv kernel
     const long long simds = (long long)(num_cus() / 8 * 8) * 4;
     const long long n64 = ((long long)tout * r.batch + 63) / 64;
     struct Cand { int cfg, mt, w; double pref; };
@@ -307,8 +303,7 @@ static int choose_gemm_pw_xcd_rows(const ConvLayer& L, const ConvRun& r, long lo
     const int mtiles = (L.M + 32 * mt - 1) / (32 * mt);
     const double a_bytes = 4.0 * L.c_in * L.c_out, b_bytes = 4.0 * L.c_in * (double)tout * r.batch;
     int px = b_bytes < 10.0 * a_bytes ? 4 : 1;
-    static const char* const force_px = std::getenv("FV_PW_PX");   // experiments
-    if (force_px) px = std::atoi(force_px);
+    if (knobs().pw_px) px = knobs().pw_px;   // experiments (FV_PW_PX)
     if (px != 1 && px != 2 && px != 4 && px != 8) px = 1;
     while (px > 1 && mtiles % px != 0) px /= 2;
     return px;

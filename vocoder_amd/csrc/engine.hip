@@ -53,6 +53,26 @@ bool ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long* done_
     if (dev >= 0 && dev < 64) __atomic_fetch_or(done_mask, 1ull << dev, __ATOMIC_RELEASE);   // devices >= 64: set every time
     return true;
 }
+static Knobs g_knobs;
+static bool g_knobs_loaded = false;
+static void load_knobs() {
+    Knobs k;
+    if (const char* v = std::getenv("FV_PW")) {
+        const int n = std::atoi(v);
+        k.pw = (v[0] == 'o' || n < 0 || n >= GEMM_PW_COUNT) ? -1 : n;
+    }
+    if (const char* v = std::getenv("FV_PW_PX")) k.pw_px = std::atoi(v);
+    k.dwln_ng8 = std::getenv("FV_DWLN_NG8") != nullptr;
+    k.dwln_rr = std::getenv("FV_DWLN_RR") != nullptr;
+    k.old_dwln = std::getenv("FV_OLD_DWLN") != nullptr;
+    g_knobs = k;
+    g_knobs_loaded = true;
+}
+const Knobs& knobs() {
+    if (!g_knobs_loaded) load_knobs();
+    return g_knobs;
+}
+
 int num_cus() {
     static thread_local int cached_dev = -1, cached = 0;
     int dev = 0;
@@ -1964,6 +1984,7 @@ FV_API void fv_conv_destroy(fv_conv* c) {
     delete c;
 }
 
+FV_API void fv_reload_env(void) { fv::load_knobs(); }
 FV_API const char* fv_last_error(void) { return g_err.c_str(); }
 FV_API int32_t fv_abi_version(void) { return FV_ABI_VERSION; }
 FV_API const char* fv_last_kernel(void) { return g_kernel.c_str(); }

@@ -20,6 +20,14 @@ void set_error(const char* fmt, ...);
 void set_last_kernel(const char* name);
 int num_cus();   // compute units of the current device (cached)
 
+// Experiment knobs, read from the environment once per process (fv_reload_env() re-reads them): the launch path never calls getenv
+struct Knobs {
+    int pw = -2;          // FV_PW: forced gemm_pw configuration, -1 = "old" (the conv kernel), -2 = unset
+    int pw_px = 0;        // FV_PW_PX: forced XCD row groups, 0 = unset
+    bool dwln_ng8 = false, dwln_rr = false, old_dwln = false;   // FV_DWLN_NG8 / FV_DWLN_RR / FV_OLD_DWLN
+};
+const Knobs& knobs();
+
 // Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  Register-resident operand
 // rings need every index to be a constant expression in the source (an index that only becomes constant after loop unrolling
 // can leave the array in scratch memory: the optimiser promotes arrays to registers before it unrolls).

@@ -608,8 +608,8 @@ static bool launch_dwconv_ln_tile(const float* x, const float* dw_w, const float
                                   float* y, int B, int C, int T, float eps, hipStream_t s) {
     const int n_tiles = (T + DWT_TT - 1) / DWT_TT;
     const dim3 grid((B * n_tiles + 7) / 8 * 8);   // whole groups of 8: see the XCD mapping in the kernel
-    static const bool wide = getenv("FV_DWLN_NG8") == nullptr;   // 16 channel groups (512 threads) for C > 256
-    static const int xcd_map = getenv("FV_DWLN_RR") == nullptr;   // experiments: round-robin tiles (the old mapping)
+    const bool wide = !knobs().dwln_ng8;   // 16 channel groups (512 threads) for C > 256
+    const int xcd_map = !knobs().dwln_rr;   // experiments: round-robin tiles (the old mapping)
     if (C <= 256) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 256, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles, B, xcd_map);
     else if (C <= 512 && wide) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512, 16>), grid, dim3(512), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles, B, xcd_map);
     else if (C <= 512) hipLaunchKernelGGL((dwconv_ln_tile_kernel<K, 512, 8>), grid, dim3(256), 0, s, x, dw_w, dw_b, ln_w, ln_b, y, C, T, eps, n_tiles, B, xcd_map);
@@ -622,8 +622,7 @@ static bool launch_dwconv_ln_tile(const float* x, const float* dw_w, const float
 fv_status launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                            float* y, int B, int C, int T, int k, float eps, hipStream_t s) {
     // per-item tensors below 1 GiB: 32-bit buffer offsets
-    static const bool old_dwln = getenv("FV_OLD_DWLN") != nullptr;   // experiments
-    if ((long long)C * T < (1LL << 28) && !old_dwln) {
+    if ((long long)C * T < (1LL << 28) && !knobs().old_dwln) {
         bool done = false;
         if (!dw_w) done = launch_dwconv_ln_tile<1>(x, nullptr, nullptr, ln_w, ln_b, y, B, C, T, eps, s);
         else if (k == 7) done = launch_dwconv_ln_tile<7>(x, dw_w, dw_b, ln_w, ln_b, y, B, C, T, eps, s);
