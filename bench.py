@@ -111,7 +111,7 @@ def init_dist(dev):
     return dist
 
 
-def dry_run(a, world, rank, local_rank) -> None:
+def dry_run(a, world, rank, local_rank, real_stdout) -> None:
     from vocoder_amd.sharding import gather_batch, scatter_batch, shard_sizes
     use_gpu = torch.cuda.is_available()
     if use_gpu:
@@ -142,7 +142,7 @@ def dry_run(a, world, rank, local_rank) -> None:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": ranks, "backend": "nccl" if use_gpu else "gloo",
-                          "scatter_gather_ok": bool(ok), "note": "plumbing only: no engine, nothing measured"}))
+                          "scatter_gather_ok": bool(ok), "note": "plumbing only: no engine, nothing measured"}), file=real_stdout, flush=True)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -365,13 +365,25 @@ def other_configs(dev, steps, warmup) -> list[dict]:
 def main():
     a = parse()
     maybe_self_launch(a)
+    # stdout carries exactly ONE line, the JSON: native libraries write banners to fd 1 through their own stdio buffers (RCCL prints
+    # its version block when the process group comes up, flushed at exit, i.e. AFTER the line) — everything else goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    try:
+        _main(a, real_stdout)
+    finally:
+        real_stdout.flush()
+
+
+def _main(a, real_stdout):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.dry_run:
-        dry_run(a, world, rank, local_rank)
+        dry_run(a, world, rank, local_rank, real_stdout)
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
@@ -579,7 +591,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), file=real_stdout, flush=True)
 
 
 if __name__ == "__main__":

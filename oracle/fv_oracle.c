@@ -85,6 +85,7 @@ typedef float v8f __attribute__((vector_size(32)));
 #define COB 4
 #define TVB 3
 #define TBLK (TVB * 8)
+#define TSB 21   /* time blocks per L2-resident super-block (504 samples) */
 
 static inline v8f ld8(const float* p) {
     v8f v;
@@ -147,13 +148,19 @@ FVO_API void fvo_conv1d(const float* x, const float* w, const float* bias, float
                         memcpy(xp + ((int64_t)b * Cin + ci) * Tp + (pad > 0 ? pad : 0), x + ((int64_t)b * Cin + ci) * T + lo,
                                (size_t)(T - lo) * sizeof(float));
                 }
+            /* loop order: a super-block of TSB time blocks (all Cin rows of it: <= 0.5 MB at Cin = 256) stays in the core's L2 while
+             * every output-channel block sweeps over it, so x is streamed from memory once per conv, not Cout / COB times */
             const int n_cb = (Cout + COB - 1) / COB;
+            const int n_tsb = (n_tb + TSB - 1) / TSB;
 #pragma omp parallel for collapse(3) schedule(static)
             for (int b = 0; b < B; ++b)
-                for (int cb = 0; cb < n_cb; ++cb)
-                    for (int tb = 0; tb < n_tb; ++tb)
-                        conv_block(xp + (int64_t)b * Cin * Tp, Tp, w, bias, y + (int64_t)b * Cout * Tout, Cin, Cout, Tout, k, dil,
-                                   cb * COB, tb * TBLK);
+                for (int tsb = 0; tsb < n_tsb; ++tsb)
+                    for (int cb = 0; cb < n_cb; ++cb) {
+                        const int tb1 = (tsb + 1) * TSB < n_tb ? (tsb + 1) * TSB : n_tb;
+                        for (int tb = tsb * TSB; tb < tb1; ++tb)
+                            conv_block(xp + (int64_t)b * Cin * Tp, Tp, w, bias, y + (int64_t)b * Cout * Tout, Cin, Cout, Tout, k, dil,
+                                       cb * COB, tb * TBLK);
+                    }
             free(xp);
             return;
         }
