@@ -218,6 +218,7 @@ struct PairParams {
     float out_scale;
 };
 bool pair_supported(int C, int ks, int dil);
+
 bool pair_f16x3_supported(const ConvLayer& c1, const ConvLayer& c2);   // wide SiLU pairs of the f16x3 precision mode
 bool launch_resblock_pair(const PairParams& p, int C, int ks, int dil, int batch, hipStream_t s);
 fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x, float* y, int batch, int t, int out_mode,

@@ -217,6 +217,27 @@ __device__ __forceinline__ f32x2 sin_squared2(f32x2 z) {
     return sn * sn;
 }
 
+// Snake on a sample pair: a = u + inv_beta * sin(alpha u)^2 = (u + hb) - hb * cos(2 alpha u), hb = inv_beta / 2, with the hardware cosine
+// (v_cos_f32 takes revolutions: cos(2 pi x), x = u * alpha / pi, reduced by v_fract_f32 — the instruction's own domain is |x| <= 256).
+// Seven instructions per pair instead of the polynomial's sixteen: what this kernel costs is its VALU INSTRUCTION COUNT — beside
+// the fp32 MFMAs of the conv kernels that share the SIMDs (other ResBlock branches) every VALU instruction, plain, packed or
+// transcendental, takes ~12 - 20 cycles out of the matrix stream (tools/ubench/mfma_mix.hip).  Accuracy against sin^2 in double
+// (same ubench): 3.8e-7 for |alpha u| <= 5, 3.1e-6 up to 40 (the fp32 rounding of the argument; the polynomial: 2.9e-7 / 3.2e-7);
+// FV_X_SNAKE_POLY builds the polynomial back in.
+__device__ __forceinline__ f32x2 snake2(f32x2 u, float al, float ib, float al_pi, float hb) {
+#ifdef FV_X_SNAKE_POLY
+    (void)al_pi; (void)hb;
+    return __builtin_elementwise_fma((f32x2)(ib), sin_squared2(u * al), u);
+#else
+    (void)al; (void)ib;
+    const f32x2 ph = u * al_pi;
+    f32x2 c;
+    c.x = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ph.x));
+    c.y = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ph.y));
+    return __builtin_elementwise_fma(c, (f32x2)(-hb), u + hb);
+#endif
+}
+
 // EDGE = false: the tile and its 6-sample halo lie inside [0, T) — no clamps, no bounds tests, fixed trip counts (the
 // clamp / compare / loop-carried VALU work was about a quarter of the kernel's instructions).  Same arithmetic order either way.
 template <bool EDGE>
@@ -224,6 +245,7 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
                                               float* __restrict__ A, const float* __restrict__ up_taps,
                                               const float* __restrict__ down_taps, float al, float ib, int t0, int T) {
     const int tid = threadIdx.x;
+    const float al_pi = al * 0.318309886183790672f, hb = 0.5f * ib;
     auto load_x = [&](int e) {
         int t = t0 - 6 + e;
         if (EDGE) t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);   // replicate padding of the up-sampler input
@@ -253,7 +275,7 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
             const f32x2 xp = {xs[xi + 2 - q], xs[xi + 3 - q]};
             u = __builtin_elementwise_fma(upp[q], xp, u);
         }
-        f32x2 a = __builtin_elementwise_fma((f32x2)(ib), sin_squared2(u * al), u);
+        f32x2 a = snake2(u, al, ib, al_pi, hb);
         if (EDGE) {   // replicate padding of the down-sampler input: n < 0 -> a[0] (even sample of h = 0), n > 2T-1 -> a[2T-1]
             if (h < 0) a.y = a.x;
             if (h > T - 1) a.x = a.y;
