@@ -54,7 +54,8 @@ def bench_key(label: str):
 
 
 def collect(d, counter):
-    path = max(glob.glob(os.path.join(d, "*counter_collection.csv")), key=os.path.getmtime)   # newest pass in the directory
+    # newest pass in the directory (rocprofv3 nests its output one level down, under the host name)
+    path = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:

@@ -216,6 +216,7 @@ struct PairParams {
     int T, n_tiles;
     int out_mode;
     float out_scale;
+    int batch;            // items in the launch (the kernels map workgroups to (item, tile) themselves)
 };
 bool pair_supported(int C, int ks, int dil);
 

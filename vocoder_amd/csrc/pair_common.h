@@ -10,14 +10,15 @@ typedef float f32x4p __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
+// (TT, XS, Xr: optional second destination, see below)
 // As[r][col] = silu(x[r][t0 - HP + col]) for r < C, col < WA_RAW (0 outside [0, T): silu(0) = 0 is the conv's zero padding).
 // Each wave stages C/4 whole rows: per element one buffer load (row descriptor in SGPRs, column offset in a VGPR, out-of-
 // range columns come back as 0 from the hardware bounds check), silu, one ds_write — the PMC profile of the first version
 // showed the kernel bound by VALU issue (1400 VALU vs 96 MFMA instructions per wave), most of it index / clamp / 64-bit
 // address arithmetic around these loads.
-template <int C, int WA_RAW, int WA, int HP>
+template <int C, int WA_RAW, int WA, int HP, int TT = 0, int XS = 0>
 __device__ __forceinline__ void stage_window(const float* __restrict__ xb, float* __restrict__ As, int wave, int lane, int t0,
-                                             int T) {
+                                             int T, float* __restrict__ Xr = nullptr) {
     constexpr int ROWS = C / 4;                  // rows per wave
     constexpr int NI = (WA_RAW + 63) / 64;       // columns per lane
     float v[ROWS][NI];
@@ -35,6 +36,11 @@ __device__ __forceinline__ void stage_window(const float* __restrict__ xb, float
         for (int i = 0; i < NI; ++i) {
             const int col = lane + 64 * i;
             if (col < WA_RAW) As[(wave * ROWS + rr) * WA + col] = silu_f(v[rr][i]);
+            // the raw centre columns [HP, HP + TT) — the residual operand of the final epilogue — stay in LDS as well: x is read from
+            // HBM once per tile (round 2 fetched it again in the epilogue: 1.6 - 2.7x the algorithmic traffic, profiles/traffic.json)
+            if constexpr (TT > 0) {
+                if (col >= HP && col < HP + TT) Xr[(wave * ROWS + rr) * XS + col - HP] = v[rr][i];
+            }
         }
 }
 

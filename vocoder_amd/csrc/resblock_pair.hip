@@ -34,7 +34,9 @@ struct PairGeom {
     static constexpr int WA = (WA_RAW - 16 + 31) / 32 * 32 + 16;
     static constexpr int WB = (WB_RAW - 16 + 31) / 32 * 32 + 16;
     // the intermediate overlays the input window (one extra barrier): half the LDS, up to 8 workgroups per CU (-4 %)
-    static constexpr int LDS_FLOATS = C * (WA > WB ? WA : WB);
+    static constexpr int AB_FLOATS = C * (WA > WB ? WA : WB);
+    static constexpr int XS = TT;                       // row stride of the raw centre tile kept for the residual
+    static constexpr int LDS_FLOATS = AB_FLOATS + C * XS;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -49,16 +51,23 @@ __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair32_kernel(con
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;
     float* Bs = lds;   // overlays As once every wave has finished c1
+    float* Xr = lds + G::AB_FLOATS;   // raw x[:, t0 : t0 + TT): the residual operand
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x % p.n_tiles, b = blockIdx.x / p.n_tiles;
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it).  Neighbouring tiles of a clip share their
+    // halo columns (up to 30 per side on 118 - 246 produced): handing them to the SAME XCD lets its L2 serve those lines once —
+    // dealt round-robin, each XCD fetched them from HBM for itself.  Logical id = (b % 8) * (grid / 8) + b / 8 (grid rounded up
+    // to a multiple of 8 by the host; surplus workgroups leave).
+    const int lid = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (lid >= p.n_tiles * p.batch) return;
+    const int tile = lid % p.n_tiles, b = lid / p.n_tiles;
     const int t0 = tile * G::TT;
     const float* __restrict__ xb = p.x + (long long)b * C * p.T;
 
     // phase 1: A = silu(x) window.  Loads are unconditional on clamped addresses and issued in batches of 8 so that
     // their latencies overlap (a guarded load per element compiles to a branch + vmcnt(0) each).
-    stage_window<C, G::WA_RAW, G::WA, G::HP>(xb, As, wave, lane, t0, p.T);
+    stage_window<C, G::WA_RAW, G::WA, G::HP, G::TT, G::XS>(xb, As, wave, lane, t0, p.T, Xr);
     __syncthreads();
 
     const int ncol = wave * (NT * 32) + (lane & 31);
@@ -102,24 +111,13 @@ __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair32_kernel(con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         gemm32_resident<KS, G::WB, 1, MT, NT, NCH>(p.w2, lane, Bs + krow * G::WB + ncol, acc);
-        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb, (unsigned)(C * p.T) * 4u);
         const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * C * p.T, (unsigned)(C * p.T) * 4u);
-        // residual operands of the whole register tile first, then combine and store: one HBM round trip instead of one per
-        // accumulator row (the loads of row r + 1 could not start before the stores of row r were issued)
         auto off = [&](int i, int r, int jn) -> unsigned {   // byte offset inside this batch item, or 0xFFFFFFFF (masked)
             const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
             const int n = ncol + jn * 32;
             const int t = t0 + n;
             return (n < G::TT && t < p.T) ? (unsigned)(m * p.T + t) * 4u : 0xFFFFFFFFu;
         };
-        float xr[MT][16][NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int jn = 0; jn < NT; ++jn)
-                    xr[i][r][jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off(i, r, jn), 0, 0));
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -133,7 +131,9 @@ __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair32_kernel(con
                 }
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) {
-                    float v = acc[i][jn][r] + bias + xr[i][r][jn];
+                    const int n = ncol + jn * 32;
+                    // residual from the raw tile in LDS (columns past TT belong to the next tile: masked by off(), any finite address)
+                    float v = acc[i][jn][r] + bias + Xr[m * G::XS + (n < G::TT ? n : 0)];
                     if (p.out_mode == OUT_ACCUM) v = (yo[jn] + v) * p.out_scale;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, off(i, r, jn), 0, 0);
                 }
@@ -153,14 +153,17 @@ __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair16_kernel(con
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;
     float* Bs = lds;   // overlays As once every wave has finished c1
+    float* Xr = lds + G::AB_FLOATS;   // raw x[:, t0 : t0 + TT): the residual operand (see resblock_pair32_kernel)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x % p.n_tiles, b = blockIdx.x / p.n_tiles;
+    const int lid = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);   // a clip's tiles on one XCD
+    if (lid >= p.n_tiles * p.batch) return;
+    const int tile = lid % p.n_tiles, b = lid / p.n_tiles;
     const int t0 = tile * G::TT;
     const float* __restrict__ xb = p.x + (long long)b * C * p.T;
 
-    stage_window<C, G::WA_RAW, G::WA, G::HP>(xb, As, wave, lane, t0, p.T);
+    stage_window<C, G::WA_RAW, G::WA, G::HP, G::TT, G::XS>(xb, As, wave, lane, t0, p.T, Xr);
     __syncthreads();
 
     const int ncol = wave * (NT * 16) + (lane & 15);
@@ -191,18 +194,12 @@ __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair16_kernel(con
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         gemm16_resident<KS, G::WB, 1, NT>(p.w2, lane, Bs + krow * G::WB + ncol, acc);
-        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb, (unsigned)(C * p.T) * 4u);
         const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * C * p.T, (unsigned)(C * p.T) * 4u);
         auto off = [&](int r, int jn) -> unsigned {   // byte offset inside this batch item, 0xFFFFFFFF = masked
             const int n = ncol + jn * 16;
             const int t = t0 + n;
             return (n < G::TT && t < p.T) ? (unsigned)((4 * krow + r) * p.T + t) * 4u : 0xFFFFFFFFu;
         };
-        float xr[4][NT];   // the whole tile's residual operands in one round trip (see resblock_pair32_kernel)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int jn = 0; jn < NT; ++jn) xr[r][jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off(r, jn), 0, 0));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float bias = p.b2[4 * krow + r];
@@ -213,7 +210,8 @@ __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair16_kernel(con
             }
 #pragma unroll
             for (int jn = 0; jn < NT; ++jn) {
-                float v = acc[jn][r] + bias + xr[r][jn];
+                const int n = ncol + jn * 16;
+                float v = acc[jn][r] + bias + Xr[(4 * krow + r) * G::XS + (n < G::TT ? n : 0)];   // residual from the raw tile in LDS
                 if (p.out_mode == OUT_ACCUM) v = (yo[jn] + v) * p.out_scale;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, off(r, jn), 0, 0);
             }
@@ -229,7 +227,8 @@ static bool launch_pair_c(const PairParams& p, int C, int batch, hipStream_t s) 
         q.n_tiles = (p.T + G::TT - 1) / G::TT;
         const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
         if (!FV_ENSURE_DYN_LDS((resblock_pair16_kernel<KS, DIL>), lds)) return false;
-        hipLaunchKernelGGL((resblock_pair16_kernel<KS, DIL>), dim3(batch * q.n_tiles), dim3(256), lds, s, q);
+        q.batch = batch;
+        hipLaunchKernelGGL((resblock_pair16_kernel<KS, DIL>), dim3((batch * q.n_tiles + 7) / 8 * 8), dim3(256), lds, s, q);
         return true;
     }
     if (C == 32) {
@@ -238,7 +237,8 @@ static bool launch_pair_c(const PairParams& p, int C, int batch, hipStream_t s) 
         q.n_tiles = (p.T + G::TT - 1) / G::TT;
         const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
         if (!FV_ENSURE_DYN_LDS((resblock_pair32_kernel<KS, DIL, 32>), lds)) return false;
-        hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 32>), dim3(batch * q.n_tiles), dim3(256), lds, s, q);
+        q.batch = batch;
+        hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 32>), dim3((batch * q.n_tiles + 7) / 8 * 8), dim3(256), lds, s, q);
         return true;
     }
     if (C == 64) {
@@ -247,7 +247,8 @@ static bool launch_pair_c(const PairParams& p, int C, int batch, hipStream_t s) 
         q.n_tiles = (p.T + G::TT - 1) / G::TT;
         const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
         if (!FV_ENSURE_DYN_LDS((resblock_pair32_kernel<KS, DIL, 64>), lds)) return false;
-        hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 64>), dim3(batch * q.n_tiles), dim3(256), lds, s, q);
+        q.batch = batch;
+        hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 64>), dim3((batch * q.n_tiles + 7) / 8 * 8), dim3(256), lds, s, q);
         return true;
     }
     return false;
