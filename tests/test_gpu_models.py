@@ -866,3 +866,35 @@ def test_bench_runs_its_collectives_on_a_one_rank_rccl_group():
         assert c["backend"] == "rccl" and c["collected_finite"] and c["rank0_shard_equals_direct_forward"], c
         assert c["collected_shape"] == [32, 1, 44032] and c["all_gather_bytes_per_step"] == 32 * 44032 * 4
         assert j["output_finite"] and j["ms_per_step_eager"] > 0 and j["mixed_shapes"]["output_finite"]
+
+
+@pytest.mark.parametrize("maxk", ["3", "11"])
+def test_bigvgan_fused_amp_convs_equal_the_activation_plus_conv_launches(maxk, monkeypatch):
+    """amp_conv.hip (AMPBlock conv with its anti-aliased SnakeBeta fused in front, bigvgan.py:235-245) against the aa_snake + conv
+    launches it replaces: the same arithmetic in the same order, so full-size tiles agree bit for bit; every kernel size (the
+    default fuses k = 3 only), sequence ends inside a tile (replicate padding of both FIRs, zero padding of the conv), ragged T;
+    and both against the CPU oracle."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, upsampler_config
+    cfg = dict(syn.BIGVGAN_24K)
+    sd = syn.bigvgan_state_dict(cfg, 3)
+    monkeypatch.setenv("FV_AMP_MAXK", maxk)
+    fused = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=sd)
+    monkeypatch.setenv("FV_NO_AMP_FUSION", "1")
+    plain = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=sd)
+    monkeypatch.delenv("FV_NO_AMP_FUSION")
+    x = torch.from_numpy(syn.synthetic_mel(40, 80, 31, seed=8)).to(_dev())     # enough columns for the tiled conv kernels
+    ya, yb = fused(x), plain(x)
+    torch.cuda.synchronize()
+    prof = fused.profile(x, repeats=1)
+    assert any(r["kernel"].startswith("amp_conv<k=3") for r in prof)
+    assert any(r["kernel"].startswith("amp_conv<k=11") for r in prof) == (maxk == "11")
+    assert torch.equal(ya, yb), float((ya - yb).abs().max())
+    for B, T in ((2, 7), (1, 1), (3, 19)):                                       # short clips: both sequence ends inside one tile
+        mel = syn.synthetic_mel(B, 80, T, seed=T)
+        ref = orc.bigvgan_forward(sd, cfg, mel)
+        for eng in (fused, plain):
+            err = np.abs(_fwd(eng, mel) - ref).max()
+            assert err <= TOL, (B, T, err)
+    fused.close()
+    plain.close()

@@ -34,3 +34,12 @@ if "--oracle" in sys.argv:
     ref = orc.bigvgan_forward(sd, cfg, m)
     y = eng(torch.from_numpy(m).cuda()).cpu().numpy()
     print(f"max|d| vs oracle on a (2, 80, 12) clip: {np.abs(y - ref).max():.3e} (waveform peak {np.abs(ref).max():.2f})")
+if "--identical" in sys.argv:   # fused amp_conv path against the aa_snake + conv launches (FV_NO_AMP_FUSION=1 engine): bit for bit
+    os.environ["FV_NO_AMP_FUSION"] = "1"
+    eng2 = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=sd)
+    del os.environ["FV_NO_AMP_FUSION"]
+    for B, T in ((64, 94), (3, 37), (1, 5)):
+        m = torch.from_numpy(syn.synthetic_mel(B, 80, T, seed=B + T)).cuda()
+        ya, yb = eng(m), eng2(m)
+        torch.cuda.synchronize()
+        print(f"B={B} T={T}: fused == unfused bit for bit: {bool(torch.equal(ya, yb))}  max|d| = {float((ya - yb).abs().max()):.2e}")

@@ -385,6 +385,12 @@ struct fv_engine {
     bool profiling = false;
     int precision = FV_PRECISION_F32;   // fv_set_precision
     bool fuse_pairs = true;   // FV_NO_PAIR_FUSION=1 in the environment disables the fused (c1, c2) kernels (A/B runs)
+    bool fuse_amp_convs = true;   // FV_NO_AMP_FUSION=1: BigVGAN's narrow stages run aa_snake + conv launches instead of amp_conv (A/B runs)
+    // Measured in the step (BigVGAN-24k B = 64, interleaved, tools/ab_bigvgan.py): none 37.35 ms; k = 3 only 37.15; k <= 7 37.5; all 38.1.
+    // Serialized, amp_conv equals conv + aa_snake within 5 % everywhere, but the separate activation pass is HBM-bound work that the
+    // other branches' MFMA-bound convs overlap, while the fused one is VALU work inside an MFMA kernel (12 - 20 cycles of matrix
+    // time per VALU instruction of a co-resident wave, tools/ubench/mfma_mix.hip) — so only the shortest convs fuse by default.
+    int fuse_amp_max_c = 64, fuse_amp_max_k = 3;   // FV_AMP_MAXC / FV_AMP_MAXK override (experiments, tests)
     struct GraphKey {
         const void* in;
         void* out;
@@ -874,6 +880,34 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 if ((st = after_last())) return st;
                 continue;
             }
+            // BigVGAN narrow stages (C = 32 / 64): each conv runs with its anti-aliased SnakeBeta fused in front (amp_conv.hip) —
+            // no activation launches, no activated tensors in HBM
+            bool fuse_amp = ups.bigvgan && fuse_amp_convs && !dbg_here && ch <= fuse_amp_max_c && br.k <= fuse_amp_max_k;
+            for (int n = 0; n < FV_MAX_DILATIONS && fuse_amp; ++n)
+                fuse_amp = br.c1[n].precision == FV_PRECISION_F32 && br.c2[n].precision == FV_PRECISION_F32 && br.c1[n].c_in == ch &&
+                           br.c1[n].c_out == ch && br.c2[n].c_in == ch && br.c2[n].c_out == ch && br.c1[n].k == br.k && br.c2[n].k == br.k &&
+                           amp_conv_supported(ch, br.k, br.c1[n].dil) && br.c2[n].dil == 1 &&
+                           br.c1[n].padding == (br.k - 1) / 2 * br.c1[n].dil && br.c2[n].padding == (br.k - 1) / 2 && (long long)ch * t < (1LL << 30);
+            if (fuse_amp) {
+                for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
+                    const float* src = n == 0 ? S : XB(bj);
+                    const bool last = n == FV_MAX_DILATIONS - 1;
+                    const AASnake &a1 = br.act[2 * n], &a2 = br.act[2 * n + 1];
+                    const double fl = 2.0 * ch * ch * br.k * (double)t * B, el = (double)B * ch * t * 4.0;
+                    char lbl[96];
+                    std::snprintf(lbl, sizeof(lbl), "amp_conv<k=%d d=%d C=%d>", br.k, br.c1[n].dil, ch);
+                    FV_PROF(bs, lbl, fl + 60.0 * B * ch * t, 2.0 * el,
+                            (launch_amp_conv(br.c1[n], src, XT(bj), nullptr, a1.d_alpha, a1.d_inv_beta, a1.d_up, a1.d_down, B, t, OUT_SET,
+                                             1.0f, bs) ? FV_OK : FV_ERR_HIP));
+                    if (last && (st = before_last())) return st;
+                    std::snprintf(lbl, sizeof(lbl), "amp_conv<k=%d d=1 C=%d>+res", br.k, ch);
+                    FV_PROF(bs, lbl, fl + 60.0 * B * ch * t, (last && mode_last == OUT_ACCUM ? 4.0 : 3.0) * el,
+                            (launch_amp_conv(br.c2[n], XT(bj), last ? y_last : XB(bj), src, a2.d_alpha, a2.d_inv_beta, a2.d_up, a2.d_down, B, t,
+                                             last ? mode_last : OUT_SET, last ? scale_last : 1.0f, bs) ? FV_OK : FV_ERR_HIP));
+                }
+                if ((st = after_last())) return st;
+                continue;
+            }
             for (int n = 0; n < FV_MAX_DILATIONS; ++n) {
                 if (dbg_here && n > dbg_pair) break;
                 const float* src = n == 0 ? S : XB(bj);
@@ -1285,6 +1319,9 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
     }
     e->cfg = *cfg;
     if (const char* v = std::getenv("FV_NO_PAIR_FUSION")) e->fuse_pairs = !(v[0] == '1');
+    if (const char* v = std::getenv("FV_NO_AMP_FUSION")) e->fuse_amp_convs = !(v[0] == '1');
+    if (const char* v = std::getenv("FV_AMP_MAXC")) e->fuse_amp_max_c = std::atoi(v);
+    if (const char* v = std::getenv("FV_AMP_MAXK")) e->fuse_amp_max_k = std::atoi(v);
     if (const char* v = std::getenv("FV_SINGLE_STREAM")) e->branch_streams = !(v[0] == '1');
     if (const char* v = std::getenv("FV_NO_GRAPH")) e->use_graph = !(v[0] == '1');
     if (std::getenv("FV_DEBUG_STOP")) e->use_graph = false;   // the early return leaves forked branch streams unjoined: not capturable

@@ -225,6 +225,12 @@ bool launch_resblock_pair(const PairParams& p, int C, int ks, int dil, int batch
 fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x, float* y, int batch, int t, int out_mode,
                         float out_scale, hipStream_t stream);
 
+// BigVGAN AMPBlock conv with its anti-aliased SnakeBeta fused in front (amp_conv.hip): y = conv(Activation1d(x)) + bias [+ res]
+// for C_in = C_out in {32, 64}, k in {3, 7, 11}, 'same' padding; alpha / inv_beta / taps as for launch_aa_snake
+bool amp_conv_supported(int C, int ks, int dil);
+bool launch_amp_conv(const ConvLayer& L, const float* x, float* y, const float* res, const float* alpha, const float* inv_beta,
+                     const float* up_taps, const float* down_taps, int batch, int t, int out_mode, float out_scale, hipStream_t s);
+
 // Tile configurations (block = 4 waves): rows = WM*MT*32, cols = WN*NT*32.
 enum TileCfg : int { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2, TILE_128x64 = 3, TILE_32x128 = 4, TILE_64x128 = 5, TILE_SPLITK_32x64 = 6, TILE_SPLITK_32x32 = 7, TILE_256x64 = 8, TILE_256x32 = 9, TILE_COUNT };
 void tile_dims(int cfg, int* m_blk, int* n_blk);
