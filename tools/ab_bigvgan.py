@@ -27,6 +27,8 @@ for r in range(rounds):
 tab = eng.profile(mel, repeats=2)
 tot = sum(x["total_ms"] for x in tab) / 2
 aa = sum(x["total_ms"] for x in tab if x["kernel"].startswith("aa_snake")) / 2
+import hashlib
+print("output sha1 of the B = 64 step:", hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:16])
 print(f"serialized kernel sum {tot:.2f} ms, aa_snake {aa:.2f} ms ({os.environ.get('FV_LIB_PATH', 'shipped library')})")
 if "--oracle" in sys.argv:
     from oracle import oracle as orc

@@ -304,29 +304,110 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
     }
 }
 
+// Interior tiles, four positions per thread (round 3).  The pair kernel above is LDS-bound: per 64 positions it spends 12
+// ds_read2_b32 + 3 ds_write_b32 = 60 LDS cycles (128 B / clk) against ~28 cycles of VALU issue per CU (PMC round 2: LDS 76 % busy).
+// Here a thread owns positions 4j .. 4j + 3 and moves everything as 16-byte accesses, the 256 B / clk forms: the x window
+// x[4j - 2 .. 4j + 9] is three ds_read_b128, the (even, odd) samples leave as two ds_write_b128 and come back for the low-pass as
+// six ds_read_b128, rows enter and leave as dwordx4.  The FIRs run as scalar-tap v_fma_f32 in the SAME order as the packed
+// ones above (two independent accumulator chains per position), so results are bit-identical.  Needs T % 4 == 0 and 16-byte
+// aligned rows (host); xs[8 + i] = x[t0 + i], E / O[m] = samples of position h = t0 - 3 + m.
+__device__ __forceinline__ void aa_snake4_tile(const float* __restrict__ xr, float* __restrict__ yr, float* __restrict__ xs,
+                                               float* __restrict__ E, float* __restrict__ O, const float* __restrict__ up_taps,
+                                               const float* __restrict__ down_taps, float al, float ib, int t0) {
+    const int tid = threadIdx.x;
+    const float al_pi = al * 0.318309886183790672f, hb = 0.5f * ib;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    // rows: 1024 centre samples as one dwordx4 per thread, 6 + 7 halo samples by the first lanes
+    *reinterpret_cast<f4*>(xs + 8 + 4 * tid) = *reinterpret_cast<const f4*>(xr + t0 + 4 * tid);
+    if (tid < 6) xs[2 + tid] = xr[t0 - 6 + tid];
+    if (tid >= 64 && tid < 71) xs[8 + AA_TT + tid - 64] = xr[t0 + AA_TT + tid - 64];
+    float upe[6], upo[6], dne[6], dno[6];   // wave-uniform taps (SGPRs): even / odd phase of the up-sampler (gain 2 folded in), low-pass
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        upe[q] = 2.0f * up_taps[2 * q + 1];
+        upo[q] = 2.0f * up_taps[2 * q];
+        dno[q] = down_taps[2 * q];       // multiplies the odd sample of m = i + q
+        dne[q] = down_taps[2 * q + 1];   // multiplies the even sample of m = i + q + 1
+    }
+    __syncthreads();
+    auto up_group = [&](int j) {   // positions m = 4j .. 4j + 3: ue(m) = sum_q upe[q] xs[m + 7 - q], uo(m) = sum_q upo[q] xs[m + 8 - q]
+        float w[12];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const f4 t = *reinterpret_cast<const f4*>(xs + 4 * j + 4 * v);
+            w[4 * v] = t.x; w[4 * v + 1] = t.y; w[4 * v + 2] = t.z; w[4 * v + 3] = t.w;
+        }
+        f4 ev, od;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float ue = 0.f, uo = 0.f;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                ue = fmaf(upe[q], w[k + 7 - q], ue);
+                uo = fmaf(upo[q], w[k + 8 - q], uo);
+            }
+            const f32x2 a = snake2(f32x2{ue, uo}, al, ib, al_pi, hb);
+            ev[k] = a.x;
+            od[k] = a.y;
+        }
+        *reinterpret_cast<f4*>(E + 4 * j) = ev;
+        *reinterpret_cast<f4*>(O + 4 * j) = od;
+    };
+    up_group(tid);
+    if (tid < 2) up_group(256 + tid);   // positions 1024 .. 1031 (1024 .. 1029 are read below)
+    __syncthreads();
+    {   // outputs i = 4 tid .. 4 tid + 3: y = sum_q dno[q] O[i + q] + dne[q] E[i + q + 1]
+        float o[12], e[12];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const f4 a = *reinterpret_cast<const f4*>(O + 4 * tid + 4 * v);
+            const f4 b = *reinterpret_cast<const f4*>(E + 4 * tid + 4 * v);
+            o[4 * v] = a.x; o[4 * v + 1] = a.y; o[4 * v + 2] = a.z; o[4 * v + 3] = a.w;
+            e[4 * v] = b.x; e[4 * v + 1] = b.y; e[4 * v + 2] = b.z; e[4 * v + 3] = b.w;
+        }
+        f4 out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float sx = 0.f, sy = 0.f;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                sx = fmaf(dno[q], o[k + q], sx);
+                sy = fmaf(dne[q], e[k + q + 1], sy);
+            }
+            out[k] = sx + sy;
+        }
+        *reinterpret_cast<f4*>(yr + t0 + 4 * tid) = out;
+    }
+}
+
 __global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           const float* __restrict__ alpha_eff,
                                                           const float* __restrict__ inv_beta,
                                                           const float* __restrict__ up_taps,
-                                                          const float* __restrict__ down_taps, int C, int T, int n_tiles) {
-    __shared__ float xs[AA_TT + 16];
-    __shared__ __attribute__((aligned(8))) float A[2 * AA_ODD];
+                                                          const float* __restrict__ down_taps, int C, int T, int n_tiles,
+                                                          int vec4) {
+    __shared__ __attribute__((aligned(16))) float xs[AA_TT + 16];
+    __shared__ __attribute__((aligned(16))) float A[2 * AA_ODD];
     const int tile = blockIdx.x % n_tiles;
     const long long row = blockIdx.x / n_tiles;  // b * C + c
     const int c = (int)(row % C);
     const int t0 = tile * AA_TT;
     const float al = alpha_eff[c], ib = inv_beta[c];
-    if (t0 >= 6 && t0 + AA_TT + 6 < T)
-        aa_snake_tile<false>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T);
-    else
+    if (t0 >= 6 && t0 + AA_TT + 6 < T) {
+        if (vec4) aa_snake4_tile(x + row * T, y + row * T, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t0);
+        else aa_snake_tile<false>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T);
+    } else
         aa_snake_tile<true>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T);
 }
 
 fv_status launch_aa_snake(const float* x, float* y, const float* alpha_eff, const float* inv_beta, const float* up_taps,
                           const float* down_taps, int B, int C, int T, hipStream_t s) {
     const int n_tiles = (T + AA_TT - 1) / AA_TT;
+    // interior tiles move 16 bytes per lane when every row starts 16-byte aligned (aa_snake4_tile); FV_AA_VEC4=0: the pair form
+    static const bool no_vec4 = std::getenv("FV_AA_VEC4") && std::getenv("FV_AA_VEC4")[0] == '0';
+    const int vec4 = !no_vec4 && T % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
     hipLaunchKernelGGL(aa_snake_pk_kernel, dim3((unsigned)((long long)B * C * n_tiles)), dim3(256), 0, s, x, y, alpha_eff,
-                       inv_beta, up_taps, down_taps, C, T, n_tiles);
+                       inv_beta, up_taps, down_taps, C, T, n_tiles, vec4);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
 }
