@@ -148,6 +148,21 @@ def dry_run(a, world, rank, local_rank, real_stdout) -> None:
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ------------------------------------------------------------------------------------------------------------------
+def _cpu_quota() -> float | None:
+    """CPUs' worth of time the container's cgroup allows (cpu.max / cfs quota), None when unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2: "<quota|max> <period>"
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())          # cgroup v1
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def _cpu_model() -> str:
     try:
         for ln in open("/proc/cpuinfo"):
@@ -199,12 +214,16 @@ def cpu_baseline(cfg, sd, clips: int, frames: int) -> dict:
     Python and does not travel to the GPU box) on one-second clips, clip-parallel over the host's cores: one worker process
     per core in use, whole clips per worker, the convs serial inside a clip (oracle/cpu_clips.py)."""
     from oracle import oracle as orc
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    pool = _ClipWorkers(avail)
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = _cpu_quota()
+    # cores the process can actually run on at once: the affinity mask, capped by the container's CPU quota (the GPU box shows
+    # 256 hardware threads to a container that is allowed 16 CPUs' worth of time: more workers than that only time-share them)
+    avail = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    cands = sorted({n for n in (max(1, avail // 2), avail, min(affinity, 2 * avail)) if n >= 1})
+    pool = _ClipWorkers(max(cands))
     try:
-        # worker count: one clip per worker at a quarter, half and all of the usable cores (SMT siblings may not pay); best clips/s
+        # worker count: one clip per worker at half, all and twice the usable cores; best clips/s
         tried, best, best_rate = {}, 1, 0.0
-        cands = sorted({n for n in (avail // 4, avail // 2, avail) if n >= 1})
         for n in cands:
             dt, c, _ = pool.run(n, 1, frames, seed=7000)
             tried[n] = round(dt, 3)
@@ -228,15 +247,15 @@ def cpu_baseline(cfg, sd, clips: int, frames: int) -> dict:
         y = orc.hifigan_forward(sd, cfg, mel1)
         lat.append(time.perf_counter() - t1)
     n_samp = y.shape[-1]
-    return {"value": n_samples / dt, "unit": "samples/s", "cores": best, "kind": "port",
-            "host_cores": os.cpu_count(), "host_cores_usable": avail, "cpu_model": _cpu_model(),
-            "worker_probe_s": tried, "parallelism": "one process per core in use, whole clips per process, serial convs inside a clip",
+    return {"value": n_samples / dt, "unit": "samples/s", "cores": min(best, avail), "workers": best, "kind": "port",
+            "host_cores": os.cpu_count(), "host_cores_usable": avail, "cgroup_cpu_quota": quota, "cpu_model": _cpu_model(),
+            "worker_probe_s": tried, "parallelism": "one worker process per usable core, whole clips per process, serial convs inside a clip",
             "x_realtime": n_samples / dt / SAMPLE_RATE,
             "b1_clip_latency_ms": float(np.median(lat) * 1e3), "b1_x_realtime": n_samp / float(np.median(lat)) / SAMPLE_RATE,
             "b1_threads": b1_threads,
             "sample": f"{n_clips} x 1 s clips (T_mel={frames}) of the same HiFiGAN-V1-44k workload, {each} per worker, {dt:.2f} s wall "
-                      f"on {best} clip-parallel worker processes (best clips/s of a one-clip-per-worker probe at {cands} workers) of "
-                      f"{avail} usable cores; b1_* = one 1 s clip alone with {b1_threads} OpenMP threads inside its convs, median of 5"}
+                      f"on {best} clip-parallel worker processes (best clips/s of a one-clip-per-worker probe at {cands} workers) on "
+                      f"{avail} usable cores ({affinity} hardware threads visible, cgroup CPU quota {quota}); b1_* = one 1 s clip alone with {b1_threads} OpenMP threads inside its convs, median of 5"}
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -853,8 +853,12 @@ def test_bench_runs_its_collectives_on_a_one_rank_rccl_group():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-alt-precision"]
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     for launcher in (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-                      "--master-port", "29541"], []):
+                      "--master-port", str(port)], []):
         r = subprocess.run([sys.executable] + launcher + [os.path.join(repo, "bench.py")] + common, capture_output=True, text=True,
                            timeout=900, env=env, cwd=repo)
         assert r.returncode == 0, r.stderr[-3000:]
