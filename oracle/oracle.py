@@ -67,6 +67,17 @@ def lib():
         L.fvo_istft_head_post.argtypes = [_f, _f, _f, _i, _i, _i]
         L.fvo_istft_same.argtypes = [_f, _f, _f] + [_i] * 6
         _lib = L
+        if "OMP_NUM_THREADS" not in os.environ:
+            # default team size = the CPUs this process may actually use: the affinity mask capped by the container's cgroup CPU
+            # quota (a 256-thread host that grants 16 CPUs of time would otherwise run every conv on 256 time-sliced threads)
+            n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if q != "max":
+                    n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+            except (OSError, ValueError):
+                pass
+            L.fvo_set_num_threads(min(n, 32))
     return _lib
 
 
