@@ -156,6 +156,7 @@ PAIR_CASES = [
     # (C, k, d, B, T) — T chosen to hit: several tiles, a ragged last tile, T smaller than one tile, T == 1
     (16, 3, 1, 2, 2100), (16, 7, 3, 1, 1030), (16, 11, 5, 2, 700), (16, 11, 1, 1, 502), (16, 3, 5, 1, 1),
     (64, 3, 1, 2, 400), (64, 3, 5, 1, 1033), (64, 3, 3, 1, 2),
+    (128, 3, 1, 2, 300), (128, 3, 5, 1, 517), (128, 3, 3, 1, 3),     # waves along M, residual from HBM (round 3)
     (32, 3, 3, 2, 1000), (32, 7, 5, 1, 517), (32, 11, 1, 2, 300), (32, 11, 5, 1, 247), (32, 7, 1, 1, 5),
 ]
 

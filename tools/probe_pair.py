@@ -8,8 +8,8 @@ from vocoder_amd.engine import FusedConv
 rng = np.random.default_rng(0)
 B = 32
 tot = 0.0
-for C, T in ((32, 22016), (16, 44032)):
-    for k in (3, 7, 11):
+for C, T in ((128, 5504), (64, 11008), (32, 22016), (16, 44032)):
+    for k in ((3,) if C >= 64 else (3, 7, 11)):
         for d in (1, 3, 5):
             w1 = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
             c1 = FusedConv(w1, np.zeros(C, np.float32), dilation=d, padding=(k * d - d) // 2)

@@ -385,6 +385,7 @@ struct fv_engine {
     bool profiling = false;
     int precision = FV_PRECISION_F32;   // fv_set_precision
     bool fuse_pairs = true;   // FV_NO_PAIR_FUSION=1 in the environment disables the fused (c1, c2) kernels (A/B runs)
+    int pair_max_c = 128;     // FV_PAIR_MAXC: widest stage whose (c1, c2) pairs fuse where a kernel exists (experiments)
     bool fuse_amp_convs = true;   // FV_NO_AMP_FUSION=1: BigVGAN's narrow stages run aa_snake + conv launches instead of amp_conv (A/B runs)
     // Measured in the step (BigVGAN-24k B = 64, interleaved, tools/ab_bigvgan.py): none 37.35 ms; k = 3 only 37.15; k <= 7 37.5; all 38.1.
     // Serialized, amp_conv equals conv + aa_snake within 5 % everywhere, but the separate activation pass is HBM-bound work that the
@@ -860,8 +861,10 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
             float* const y_last = tree ? XB(bj) : Y;   // tree: the branch keeps its own output, summed after the join
             // HiFiGAN narrow stages: the whole (c1, c2) pair in one kernel, intermediate kept in LDS.  Not in place
             // (workgroups read their neighbours' halo), so the branch ping-pongs S -> XB -> XT -> Y.
-            const bool fuse_narrow = pair_supported(ch, br.k, br.dil[0]) && pair_supported(ch, br.k, br.dil[1]) &&
-                                     pair_supported(ch, br.k, br.dil[2]);
+            // (C = 128 pairs: 126-column tiles, two workgroups per CU — only when the launch fills the chip; a single clip's 44 tiles
+            //  are better served by the split-K latency kernels: p50 0.96 vs 1.04 ms)
+            const bool fuse_narrow = ch <= pair_max_c && pair_supported(ch, br.k, br.dil[0]) && pair_supported(ch, br.k, br.dil[1]) &&
+                                     pair_supported(ch, br.k, br.dil[2]) && (ch < 128 || (long long)B * ((t + 125) / 126) >= 2LL * num_cus());
             // f16x3 precision mode: the wide stages (C = 128 / 64) fuse too (pair_f16x3_impl.h)
             const bool fuse_wide = pair_f16x3_supported(br.c1[0], br.c2[0]) && pair_f16x3_supported(br.c1[1], br.c2[1]) &&
                                    pair_f16x3_supported(br.c1[2], br.c2[2]);
@@ -1319,6 +1322,7 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
     }
     e->cfg = *cfg;
     if (const char* v = std::getenv("FV_NO_PAIR_FUSION")) e->fuse_pairs = !(v[0] == '1');
+    if (const char* v = std::getenv("FV_PAIR_MAXC")) e->pair_max_c = std::atoi(v);
     if (const char* v = std::getenv("FV_NO_AMP_FUSION")) e->fuse_amp_convs = !(v[0] == '1');
     if (const char* v = std::getenv("FV_AMP_MAXC")) e->fuse_amp_max_c = std::atoi(v);
     if (const char* v = std::getenv("FV_AMP_MAXK")) e->fuse_amp_max_k = std::atoi(v);

@@ -40,18 +40,23 @@ struct PairGeom {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// C = 32 (MT = 1) and C = 64 (MT = 2): 32x32x2 MFMA.  Each wave owns NT n-tiles of 32 columns and all m-tiles.
+// C = 32 (MT = 1) and C = 64 (MT = 2): 32x32x2 MFMA, each wave owns NT n-tiles of 32 columns and all m-tiles (WM = 1).
+// C = 128 (k = 3 only, round 3): WM = 4 — each wave owns ONE m-tile (its own quarter of the weights: no fragment is fetched by
+// two waves) and all four n-tiles; the raw tile for the residual does not fit next to the 74 KB window (XRES = false: the
+// epilogue reads x from HBM again, L2-warm), two workgroups per CU.
 // ---------------------------------------------------------------------------------------------------------------
-template <int KS, int DIL, int C>
+template <int KS, int DIL, int C, int WM = 1, bool XRES = true>
 __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair32_kernel(const PairParams p) {
     using G = PairGeom<KS, DIL, C>;
-    constexpr int MT = C / 32;
-    constexpr int NT = G::W1 / 32 / 4;   // n-tiles per wave
+    constexpr int WN = 4 / WM;
+    constexpr int MT = C / 32 / WM;          // m-tiles per wave
+    constexpr int NT = G::W1 / 32 / WN;      // n-tiles per wave
     constexpr int NCH = C / 8;
+    constexpr int STEPS64 = NCH * KS * 64;   // float4s of packed weights per m-tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;
     float* Bs = lds;   // overlays As once every wave has finished c1
-    float* Xr = lds + G::AB_FLOATS;   // raw x[:, t0 : t0 + TT): the residual operand
+    float* Xr = lds + G::AB_FLOATS;   // raw x[:, t0 : t0 + TT): the residual operand (XRES)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,10 +72,13 @@ __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair32_kernel(con
 
     // phase 1: A = silu(x) window.  Loads are unconditional on clamped addresses and issued in batches of 8 so that
     // their latencies overlap (a guarded load per element compiles to a branch + vmcnt(0) each).
-    stage_window<C, G::WA_RAW, G::WA, G::HP, G::TT, G::XS>(xb, As, wave, lane, t0, p.T, Xr);
+    if constexpr (XRES) stage_window<C, G::WA_RAW, G::WA, G::HP, G::TT, G::XS>(xb, As, wave, lane, t0, p.T, Xr);
+    else stage_window<C, G::WA_RAW, G::WA, G::HP>(xb, As, wave, lane, t0, p.T);
     __syncthreads();
 
-    const int ncol = wave * (NT * 32) + (lane & 31);
+    const int wm = wave / WN, wn = wave % WN;
+    const int mrow0 = wm * MT * 32;          // first output row of this wave
+    const int ncol = wn * (NT * 32) + (lane & 31);
     const int krow = lane >> 5;
 
     // phase 2: c1
@@ -82,13 +90,13 @@ __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair32_kernel(con
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        gemm32_resident<KS, G::WA, DIL, MT, NT, NCH>(p.w1, lane, As + krow * G::WA + ncol, acc);
+        gemm32_resident<KS, G::WA, DIL, MT, NT, NCH>(p.w1 + (size_t)wm * MT * STEPS64, lane, As + krow * G::WA + ncol, acc);
         __syncthreads();   // every wave is done reading the window before the intermediate overwrites it
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
+                const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
                 const float bias = p.b1[m];
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) {
@@ -110,19 +118,30 @@ __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair32_kernel(con
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        gemm32_resident<KS, G::WB, 1, MT, NT, NCH>(p.w2, lane, Bs + krow * G::WB + ncol, acc);
+        gemm32_resident<KS, G::WB, 1, MT, NT, NCH>(p.w2 + (size_t)wm * MT * STEPS64, lane, Bs + krow * G::WB + ncol, acc);
         const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * C * p.T, (unsigned)(C * p.T) * 4u);
+        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb, (unsigned)(C * p.T) * 4u);
         auto off = [&](int i, int r, int jn) -> unsigned {   // byte offset inside this batch item, or 0xFFFFFFFF (masked)
-            const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
+            const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
             const int n = ncol + jn * 32;
             const int t = t0 + n;
             return (n < G::TT && t < p.T) ? (unsigned)(m * p.T + t) * 4u : 0xFFFFFFFFu;
         };
+        float xg[XRES ? 1 : MT][XRES ? 1 : 16][XRES ? 1 : NT];
+        if constexpr (!XRES) {   // residual operands of the whole register tile in one round trip
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn)
+                        xg[i][r][jn] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off(i, r, jn), 0, 0));
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
+                const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * krow;
                 const float bias = p.b2[m];
                 float yo[NT];
                 if (p.out_mode == OUT_ACCUM) {
@@ -133,7 +152,10 @@ __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair32_kernel(con
                 for (int jn = 0; jn < NT; ++jn) {
                     const int n = ncol + jn * 32;
                     // residual from the raw tile in LDS (columns past TT belong to the next tile: masked by off(), any finite address)
-                    float v = acc[i][jn][r] + bias + Xr[m * G::XS + (n < G::TT ? n : 0)];
+                    float res;
+                    if constexpr (XRES) res = Xr[m * G::XS + (n < G::TT ? n : 0)];
+                    else res = xg[i][r][jn];
+                    float v = acc[i][jn][r] + bias + res;
                     if (p.out_mode == OUT_ACCUM) v = (yo[jn] + v) * p.out_scale;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, off(i, r, jn), 0, 0);
                 }
@@ -241,6 +263,18 @@ static bool launch_pair_c(const PairParams& p, int C, int batch, hipStream_t s) 
         hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 32>), dim3((batch * q.n_tiles + 7) / 8 * 8), dim3(256), lds, s, q);
         return true;
     }
+    if constexpr (KS == 3) {
+        if (C == 128) {
+            using G = PairGeom<KS, DIL, 128>;
+            PairParams q = p;
+            q.n_tiles = (p.T + G::TT - 1) / G::TT;
+            q.batch = batch;
+            const size_t lds = (size_t)G::AB_FLOATS * sizeof(float);
+            if (!FV_ENSURE_DYN_LDS((resblock_pair32_kernel<KS, DIL, 128, 4, false>), lds)) return false;
+            hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 128, 4, false>), dim3((batch * q.n_tiles + 7) / 8 * 8), dim3(256), lds, s, q);
+            return true;
+        }
+    }
     if (C == 64) {
         using G = PairGeom<KS, DIL, 64>;
         PairParams q = p;
@@ -256,8 +290,9 @@ static bool launch_pair_c(const PairParams& p, int C, int batch, hipStream_t s) 
 
 // C = 64 fuses only at k = 3 (measured per stage: k = 3 -20 %, k = 7 +42 %, k = 11 worse still: with two m-tiles per wave and a
 // single n-tile the resident-K kernel re-fetches every weight fragment per wave, which only the short kernel can afford)
+// C = 128 at k = 3 (round 3): waves along M; the short kernel's prologue / epilogue share halves, as at C = 64
 bool pair_supported(int C, int ks, int dil) {
-    if (C != 16 && C != 32 && !(C == 64 && ks == 3)) return false;
+    if (C != 16 && C != 32 && !((C == 64 || C == 128) && ks == 3)) return false;
     if (ks != 3 && ks != 7 && ks != 11) return false;
     return dil == 1 || dil == 3 || dil == 5;
 }
