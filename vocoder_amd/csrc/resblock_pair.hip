@@ -280,9 +280,11 @@ static bool launch_pair_c(const PairParams& p, int C, int batch, hipStream_t s) 
         PairParams q = p;
         q.n_tiles = (p.T + G::TT - 1) / G::TT;
         const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
-        if (!FV_ENSURE_DYN_LDS((resblock_pair32_kernel<KS, DIL, 64>), lds)) return false;
+        // waves along M (one m-tile and two n-tiles per wave: no weight fragment is fetched by two waves): in the B = 32 step 14.94 ->
+        // 14.86 ms against the all-m-tiles-per-wave layout of round 2 (stand-alone 5 % slower; profiles/LOG.md R3.10)
+        if (!FV_ENSURE_DYN_LDS((resblock_pair32_kernel<KS, DIL, 64, 2, true>), lds)) return false;
         q.batch = batch;
-        hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 64>), dim3((batch * q.n_tiles + 7) / 8 * 8), dim3(256), lds, s, q);
+        hipLaunchKernelGGL((resblock_pair32_kernel<KS, DIL, 64, 2, true>), dim3((batch * q.n_tiles + 7) / 8 * 8), dim3(256), lds, s, q);
         return true;
     }
     return false;
