@@ -10,7 +10,7 @@
 namespace fv {
 
 void tile_dims(int cfg, int* m_blk, int* n_blk) {
-    static const int dims[TILE_COUNT][2] = {{128, 128}, {64, 256}, {32, 512}, {128, 64}, {32, 128}, {64, 128}, {32, 64}, {32, 32}, {256, 64}, {256, 32}};
+    static const int dims[TILE_COUNT][2] = {{128, 128}, {64, 256}, {32, 512}, {128, 64}, {32, 128}, {64, 128}, {32, 64}, {32, 32}, {256, 64}, {256, 32}, {128, 96}};
     *m_blk = dims[cfg][0];
     *n_blk = dims[cfg][1];
 }
@@ -309,7 +309,7 @@ static int choose_gemm_pw_xcd_rows(const ConvLayer& L, const ConvRun& r, long lo
     return px;
 }
 
-static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64", "splitK32x32", "256x64", "256x32"};
+static const char* const kTileNames[TILE_COUNT] = {"128x128", "64x256", "32x512", "128x64", "32x128", "64x128", "splitK32x64", "splitK32x32", "256x64", "256x32", "128x96"};
 
 static const char* const kSplitNames[SPLIT_COUNT] = {"128x128", "64x256", "32x256"};
 
@@ -476,6 +476,9 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     p.dbg_ts = g_sk_ts;
 #endif
     int cfg = choose_tile(L.M, p.N, r.batch);
+    // the stage-0 upsampler of a 1 s clip: 87 GEMM columns per item fill two thirds of a 128-column tile — 128 x 96 tiles (four waves
+    // along M, three n-tiles each; instantiated for the two-tap polyphase convs only)
+    if (cfg == TILE_128x128 && L.ks == 2 && L.M >= 128 && p.N > 64 && p.N <= 96) cfg = TILE_128x96;
     // pointwise convs have no halo, so batch and time flatten into one GEMM column axis: no per-item partial tiles
     // (Vocos: T = 94 frames per clip would waste 27 % of a 128-column tile)
     int launch_batch = r.batch;

@@ -707,6 +707,9 @@ inline bool launch_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
         case TILE_256x32:
             if constexpr (KS == 1) { launch_one<KS, DIL, 4, 1, 2, 1>(p, batch, s); return true; }
             return false;
+        case TILE_128x96:
+            if constexpr (KS == 2) { launch_one<KS, DIL, 4, 1, 1, 3>(p, batch, s); return true; }
+            return false;
         case TILE_256x64:
             if constexpr (KS == 1) { launch_one<KS, DIL, 4, 1, 2, 2>(p, batch, s); return true; }
             return false;

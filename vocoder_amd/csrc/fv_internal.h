@@ -232,7 +232,7 @@ bool launch_amp_conv(const ConvLayer& L, const float* x, float* y, const float* 
                      const float* up_taps, const float* down_taps, int batch, int t, int out_mode, float out_scale, hipStream_t s);
 
 // Tile configurations (block = 4 waves): rows = WM*MT*32, cols = WN*NT*32.
-enum TileCfg : int { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2, TILE_128x64 = 3, TILE_32x128 = 4, TILE_64x128 = 5, TILE_SPLITK_32x64 = 6, TILE_SPLITK_32x32 = 7, TILE_256x64 = 8, TILE_256x32 = 9, TILE_COUNT };
+enum TileCfg : int { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2, TILE_128x64 = 3, TILE_32x128 = 4, TILE_64x128 = 5, TILE_SPLITK_32x64 = 6, TILE_SPLITK_32x32 = 7, TILE_256x64 = 8, TILE_256x32 = 9, TILE_128x96 = 10, TILE_COUNT };
 void tile_dims(int cfg, int* m_blk, int* n_blk);
 
 // ---------------------------------------------------------------------------------------------
