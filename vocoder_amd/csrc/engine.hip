@@ -385,6 +385,7 @@ struct fv_engine {
     bool profiling = false;
     int precision = FV_PRECISION_F32;   // fv_set_precision
     bool fuse_pairs = true;   // FV_NO_PAIR_FUSION=1 in the environment disables the fused (c1, c2) kernels (A/B runs)
+    bool post_mean_fused = true;   // FV_NO_POST_SUM3=1: mean_of_three_kernel before conv_post instead of the mean formed in its staging (A/B runs)
     int pair_max_c = 128;     // FV_PAIR_MAXC: widest stage whose (c1, c2) pairs fuse where a kernel exists (experiments)
     bool fuse_amp_convs = true;   // FV_NO_AMP_FUSION=1: BigVGAN's narrow stages run aa_snake + conv launches instead of amp_conv (A/B runs)
     // Measured in the step (BigVGAN-24k B = 64, interleaved, tools/ab_bigvgan.py): none 37.35 ms; k = 3 only 37.15; k <= 7 37.5; all 38.1.
@@ -790,6 +791,7 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
     int t = (int)ups.conv_pre.out_len(T);
     int stage_idx = 0;
     bool sum_pending = false;   // tree mode: the stage output is still three branch buffers (XB(0..2))
+    bool post_sum3 = false;     // ... and so is the last stage's, for conv_post to average
     const int n_stages = (int)ups.stages.size();
     for (auto& stg : ups.stages) {
         // x = ups[i](silu(x))  — HiFiGAN (hifigan.py:230-231); BigVGAN has no pre-activation (bigvgan.py:355-356)
@@ -965,6 +967,9 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
             static const bool fuse_mean = std::getenv("FV_NO_SUM3") == nullptr;
             if (stage_idx + 1 < n_stages && fuse_mean && !dbg_here) {
                 sum_pending = true;
+            } else if (stage_idx + 1 == n_stages && fuse_mean && post_mean_fused && !dbg_here && !ups.bigvgan &&
+                       conv_narrow_sum3_ok(B, ups.post_cin, t, 1, ups.cfg.post_conv_kernel_size, get_padding(ups.cfg.post_conv_kernel_size))) {
+                post_sum3 = true;   // HiFiGAN's conv_post forms the last stage's branch mean while staging its input
             } else if ((st = launch_mean_of_three(XB(0), XB(1), XB(2), Y, (long long)B * ch * t, s))) {
                 return st;
             }
@@ -991,6 +996,12 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
         pre = FV_ACT_NONE;
     }
     const int qk = ups.cfg.post_conv_kernel_size;
+    if (post_sum3) {
+        FV_PROF(s, "conv_post_narrow sum3", 2.0 * B * ups.post_cin * qk * t, 4.0 * B * (3 * ups.post_cin + 1) * t,
+                launch_conv_narrow(XB(0), ups.d_wpost, ups.d_bpost, d_out, B, ups.post_cin, t, 1, qk, get_padding(qk), pre, FV_ACT_TANH, 0.f,
+                                   s, XB(1), XB(2)));
+        return FV_OK;
+    }
     FV_PROF(s, "conv_post_narrow", 2.0 * B * ups.post_cin * qk * t, 4.0 * B * (ups.post_cin + 1) * t,
             launch_conv_narrow(post_in, ups.d_wpost, ups.d_bpost, d_out, B, ups.post_cin, t, 1, qk, get_padding(qk), pre,
                                FV_ACT_TANH, 0.f, s));
@@ -1323,6 +1334,7 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
     e->cfg = *cfg;
     if (const char* v = std::getenv("FV_NO_PAIR_FUSION")) e->fuse_pairs = !(v[0] == '1');
     if (const char* v = std::getenv("FV_PAIR_MAXC")) e->pair_max_c = std::atoi(v);
+    if (const char* v = std::getenv("FV_NO_POST_SUM3")) e->post_mean_fused = !(v[0] == '1');
     if (const char* v = std::getenv("FV_NO_AMP_FUSION")) e->fuse_amp_convs = !(v[0] == '1');
     if (const char* v = std::getenv("FV_AMP_MAXC")) e->fuse_amp_max_c = std::atoi(v);
     if (const char* v = std::getenv("FV_AMP_MAXK")) e->fuse_amp_max_k = std::atoi(v);

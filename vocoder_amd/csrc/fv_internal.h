@@ -239,8 +239,11 @@ void tile_dims(int cfg, int* m_blk, int* n_blk);
 // Small fused kernels (elementwise / narrow-output / reduction)
 // ---------------------------------------------------------------------------------------------
 // y[b][co][t] = post( bias[co] + sum_{ci,j} w[co][ci][j] * pre(x[b][ci][t + j - pad]) ), c_out <= 4 (conv_post).
+// x2 / x3 (optional): the input is ((x + x2) + x3) / 3, formed while staging — only where conv_narrow_sum3_ok() says so
 fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int T,
-                             int Cout, int k, int pad, int pre_act, int post_act, float slope, hipStream_t s);
+                             int Cout, int k, int pad, int pre_act, int post_act, float slope, hipStream_t s,
+                             const float* x2 = nullptr, const float* x3 = nullptr);
+bool conv_narrow_sum3_ok(int B, int Cin, int T, int Cout, int k, int pad);
 
 // Anti-aliased SnakeBeta: y = down2(snake(up2(x))) with 12-tap kaiser-sinc filters (alias_free_torch Activation1d).
 // alpha_eff/inv_beta are per-channel, already exp()'d / inverted on the host.

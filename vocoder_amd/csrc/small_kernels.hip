@@ -85,9 +85,12 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const float* __restric
 // thread owns four consecutive outputs: per channel it reads its 4 + K - 1 window values with aligned ds_read_b128s and
 // runs the 4 * K FMAs against taps held in SGPRs; the slab is staged row by row (no division) with raw buffer loads whose
 // bounds check supplies the zero padding.
+// SUM3: the input is ((x + x2) + x3) / 3 — the stack-mean of the last stage's three ResBlock branches, formed while staging instead
+// of by a mean_of_three_kernel pass over four tensors (the same additions in the same order: bit-identical).
 constexpr int POST_TT = 1024;
-template <int K>
-__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int K, bool SUM3>
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                        const float* __restrict__ x3, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int Cin, int T,
                                                         int pre_act, int post_act, float slope, int n_tiles) {
     constexpr int PAD = (K - 1) / 2;
@@ -99,6 +102,8 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
     const int t0 = tile * POST_TT;
     const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(x + (long long)b * Cin * T, (unsigned)((long long)Cin * T * 4));
+    const __amdgpu_buffer_rsrc_t xrs2 = uniform_rsrc((SUM3 ? x2 : x) + (long long)b * Cin * T, (unsigned)((long long)Cin * T * 4));
+    const __amdgpu_buffer_rsrc_t xrs3 = uniform_rsrc((SUM3 ? x3 : x) + (long long)b * Cin * T, (unsigned)((long long)Cin * T * 4));
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < Cin; c0 += NARROW_CH) {
         __syncthreads();
@@ -110,7 +115,13 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
                 const int col = tid + i * 256;
                 const int t = t0 - LEAD + col;
                 const bool ok = ci < Cin && t >= 0 && t < T;
-                const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? (unsigned)(ci * T + t) * 4u : 0xFFFFFFFFu, 0, 0));
+                const unsigned off = ok ? (unsigned)(ci * T + t) * 4u : 0xFFFFFFFFu;
+                float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
+                if constexpr (SUM3) {
+                    const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs2, off, 0, 0));
+                    const float v3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs3, off, 0, 0));
+                    v = ((v + v2) + v3) * (1.0f / 3.0f);
+                }
                 if (col < PITCH) xs[r][col] = pre_act == FV_ACT_SILU ? v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) : act_apply(v, pre_act, slope);
             }
         }
@@ -149,8 +160,19 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     }
 }
 
+// does launch_conv_narrow form a three-operand input mean itself for this call (the 1024-column conv_post kernel)?
+bool conv_narrow_sum3_ok(int B, int Cin, int T, int Cout, int k, int pad) {
+    const bool small = (long long)B * ((T + 1023) / 1024) < 2 * num_cus();
+    return !small && Cout == 1 && (k == 7 || k == 13) && 2 * pad == k - 1 && (long long)Cin * T < (1LL << 30);
+}
+
 fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int T,
-                             int Cout, int k, int pad, int pre_act, int post_act, float slope, hipStream_t s) {
+                             int Cout, int k, int pad, int pre_act, int post_act, float slope, hipStream_t s, const float* x2,
+                             const float* x3) {
+    if ((x2 || x3) && !(x2 && x3 && conv_narrow_sum3_ok(B, Cin, T, Cout, k, pad))) {
+        set_error("conv_narrow: this call cannot take a three-operand input (ask conv_narrow_sum3_ok first)");
+        return FV_ERR_INVALID;
+    }
     if (Cout > NARROW_MAXCO || 2 * pad != k - 1) {
         set_error("conv_narrow: needs c_out <= %d and 'same' padding (c_out=%d k=%d pad=%d)", NARROW_MAXCO, Cout, k, pad);
         return FV_ERR_UNSUPPORTED;
@@ -159,10 +181,14 @@ fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, 
     const bool small = (long long)B * ((T + 1023) / 1024) < 2 * num_cus();
     if (!small && Cout == 1 && (k == 7 || k == 13) && (long long)Cin * T < (1LL << 30)) {
         const int nt = (T + POST_TT - 1) / POST_TT;
-        if (k == 7)
-            hipLaunchKernelGGL(conv_post_kernel<7>, dim3(B * nt), dim3(256), 0, s, x, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
+        if (k == 7 && x2)
+            hipLaunchKernelGGL((conv_post_kernel<7, true>), dim3(B * nt), dim3(256), 0, s, x, x2, x3, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
+        else if (k == 7)
+            hipLaunchKernelGGL((conv_post_kernel<7, false>), dim3(B * nt), dim3(256), 0, s, x, x, x, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
+        else if (x2)
+            hipLaunchKernelGGL((conv_post_kernel<13, true>), dim3(B * nt), dim3(256), 0, s, x, x2, x3, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
         else
-            hipLaunchKernelGGL(conv_post_kernel<13>, dim3(B * nt), dim3(256), 0, s, x, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
+            hipLaunchKernelGGL((conv_post_kernel<13, false>), dim3(B * nt), dim3(256), 0, s, x, x, x, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
         FV_HIP_CHECK(hipGetLastError());
         return FV_OK;
     }
