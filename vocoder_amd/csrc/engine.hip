@@ -967,9 +967,10 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
             static const bool fuse_mean = std::getenv("FV_NO_SUM3") == nullptr;
             if (stage_idx + 1 < n_stages && fuse_mean && !dbg_here) {
                 sum_pending = true;
-            } else if (stage_idx + 1 == n_stages && fuse_mean && post_mean_fused && !dbg_here && !ups.bigvgan &&
-                       conv_narrow_sum3_ok(B, ups.post_cin, t, 1, ups.cfg.post_conv_kernel_size, get_padding(ups.cfg.post_conv_kernel_size))) {
-                post_sum3 = true;   // HiFiGAN's conv_post forms the last stage's branch mean while staging its input
+            } else if (stage_idx + 1 == n_stages && fuse_mean && post_mean_fused && !dbg_here &&
+                       (ups.bigvgan || conv_narrow_sum3_ok(B, ups.post_cin, t, 1, ups.cfg.post_conv_kernel_size,
+                                                           get_padding(ups.cfg.post_conv_kernel_size)))) {
+                post_sum3 = true;   // conv_post (HiFiGAN) / activation_post (BigVGAN) forms the last stage's branch mean while loading its input
             } else if ((st = launch_mean_of_three(XB(0), XB(1), XB(2), Y, (long long)B * ch * t, s))) {
                 return st;
             }
@@ -989,11 +990,13 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
     const float* post_in = cur;
     int pre = FV_ACT_SILU;
     if (ups.bigvgan) {
-        FV_PROF(s, "aa_snake", 60.0 * B * ups.post_cin * t, 8.0 * B * ups.post_cin * t,
-                launch_aa_snake(cur, XA(0), ups.act_post.d_alpha, ups.act_post.d_inv_beta, ups.act_post.d_up,
-                                ups.act_post.d_down, B, ups.post_cin, t, s));
+        // (XA(0) is free again: every branch has joined)
+        FV_PROF(s, post_sum3 ? "aa_snake sum3" : "aa_snake", 60.0 * B * ups.post_cin * t, (post_sum3 ? 16.0 : 8.0) * B * ups.post_cin * t,
+                launch_aa_snake(post_sum3 ? XB(0) : cur, XA(0), ups.act_post.d_alpha, ups.act_post.d_inv_beta, ups.act_post.d_up,
+                                ups.act_post.d_down, B, ups.post_cin, t, s, post_sum3 ? XB(1) : nullptr, post_sum3 ? XB(2) : nullptr));
         post_in = XA(0);
         pre = FV_ACT_NONE;
+        post_sum3 = false;   // the mean is in: conv_post reads the activated tensor
     }
     const int qk = ups.cfg.post_conv_kernel_size;
     if (post_sum3) {

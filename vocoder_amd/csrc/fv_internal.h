@@ -247,8 +247,10 @@ bool conv_narrow_sum3_ok(int B, int Cin, int T, int Cout, int k, int pad);
 
 // Anti-aliased SnakeBeta: y = down2(snake(up2(x))) with 12-tap kaiser-sinc filters (alias_free_torch Activation1d).
 // alpha_eff/inv_beta are per-channel, already exp()'d / inverted on the host.
+// x2 / x3 (optional): the input is ((x + x2) + x3) / 3 (three branch outputs), formed while loading.
 fv_status launch_aa_snake(const float* x, float* y, const float* alpha_eff, const float* inv_beta, const float* up_taps,
-                          const float* down_taps, int B, int C, int T, hipStream_t s);
+                          const float* down_taps, int B, int C, int T, hipStream_t s, const float* x2 = nullptr,
+                          const float* x3 = nullptr);
 
 // Depthwise conv (k taps, zero pad) + LayerNorm over channels, fused: y = LN_c(dwconv(x)) * w + b.
 // With dw_w == NULL: plain channels-first LayerNorm.

@@ -266,16 +266,19 @@ __device__ __forceinline__ f32x2 snake2(f32x2 u, float al, float ib, float al_pi
 
 // EDGE = false: the tile and its 6-sample halo lie inside [0, T) — no clamps, no bounds tests, fixed trip counts (the
 // clamp / compare / loop-carried VALU work was about a quarter of the kernel's instructions).  Same arithmetic order either way.
+// x2r / x3r (optional): the input row is ((x + x2) + x3) / 3 — the stack-mean of three ResBlock branches (activation_post after the
+// last stage, bigvgan.py:365-367), formed on the way into LDS instead of by a mean_of_three_kernel pass.
 template <bool EDGE>
 __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, float* __restrict__ yr, float* __restrict__ xs,
                                               float* __restrict__ A, const float* __restrict__ up_taps,
-                                              const float* __restrict__ down_taps, float al, float ib, int t0, int T) {
+                                              const float* __restrict__ down_taps, float al, float ib, int t0, int T,
+                                              const float* __restrict__ x2r = nullptr, const float* __restrict__ x3r = nullptr) {
     const int tid = threadIdx.x;
     const float al_pi = al * 0.318309886183790672f, hb = 0.5f * ib;
     auto load_x = [&](int e) {
         int t = t0 - 6 + e;
         if (EDGE) t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);   // replicate padding of the up-sampler input
-        xs[e] = xr[t];
+        xs[e] = x2r ? ((xr[t] + x2r[t]) + x3r[t]) * (1.0f / 3.0f) : xr[t];
     };
 #pragma unroll
     for (int i = 0; i < AA_TT / 256; ++i) load_x(tid + i * 256);
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restric
                                                           const float* __restrict__ inv_beta,
                                                           const float* __restrict__ up_taps,
                                                           const float* __restrict__ down_taps, int C, int T, int n_tiles,
-                                                          int vec4) {
+                                                          int vec4, const float* __restrict__ x2, const float* __restrict__ x3) {
     __shared__ __attribute__((aligned(16))) float xs[AA_TT + 16];
     __shared__ __attribute__((aligned(16))) float A[2 * AA_ODD];
     const int tile = blockIdx.x % n_tiles;
@@ -419,21 +422,27 @@ __global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restric
     const int c = (int)(row % C);
     const int t0 = tile * AA_TT;
     const float al = alpha_eff[c], ib = inv_beta[c];
+    const float* x2r = x2 ? x2 + row * T : nullptr;
+    const float* x3r = x2 ? x3 + row * T : nullptr;
     if (t0 >= 6 && t0 + AA_TT + 6 < T) {
-        if (vec4) aa_snake4_tile(x + row * T, y + row * T, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t0);
-        else aa_snake_tile<false>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T);
+        if (vec4 && !x2) aa_snake4_tile(x + row * T, y + row * T, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t0);
+        else aa_snake_tile<false>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T, x2r, x3r);
     } else
-        aa_snake_tile<true>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T);
+        aa_snake_tile<true>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T, x2r, x3r);
 }
 
 fv_status launch_aa_snake(const float* x, float* y, const float* alpha_eff, const float* inv_beta, const float* up_taps,
-                          const float* down_taps, int B, int C, int T, hipStream_t s) {
+                          const float* down_taps, int B, int C, int T, hipStream_t s, const float* x2, const float* x3) {
+    if ((x2 == nullptr) != (x3 == nullptr)) {
+        set_error("aa_snake: x2 and x3 go together");
+        return FV_ERR_INVALID;
+    }
     const int n_tiles = (T + AA_TT - 1) / AA_TT;
     // interior tiles move 16 bytes per lane when every row starts 16-byte aligned (aa_snake4_tile); FV_AA_VEC4=0: the pair form
     static const bool no_vec4 = std::getenv("FV_AA_VEC4") && std::getenv("FV_AA_VEC4")[0] == '0';
     const int vec4 = !no_vec4 && T % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
     hipLaunchKernelGGL(aa_snake_pk_kernel, dim3((unsigned)((long long)B * C * n_tiles)), dim3(256), 0, s, x, y, alpha_eff,
-                       inv_beta, up_taps, down_taps, C, T, n_tiles, vec4);
+                       inv_beta, up_taps, down_taps, C, T, n_tiles, vec4, x2, x3);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
 }
