@@ -30,7 +30,7 @@ def key_of(kernel_name: str, grid_threads: int):
     m = re.search(r"resblock_pair16_kernel<(\d+), (\d+)>", kernel_name)
     if m:
         return f"resblock_pair k={m.group(1)} d={m.group(2)} C=16 grid={blocks}"
-    m = re.search(r"resblock_pair32_kernel<(\d+), (\d+), (\d+)>", kernel_name)
+    m = re.search(r"resblock_pair32_kernel<(\d+), (\d+), (\d+)(?:, \d+, (?:true|false))?>", kernel_name)   # (+ wave layout, residual source)
     if m:
         return f"resblock_pair k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={blocks}"
     return None
