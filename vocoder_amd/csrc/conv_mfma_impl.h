@@ -163,17 +163,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #ifndef FV_X_INTERLEAVE
 #define FV_X_INTERLEAVE 1
 #endif
-constexpr int kWeightPrefetch = 3;   // weight-fragment prefetch distance in k-steps (taps)
+#ifndef FV_X_DA
+#define FV_X_DA 3
+#endif
+constexpr int kWeightPrefetch = FV_X_DA;   // weight-fragment prefetch distance in k-steps (taps)
 
 // 8-channel sub-chunks staged per barrier (LDS budget 2 * 8*SUBS * W floats, <= 36 KiB)
 #ifndef FV_X_SUBS_LONG
 #define FV_X_SUBS_LONG 2
 #endif
+#ifndef FV_X_SUBS_MID
+#define FV_X_SUBS_MID 2
+#endif
 constexpr int subs_for(int ks, int w) {
     // measured: k = 3 +4 % with 16-channel chunks, +2 % more with 32.  k >= 7: 16-channel chunks were -3 % in round 1 (before the
     // operand pipeline and the interleaved memory operations) and are +0.8 % on the B = 32 step now (14.89 -> 14.77 ms, three
     // interleaved rounds; 32 channels: 14.83); half the barriers and staging phases per tile
-    int s = ks <= 3 ? 4 : (ks <= 4 ? 2 : FV_X_SUBS_LONG);
+    int s = ks <= 3 ? 4 : (ks <= 4 ? FV_X_SUBS_MID : FV_X_SUBS_LONG);
     while (s > 1 && s * kChunk * w > 4608) s /= 2;
     return s;
 }
