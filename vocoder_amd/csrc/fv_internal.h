@@ -201,7 +201,7 @@ enum GemmPwCfg : int { GEMM_PW_64x64_W2 = 0, GEMM_PW_32x64_W3 = 1, GEMM_PW_COUNT
 int launch_gemm_pw(const ConvParams& p, int cfg, bool pair, hipStream_t s);
 
 #ifndef FV_X_PAIRCOLS
-#define FV_X_PAIRCOLS 4096
+#define FV_X_PAIRCOLS 2048   // round 3: 128-column tiles at C = 16 too (4096: 256 columns) — same B = 32 step, single-clip p50 -4 %
 #endif
 constexpr int kPairCols = FV_X_PAIRCOLS;   // c1 columns per workgroup x channels (LDS budget of the fused pair kernel)
 

@@ -25,7 +25,7 @@ constexpr int kPairMinWaves = 2;   // min waves per SIMD the register allocator 
 
 template <int KS, int DIL, int C>
 struct PairGeom {
-    static constexpr int W1 = kPairCols / C < 128 ? 128 : kPairCols / C;   // c1 output columns per workgroup (256 at C=16, 128 at C=32 / 64)
+    static constexpr int W1 = kPairCols / C < 128 ? 128 : kPairCols / C;   // c1 output columns per workgroup (128 at every width since round 3)
     static constexpr int TT = W1 - (KS - 1);            // final output columns per workgroup
     static constexpr int H1 = (KS - 1) / 2 * DIL, H2 = (KS - 1) / 2, HP = H1 + H2;
     static constexpr int WA_RAW = W1 + (KS - 1) * DIL;  // staged x columns
