@@ -340,16 +340,29 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
 // six ds_read_b128, rows enter and leave as dwordx4.  The FIRs run as scalar-tap v_fma_f32 in the SAME order as the packed
 // ones above (two independent accumulator chains per position), so results are bit-identical.  Needs T % 4 == 0 and 16-byte
 // aligned rows (host); xs[8 + i] = x[t0 + i], E / O[m] = samples of position h = t0 - 3 + m.
+// EDGE tiles (sequence ends inside the window; also rows shorter than a tile): x is loaded with clamped indices (replicate padding
+// of the up-sampler input), every position is computed the same way, then the positions outside [0, T) are overwritten with the
+// first even / last odd sample (replicate padding of the 2x-rate signal: aa_snake_tile's a.y = a.x / a.x = a.y) and the stores
+// are masked — the same values as the pair form, element for element.
+template <bool EDGE>
 __device__ __forceinline__ void aa_snake4_tile(const float* __restrict__ xr, float* __restrict__ yr, float* __restrict__ xs,
                                                float* __restrict__ E, float* __restrict__ O, const float* __restrict__ up_taps,
-                                               const float* __restrict__ down_taps, float al, float ib, int t0) {
+                                               const float* __restrict__ down_taps, float al, float ib, int t0, int T) {
     const int tid = threadIdx.x;
     const float al_pi = al * 0.318309886183790672f, hb = 0.5f * ib;
     typedef float f4 __attribute__((ext_vector_type(4)));
+    if constexpr (EDGE) {
+        auto cl = [&](int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xs[8 + 4 * tid + k] = xr[cl(t0 + 4 * tid + k)];
+        if (tid < 6) xs[2 + tid] = xr[cl(t0 - 6 + tid)];
+        if (tid >= 64 && tid < 71) xs[8 + AA_TT + tid - 64] = xr[cl(t0 + AA_TT + tid - 64)];
+    } else {
     // rows: 1024 centre samples as one dwordx4 per thread, 6 + 7 halo samples by the first lanes
     *reinterpret_cast<f4*>(xs + 8 + 4 * tid) = *reinterpret_cast<const f4*>(xr + t0 + 4 * tid);
     if (tid < 6) xs[2 + tid] = xr[t0 - 6 + tid];
     if (tid >= 64 && tid < 71) xs[8 + AA_TT + tid - 64] = xr[t0 + AA_TT + tid - 64];
+    }
     float upe[6], upo[6], dne[6], dno[6];   // wave-uniform taps (SGPRs): even / odd phase of the up-sampler (gain 2 folded in), low-pass
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -385,6 +398,22 @@ __device__ __forceinline__ void aa_snake4_tile(const float* __restrict__ xr, flo
     up_group(tid);
     if (tid < 2) up_group(256 + tid);   // positions 1024 .. 1031 (1024 .. 1029 are read below)
     __syncthreads();
+    if constexpr (EDGE) {   // position m <-> h = t0 - 3 + m
+        const int m_first = 3 - t0;          // h = 0   (m_first > 0 only in the row's first tile)
+        const int m_last = T - 1 - t0 + 3;   // h = T - 1
+        bool wrote = false;
+        for (int m = tid; m < AA_TT + 8; m += 256) {
+            if (m < m_first) {
+                const float v = E[m_first];
+                E[m] = v; O[m] = v; wrote = true;
+            } else if (m > m_last && m_last >= 0) {
+                const float v = O[m_last];
+                E[m] = v; O[m] = v; wrote = true;
+            }
+        }
+        (void)wrote;
+        __syncthreads();
+    }
     {   // outputs i = 4 tid .. 4 tid + 3: y = sum_q dno[q] O[i + q] + dne[q] E[i + q + 1]
         float o[12], e[12];
 #pragma unroll
@@ -405,7 +434,13 @@ __device__ __forceinline__ void aa_snake4_tile(const float* __restrict__ xr, flo
             }
             out[k] = sx + sy;
         }
-        *reinterpret_cast<f4*>(yr + t0 + 4 * tid) = out;
+        if constexpr (EDGE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t0 + 4 * tid + k < T) yr[t0 + 4 * tid + k] = out[k];
+        } else {
+            *reinterpret_cast<f4*>(yr + t0 + 4 * tid) = out;
+        }
     }
 }
 
@@ -425,9 +460,11 @@ __global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restric
     const float* x2r = x2 ? x2 + row * T : nullptr;
     const float* x3r = x2 ? x3 + row * T : nullptr;
     if (t0 >= 6 && t0 + AA_TT + 6 < T) {
-        if (vec4 && !x2) aa_snake4_tile(x + row * T, y + row * T, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t0);
+        if (vec4 && !x2) aa_snake4_tile<false>(x + row * T, y + row * T, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t0, T);
         else aa_snake_tile<false>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T, x2r, x3r);
-    } else
+    } else if (vec4 && !x2 && T >= 8)
+        aa_snake4_tile<true>(x + row * T, y + row * T, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t0, T);
+    else
         aa_snake_tile<true>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T, x2r, x3r);
 }
 
