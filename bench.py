@@ -68,6 +68,10 @@ def parse():
                     help="skip the BigVGAN-24k B=64 / Vocos-24k B=128 measurements appended as 'other_configs' (N=1 only)")
     ap.add_argument("--no-collectives", action="store_true", help="skip the scatter -> forward -> gather figure")
     ap.add_argument("--profile-json", default=None, help="also dump the per-kernel hipEvent table to this file")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the roofline section: three single-stream forwards with per-launch hipEvents (what `roofline` is computed "
+                         "from) and a short line — the command to put under `rocprofv3 --kernel-trace --stats` so that its per-kernel "
+                         "averages are taken under the same conditions as bench.py's own")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group / scatter-gather plumbing only, no engine and no timing claims "
                          "(backend gloo when there is no GPU: the CPU test of the self-launch path)")
@@ -431,6 +435,18 @@ def _main(a, real_stdout):
     mel = torch.from_numpy(syn.synthetic_mel(B, cfg["num_mels"], T, seed=1234 + rank)).to(dev)
     out = torch.empty((B, 1, eng.output_length(T)), dtype=torch.float32, device=dev)
     samples_per_step = B * eng.output_length(T)
+    if a.roofline_only:
+        eng.profile(mel, repeats=1)   # warm-up in the same mode (single stream, eager): every launch of the trace is comparable
+        table = eng.profile(mel, repeats=3)
+        if a.profile_json:
+            json.dump(table, open(a.profile_json, "w"), indent=1)
+        if rank == 0:
+            print(json.dumps({"roofline_only": True, "roofline": roofline_from_profile(table, 3),
+                              "serialized_kernel_ms": sum(r["total_ms"] for r in table) / 3}), file=real_stdout, flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     def fence():
         torch.cuda.synchronize(dev)
