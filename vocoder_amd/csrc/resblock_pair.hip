@@ -1,11 +1,12 @@
-// Fused ResBlock (c1, c2) pair for the narrow, bandwidth-bound stages (C = 16 / 32 / 64):
+// Fused ResBlock (c1, c2) pair for the narrow stages (C = 16 / 32 at every kernel size) and the k = 3 branch of C = 64 / 128:
 //
 //     y = x + c2( silu( c1( silu(x) ) ) )          (one iteration of ResBlock1.forward,
 //                                                    fish_vocoder/modules/generators/hifigan.py:102-107)
 //
 // in ONE launch.  Per layer the reference (and the unfused path here) moves 5 tensor passes through HBM for this
-// (read x, write xt, read xt, read x, write x'); fused it is ~2-3: the x window is read once (+ halo), the
-// intermediate silu(c1(.)) never leaves LDS, and the residual re-read hits L2/MALL.
+// (read x, write xt, read xt, read x, write x'); fused it is 2: the x window is read once (its halo from the L2 the clip's
+// neighbouring tiles share), the intermediate silu(c1(.)) never leaves LDS, and the residual comes from an LDS copy of the raw
+// tile (round 3; PMC: 181 MB per launch = the algorithmic 2 C T 4 B.  C = 128 re-reads it from HBM: no room next to the window).
 //
 // Workgroup = 4 wavefronts, one batch item, TT final columns:
 //   phase 1  stage A = silu(x[:, t0-HP : t0+W1+HP']) for ALL C channels into LDS (zero outside [0, T))
@@ -14,7 +15,8 @@
 //   phase 3  c2 as implicit GEMM reading Bf, epilogue bias + residual x (+ MRF accumulate) to HBM
 // All K = C*KS is resident, so there are only three barriers per workgroup and every LDS address is an immediate; Bf
 // overlays A (written after a barrier once c1 has consumed it).
-// C = 32 / 64 use v_mfma_f32_32x32x2_f32; C = 16 uses v_mfma_f32_16x16x4_f32 (no padded rows).
+// C >= 32 use v_mfma_f32_32x32x2_f32 (C >= 64: waves stacked along M, see resblock_pair32_kernel); C = 16 uses
+// v_mfma_f32_16x16x4_f32 (no padded rows).
 #include "pair_common.h"
 
 namespace fv {
