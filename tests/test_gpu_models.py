@@ -902,3 +902,26 @@ def test_bigvgan_fused_amp_convs_equal_the_activation_plus_conv_launches(maxk, m
             assert err <= TOL, (B, T, err)
     fused.close()
     plain.close()
+
+
+def test_round3_fusions_are_bit_identical_to_the_launches_they_replace(monkeypatch):
+    """Round-3 engine paths against the launch sequences they replace, on a batch large enough to take them (C = 128 pairs need
+    tiles >= 2 x CUs): k = 3 (c1, c2) pairs at C = 128 (FV_PAIR_MAXC=64 keeps them per layer) and the last stage's branch mean formed
+    inside conv_post (FV_NO_POST_SUM3=1 keeps mean_of_three_kernel).  Same k-step order / same additions: bit for bit."""
+    cfg = dict(syn.HIFIGAN_V1_44K)
+    sd = syn.hifigan_state_dict(cfg, seed=5)
+    x = torch.from_numpy(syn.synthetic_mel(12, 80, 86, seed=77)).to(_dev())
+    base = _hifigan_engine(cfg, sd)
+    y = base(x)
+    torch.cuda.synchronize()
+    prof = base.profile(x, repeats=1)
+    assert any(r["kernel"].startswith("resblock_pair<k=3") and "C=128" in r["kernel"] for r in prof), [r["kernel"] for r in prof][:12]
+    for var, val in (("FV_PAIR_MAXC", "64"), ("FV_NO_POST_SUM3", "1")):
+        monkeypatch.setenv(var, val)
+        eng = _hifigan_engine(cfg, sd)
+        monkeypatch.delenv(var)
+        y2 = eng(x)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2), (var, float((y - y2).abs().max()))
+        eng.close()
+    base.close()
