@@ -213,7 +213,9 @@ static int choose_tile(int M, long long N, int batch) {
         big = TILE_32x512;
         small = TILE_32x128;
     } else if (M <= 64) {
-        big = TILE_64x256;
+        // 64 x 128 tiles also for launches that would fill the chip with 64 x 256 ones (round 3: HiFiGAN step -0.35 %, BigVGAN -0.15 %
+        // over five / three interleaved rounds: twice the workgroups, shorter lives, less lock-step)
+        big = TILE_64x128;
         small = TILE_64x128;
     } else {
         big = TILE_128x128;
@@ -479,6 +481,9 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     // the stage-0 upsampler of a 1 s clip: 87 GEMM columns per item fill two thirds of a 128-column tile — 128 x 96 tiles (four waves
     // along M, three n-tiles each; instantiated for the two-tap polyphase convs only)
     if (cfg == TILE_128x128 && L.ks == 2 && L.M >= 128 && p.N > 64 && p.N <= 96) cfg = TILE_128x96;
+    // the last, HBM-bound upsampler (C -> C / 2 with C / 2 * stride <= 32 rows): 32 x 128 tiles (HiFiGAN step -0.06 ms; for the
+    // stride-1 convs of that width — BigVGAN's last stage — the 32 x 512 tile stays: +0.26 ms with the small one)
+    if (cfg == TILE_32x512 && L.transposed) cfg = TILE_32x128;
     // pointwise convs have no halo, so batch and time flatten into one GEMM column axis: no per-item partial tiles
     // (Vocos: T = 94 frames per clip would waste 27 % of a 128-column tile)
     int launch_batch = r.batch;
