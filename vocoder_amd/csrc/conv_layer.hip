@@ -229,7 +229,9 @@ static int choose_tile(int M, long long N, int batch) {
     const double cols_big = (double)tiles_big * nb_big, cols_small = (double)tiles_small * nb_small * 1.04;
     const long long blocks_big = tiles_big * m_blks * batch;
     // not enough workgroups to fill 256 CUs twice over, or a lot of padded columns -> smaller tile
-    if (blocks_big < 512 || cols_small < cols_big) {
+    // (round 3: < 1024 instead of < 512 workgroups — BigVGAN's C = 256 stage is exactly one round of 768 full tiles, every workgroup in
+    //  lock-step: half-width tiles took its B = 64 step from 36.33 to 36.10 ms; HiFiGAN has no launch in that range)
+    if (blocks_big < 1024 || cols_small < cols_big) {
         // still fewer workgroups than CUs: 32 x 64 tiles with K split across the four waves (latency variant)
         const long long blocks_small = tiles_small * m_blks * batch;
         static const long long sk_max = std::getenv("FV_SPLITK_MAX") ? std::atoll(std::getenv("FV_SPLITK_MAX")) : 200;   // experiments
@@ -480,7 +482,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     int cfg = choose_tile(L.M, p.N, r.batch);
     // the stage-0 upsampler of a 1 s clip: 87 GEMM columns per item fill two thirds of a 128-column tile — 128 x 96 tiles (four waves
     // along M, three n-tiles each; instantiated for the two-tap polyphase convs only)
-    if (cfg == TILE_128x128 && L.ks == 2 && L.M >= 128 && p.N > 64 && p.N <= 96) cfg = TILE_128x96;
+    if ((cfg == TILE_128x128 || cfg == TILE_128x64) && L.ks == 2 && L.M >= 128 && p.N > 64 && p.N <= 96) cfg = TILE_128x96;
     // the last, HBM-bound upsampler (C -> C / 2 with C / 2 * stride <= 32 rows): 32 x 128 tiles (HiFiGAN step -0.06 ms; for the
     // stride-1 convs of that width — BigVGAN's last stage — the 32 x 512 tile stays: +0.26 ms with the small one)
     if (cfg == TILE_32x512 && L.transposed) cfg = TILE_32x128;
