@@ -1,0 +1,131 @@
+#!/usr/bin/env python
+"""CPU experiment (runs in the build container only: imports the reference through tests/golden/gen_golden.py): what does
+Winograd F(2,3) tap grouping cost in accuracy?  The dilated k = 3 / 7 / 11 convs of HiFiGAN-V1 / BigVGAN are run three ways —
+float64 (truth), float32 direct, float32 with the taps grouped {0,1,2},{4,5,6},{8,9,10} + single taps 3, 7 on the dilated pair
+lattice (outputs t, t + D from inputs t, t + D, t + 2D, t + 3D), transformed weights rounded to float32 — and the waveforms
+compared.    python tools/experiments/winograd_precision.py [hifigan|bigvgan] [frames]"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+sys.path.insert(0, REPO)
+import gen_golden as gg  # noqa: E402
+from vocoder_amd import synthetic as syn  # noqa: E402
+
+_orig = F.conv1d
+USE = {"on": False}
+
+
+def plan(k):
+    """(groups of three taps starting at even offsets, single taps)"""
+    if k == 3:
+        return [0], []
+    if k == 7:
+        return [0, 4], [3]
+    if k == 11:
+        return [0, 4, 8], [3, 7]
+    return None
+
+
+def wino_conv1d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+    if isinstance(stride, tuple):
+        stride = stride[0]
+    if isinstance(padding, tuple):
+        padding = padding[0]
+    if isinstance(dilation, tuple):
+        dilation = dilation[0]
+    k = w.shape[-1]
+    pl = plan(k)
+    if not USE["on"] or x.dtype != torch.float32 or stride != 1 or groups != 1 or pl is None or w.shape[1] < 16 \
+            or padding != (k - 1) * dilation // 2:
+        return _orig(x, w, b, stride, padding, dilation, groups)
+    D = dilation
+    B, C, T = x.shape
+    Tp = -(-T // (2 * D)) * (2 * D)              # outputs padded to whole blocks of 2D
+    xp = F.pad(x, (padding, Tp - T + padding + 4 * D))   # x'[tau] = x[tau - pad]
+    nq = Tp // (2 * D)
+    # pair-column n = q*D + r  <->  t0 = 2D*q + r
+    n = torch.arange(nq * D + 6 * D)
+    t0 = 2 * D * (n // D) + (n % D)
+    L = xp.shape[-1]
+    ok = t0 + D < L
+    idxE = torch.where(ok, t0, torch.zeros_like(t0))
+    idxO = torch.where(ok, t0 + D, torch.zeros_like(t0))
+    E = xp[..., idxE] * ok
+    O = xp[..., idxO] * ok
+    NP = nq * D
+
+    def sh(a, s):
+        return a[..., s:s + NP]
+
+    m = [torch.zeros(B, w.shape[0], NP) for _ in range(4)]
+    wd = w.double()
+    for j0 in pl[0]:
+        s = (j0 // 2) * D
+        g0, g1, g2 = wd[..., j0], wd[..., j0 + 1], wd[..., j0 + 2]
+        G = [g0.float(), ((g0 + g1 + g2) / 2).float(), ((g0 - g1 + g2) / 2).float(), g2.float()]
+        d = [sh(E, s) - sh(E, s + D), sh(O, s) + sh(E, s + D), sh(E, s + D) - sh(O, s), sh(O, s) - sh(O, s + D)]
+        for p in range(4):
+            m[p] = m[p] + torch.einsum("oc,bcn->bon", G[p], d[p])
+    for j in pl[1]:
+        q = (j - 1) // 2
+        m[0] = m[0] + torch.einsum("oc,bcn->bon", w[..., j], sh(O, q * D))
+        m[3] = m[3] + torch.einsum("oc,bcn->bon", -w[..., j], sh(E, (q + 1) * D))
+    y0 = m[0] + m[1] + m[2]
+    y1 = m[1] - m[2] - m[3]
+    y = torch.zeros(B, w.shape[0], Tp)
+    nn_ = torch.arange(NP)
+    tt = 2 * D * (nn_ // D) + (nn_ % D)
+    y[..., tt] = y0
+    y[..., tt + D] = y1
+    y = y[..., :T]
+    if b is not None:
+        y = y + b[None, :, None]
+    return y
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "hifigan"
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    torch.manual_seed(0)
+    if which == "hifigan":
+        cfg = dict(syn.HIFIGAN_V1_44K)
+        sd = syn.hifigan_state_dict(cfg, 1)
+        g = gg.HiFiGANGenerator(**cfg).eval()
+    else:
+        cfg = dict(syn.BIGVGAN_24K)
+        sd = syn.bigvgan_state_dict(cfg, 1)
+        g = gg.BigVGANGenerator(**cfg).eval()
+    g.load_state_dict(gg._t(sd), strict=True)
+    mel = torch.from_numpy(syn.synthetic_mel(1, cfg["num_mels"], frames, 7))
+    F.conv1d = wino_conv1d
+    torch.nn.functional.conv1d = wino_conv1d
+    with torch.no_grad():
+        # sanity of the restatement itself in one layer
+        x = torch.randn(1, 32, 50)
+        for k, D in ((3, 1), (7, 3), (11, 5), (11, 1), (3, 5)):
+            w = torch.randn(32, 32, k) * 0.1
+            USE["on"] = False
+            a = F.conv1d(x, w, None, 1, (k - 1) * D // 2, D)
+            USE["on"] = True
+            c = wino_conv1d(x, w, None, 1, (k - 1) * D // 2, D)
+            print(f"layer check k={k} D={D}: max diff {float((a - c).abs().max()):.2e}")
+        USE["on"] = False
+        ref64 = g.double()(mel.double()).float()
+        g.float()
+        y32 = g(mel)
+        USE["on"] = True
+        yw = g(mel)
+    print(f"{which} {frames} frames: peak {float(ref64.abs().max()):.3f}")
+    print(f"  fp32 direct   vs fp64: max {float((y32 - ref64).abs().max()):.3e}  rms {float((y32 - ref64).pow(2).mean().sqrt()):.3e}")
+    print(f"  fp32 winograd vs fp64: max {float((yw - ref64).abs().max()):.3e}  rms {float((yw - ref64).pow(2).mean().sqrt()):.3e}")
+    print(f"  winograd vs direct   : max {float((yw - y32).abs().max()):.3e}")
+
+
+if __name__ == "__main__":
+    main()

@@ -142,6 +142,33 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
     FV_HIP_CHECK(hipMalloc((void**)&L.d_bias, bias.size() * sizeof(float)));
     FV_HIP_CHECK(hipMemcpy(L.d_wp, packed.data(), L.wp_bytes, hipMemcpyHostToDevice));
     FV_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!transposed && stride == 1 && (k == 3 || k == 7 || k == 11) && (dil == 1 || dil == 3 || dil == 5) && padding == (k - 1) / 2 * dil &&
+        c_in >= 32 && c_out >= 64) {
+        // Winograd F(2,3) tap groups (conv_wino.hip): groups at taps 0, 4, 8 -> four transformed weights each, the taps between them
+        // (3, 7) -> (+w, -w); virtual-tap order = WinoGeom::off_of / acc_of
+        const int ng = (k + 1) / 4, ns = (k - 3) / 4;
+        L.nv = 4 * ng + 2 * ns;
+        std::vector<float> ww((size_t)c_out * c_in * L.nv);
+        for (size_t oc = 0; oc < (size_t)c_out * c_in; ++oc) {
+            const float* w = &wc[oc * k];
+            float* o = &ww[oc * L.nv];
+            for (int g = 0; g < ng; ++g) {
+                const double g0 = w[4 * g], g1 = w[4 * g + 1], g2 = w[4 * g + 2];
+                o[4 * g + 0] = (float)g0;
+                o[4 * g + 1] = (float)((g0 + g1 + g2) * 0.5);
+                o[4 * g + 2] = (float)((g0 - g1 + g2) * 0.5);
+                o[4 * g + 3] = (float)g2;
+            }
+            for (int s2 = 0; s2 < ns; ++s2) {
+                o[4 * ng + 2 * s2] = w[4 * s2 + 3];
+                o[4 * ng + 2 * s2 + 1] = -w[4 * s2 + 3];
+            }
+        }
+        std::vector<float> pw;
+        pack_conv_weights(ww, L.M, c_in, L.nv, L.m_pad, L.nchunk, pw);
+        FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw, pw.size() * sizeof(float)));
+        FV_HIP_CHECK(hipMemcpy(L.d_wpw, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (with_f16x3 && f16x3_eligible(transposed, c_in, L.M, L.ks, L.dil)) {
         L.nch16 = (c_in + 15) / 16;
         if (L.ks <= 4) L.nch16 = (L.nch16 + 3) / 4 * 4;   // whole LDS chunks of two / four sub-chunks
@@ -194,6 +221,8 @@ void conv_layer_destroy(ConvLayer& L) {
     if (L.d_wp) (void)hipFree(L.d_wp);
     if (L.d_bias) (void)hipFree(L.d_bias);
     if (L.d_wp16) (void)hipFree(L.d_wp16);
+    if (L.d_wpw) (void)hipFree(L.d_wpw);
+    L.d_wpw = nullptr;
     if (L.d_wph) (void)hipFree(L.d_wph);
     if (L.d_wph16) (void)hipFree(L.d_wph16);
     L.d_wph16 = nullptr;
@@ -476,6 +505,40 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         }
     }
 
+    // Winograd F(2,3) tap groups for the dilated ResBlock / AMPBlock convs of launches that fill the chip (conv_wino.hip)
+    if (knobs().wino && L.d_wpw && !p.x2 && L.M >= knobs().wino_min_m) {
+        const int wcfg = L.M >= 128 ? WINO_128x64 : WINO_64x64;
+        int mb, pairs;
+        wino_tile_dims(wcfg, &mb, &pairs);
+        const long long np = (long long)L.dil * ((tout + 2 * L.dil - 1) / (2 * L.dil));   // pair columns: whole blocks of 2 D samples
+        const long long blocks = (long long)r.batch * ((L.M + mb - 1) / mb) * ((np + pairs - 1) / pairs);
+        if (blocks >= 2 * num_cus() || knobs().wino >= 2) {   // (FV_WINO=2: tests force it on small launches)
+            p.wp = L.d_wpw;
+            p.m_blks = (L.M + mb - 1) / mb;
+            p.n_tiles = (int)((np + pairs - 1) / pairs);
+            const int prof_idx = prof_begin(stream);
+            if (!launch_conv_wino(p, wcfg, r.batch, stream)) {
+                set_error("conv_layer_run: no Winograd kernel for (k=%d, dilation=%d)", L.ks, L.dil);
+                return FV_ERR_UNSUPPORTED;
+            }
+            {
+                static thread_local char name[96];
+                std::snprintf(name, sizeof(name), "conv_wino<k=%d d=%d tile=%dx%dp>", L.ks, L.dil, mb, pairs);
+                set_last_kernel(name);
+                if (prof_idx >= 0) {
+                    const double macs = (double)L.c_in * L.c_out * L.k * (double)tout * r.batch;   // ALGORITHMIC (direct-sum) MACs
+                    double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
+                    if (r.res) elems += (double)L.c_out * tout;
+                    if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
+                    char lbl[160];
+                    std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d grid=%lld", name, L.c_in, L.c_out, blocks);
+                    prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
+                }
+                FV_HIP_CHECK(hipGetLastError());
+                return FV_OK;
+            }
+        }
+    }
 #if defined(FV_X_SPLITK_TS) || defined(FV_X_CONV_TS)
     p.dbg_ts = g_sk_ts;
 #endif

@@ -70,32 +70,16 @@ __device__ __forceinline__ void act_apply_all(float (&v)[N], int act, float slop
 // scatter.  acc follows the 32x32 MFMA C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 // All global traffic goes through raw buffer ops on byte offsets relative to the output tensor (masked elements get offset
 // 0xFFFFFFFF: loads return 0, stores are dropped) — no 64-bit address arithmetic, no per-element branches.
+// (conv_epilogue_cols: the caller supplies each n-tile's column offset and validity — conv_wino.hip's columns are output pairs)
 template <int MT, int NT>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][NT], int b, int mt0, int ncol0, int lane) {
+__device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, f32x16 (&acc)[MT][NT], int b, int mt0, const int (&coff)[NT],
+                                                   const bool (&cok)[NT], int lane) {
     // in flat mode the tensor spans all batch items (b == 0), otherwise one item
     const unsigned span = (unsigned)((p.flat ? (long long)p.y_bstride * (p.n_total / p.N) : p.y_bstride) * 4);
     const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
     const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
     const bool has_res = p.res != nullptr;
     const bool accum = p.out_mode == OUT_ACCUM;
-    // column part of the element offset (independent of the row) and its validity
-    int coff[NT];
-    bool cok[NT];
-#pragma unroll
-    for (int jn = 0; jn < NT; ++jn) {
-        const int n = ncol0 + jn * 32;
-        if (p.convt) {
-            coff[jn] = n * p.u - p.pad_t;   // + phase added per row
-            cok[jn] = n < p.N;
-        } else if (p.flat) {
-            const int bb = n / p.N;         // column = (batch item, t)
-            coff[jn] = bb * (int)p.y_bstride + (n - bb * p.N);
-            cok[jn] = n < p.n_total;
-        } else {
-            coff[jn] = n;
-            cok[jn] = n < p.N;
-        }
-    }
 #ifndef FV_X_EPI_ROWS
 #define FV_X_EPI_ROWS 8
 #endif
@@ -158,6 +142,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             for (int q = 0; q < 4 * RG * NT; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[q]), yrs, off[q], 0, 0);
         }
     }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][NT], int b, int mt0, int ncol0, int lane) {
+    // column part of the element offset (independent of the row) and its validity
+    int coff[NT];
+    bool cok[NT];
+#pragma unroll
+    for (int jn = 0; jn < NT; ++jn) {
+        const int n = ncol0 + jn * 32;
+        if (p.convt) {
+            coff[jn] = n * p.u - p.pad_t;   // + phase added per row
+            cok[jn] = n < p.N;
+        } else if (p.flat) {
+            const int bb = n / p.N;         // column = (batch item, t)
+            coff[jn] = bb * (int)p.y_bstride + (n - bb * p.N);
+            cok[jn] = n < p.n_total;
+        } else {
+            coff[jn] = n;
+            cok[jn] = n < p.N;
+        }
+    }
+    conv_epilogue_cols<MT, NT>(p, acc, b, mt0, coff, cok, lane);
 }
 
 #ifndef FV_X_INTERLEAVE

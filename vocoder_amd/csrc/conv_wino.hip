@@ -1,0 +1,244 @@
+// Dilated "same" Conv1d (k = 3 / 7 / 11: the ResBlock / AMPBlock convs, fish_vocoder/modules/generators/hifigan.py:101-108,
+// bigvgan.py:235-245) as an implicit GEMM over Winograd F(2,3) tap groups on the fp32 matrix cores: 16 / 10 / 4 matrix products per
+// output pair and (c_out, c_in) instead of 22 / 14 / 6.
+//
+// Pair lattice.  With dilation D the conv couples samples D apart, so outputs are paired as (t, t + D): pair column
+//   n = q D + r  (0 <= r < D)   <->   t0(n) = 2 D q + r,     E[n] = x'[t0(n)],  O[n] = x'[t0(n) + D],    x'[tau] = act(x[tau - pad])
+// and x'[t0(n) + 2D] = E[n + D], x'[t0(n) + 3D] = O[n + D]: every dilation looks the same in pair columns.
+// Tap groups {0,1,2}, {4,5,6}, {8,9,10} (group g reads pair column n + 2 g D), transformed inputs (four planes, computed once per staged
+// window and shared by all groups and output rows):
+//   d0 = E[n] - E[n+D]    d1 = O[n] + E[n+D]    d2 = E[n+D] - O[n]    d3 = O[n] - O[n+D]
+// transformed weights (host, in double, conv_layer.hip):  g0,  (g0+g1+g2)/2,  (g0-g1+g2)/2,  g2
+// four accumulator planes   m_p += G_p d_p   and   y[t0] = m0 + m1 + m2,   y[t0 + D] = m1 - m2 - m3.
+// The taps between the groups (3, 7) are plain products folded into the same accumulators: w_j O[n + q D] into m0 and
+// -w_j E[n + (q+1) D] into m3, q = (j-1)/2 (m0 only reaches the first output of the pair, m3 only the second, negated).
+// Accuracy: tools/experiments/winograd_precision.py — the HiFiGAN-V1 waveform deviates from float64 by 1.7e-6 this way, 2.0e-6 with the
+// direct fp32 sums (F(2,3) has no large transform constants).
+//
+// Kernel = conv_mfma_kernel's pipeline (conv_mfma_impl.h) with virtual taps: a chunk of 8 / 16 channels is staged into LDS as six
+// planes per channel (d0..d3, E, O), every virtual tap reads one plane at an immediate-offset shifted address and feeds one
+// accumulator plane; weights stream from L2 in the same packed fragment order with NV virtual taps per sub-chunk.  The transform
+// needs E / O of the neighbouring pair column: each wave stages whole channel rows, writes E / O, and reads the neighbours back
+// itself (LDS operations of one wave execute in order) — one workgroup barrier per chunk as before.
+#include "conv_mfma_impl.h"
+
+namespace fv {
+
+template <int KS, int DIL, int WM, int WN, int NT>
+struct WinoGeom {
+    static constexpr int NG = (KS + 1) / 4;            // F(2,3) groups at taps 0, 4, 8
+    static constexpr int NS = (KS - 3) / 4;            // single taps 3, 7
+    static constexpr int NV = 4 * NG + 2 * NS;         // virtual taps = MFMA k-step groups per 8-channel sub-chunk
+    static constexpr int NBP = WN * NT * 32;           // output pairs per workgroup
+    static constexpr int WD = NBP + 2 * DIL * (NG - 1);   // columns of a transformed plane (largest group shift: 2 D (NG - 1))
+    static constexpr int WR = WD + DIL;                // columns of E / O (the transform reads column n + D)
+    static constexpr int ROW = 4 * WD + 2 * WR;        // floats per channel row
+    static constexpr int SUBS = 2 * 16 * ROW * 4 <= 65536 ? 2 : 1;
+    static constexpr int CH = kChunk * SUBS;
+    static constexpr int RPW = CH / 4;                 // channel rows staged by one wave
+    static constexpr int NE = (RPW * WR + 63) / 64;    // (E, O) pairs per lane and chunk
+    static constexpr int acc_of(int v) { return v < 4 * NG ? v % 4 : ((v - 4 * NG) % 2 == 0 ? 0 : 3); }
+    static constexpr int off_of(int v) {               // LDS offset of virtual tap v inside a channel row
+        if (v < 4 * NG) return (v % 4) * WD + 2 * DIL * (v / 4);
+        const int s = (v - 4 * NG) / 2;
+        return (v - 4 * NG) % 2 == 0 ? 4 * WD + WR + (2 * s + 1) * DIL : 4 * WD + (2 * s + 2) * DIL;
+    }
+};
+
+template <int KS, int DIL, int WM, int WN, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    using G = WinoGeom<KS, DIL, WM, WN, NT>;
+    constexpr int NV = G::NV, NBP = G::NBP, WD = G::WD, WR = G::WR, ROW = G::ROW, SUBS = G::SUBS, CH = G::CH, RPW = G::RPW, NE = G::NE;
+    __shared__ float xs[2][CH * ROW];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int bid = blockIdx.x;
+    const int n_tile = bid % p.n_tiles;
+    bid /= p.n_tiles;
+    const int m_blk = bid % p.m_blks;
+    const int b = bid / p.m_blks;
+    const int n0 = n_tile * NBP;
+    const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.f;
+
+    // ---- staging plan: this wave owns channel rows wave * RPW .. + RPW - 1 of every chunk; lane element i = pair column
+    // (lane + 64 i) % WR of row (lane + 64 i) / WR.  Byte offsets relative to the chunk's first row, 0xFFFFFFFF outside [0, Tin)
+    // (raw buffer loads return 0 there, and for rows past C_in through the descriptor's size) ----
+    unsigned voE[NE], voO[NE];
+    int lo[NE];               // LDS float offset of (row, column) inside the chunk buffer
+    unsigned in_mask = 0, d_mask = 0;   // bit i: element exists / also has a transformed value (column < WD)
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        int e = lane + 64 * i;
+        const bool in = e < RPW * WR;
+        e = in ? e : RPW * WR - 1;
+        const int rr = e / WR, c = e - rr * WR;
+        const int n = n0 + c;
+        const int q = n / DIL;
+        const int tE = 2 * DIL * q + (n - q * DIL) - p.pad_l, tO = tE + DIL;
+        const int row = wave * RPW + rr;
+        voE[i] = (in && tE >= 0 && tE < p.Tin) ? (unsigned)(row * p.Tin + tE) * 4u : 0xFFFFFFFFu;
+        voO[i] = (in && tO >= 0 && tO < p.Tin) ? (unsigned)(row * p.Tin + tO) * 4u : 0xFFFFFFFFu;
+        lo[i] = row * ROW + c;
+        in_mask |= in ? 1u << i : 0u;
+        d_mask |= (in && c < WD) ? 1u << i : 0u;
+    }
+    float sE[NE], sO[NE];
+    auto load_chunk = [&](int c) {
+        const int cbase = c * CH;
+        const long long span = p.x_bstride - (long long)cbase * p.Tin;
+        const long long rows = (long long)(p.Cin - cbase) * p.Tin;
+        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)((rows < span ? rows : span) * 4));
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            sE[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, voE[i], 0, 0));
+            sO[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, voO[i], 0, 0));
+        }
+    };
+    auto store_chunk = [&](float* dst) {
+        act_apply_all(sE, p.pre_act, p.slope);   // act(0) == 0 keeps the zero padding
+        act_apply_all(sO, p.pre_act, p.slope);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if (in_mask >> i & 1) {
+                dst[lo[i] + 4 * WD] = sE[i];
+                dst[lo[i] + 4 * WD + WR] = sO[i];
+            }
+        }
+        // the neighbours (column + D of the same row) were written by this wave: its LDS operations execute in order, the fence
+        // only keeps the compiler from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if (d_mask >> i & 1) {
+                const float e1 = dst[lo[i] + 4 * WD + DIL], o1 = dst[lo[i] + 4 * WD + WR + DIL];
+                dst[lo[i]] = sE[i] - e1;
+                dst[lo[i] + WD] = sO[i] + e1;
+                dst[lo[i] + 2 * WD] = e1 - sO[i];
+                dst[lo[i] + 3 * WD] = sO[i] - o1;
+            }
+        }
+    };
+
+    const int mt0 = m_blk * WM + wm;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+    const int wvoff = lane * 16;
+    const int wbase = __builtin_amdgcn_readfirstlane(mt0 * (p.nchunk * NV * 1024));   // bytes per m-tile: nchunk * NV k-step groups of 1 KiB
+    auto load_a = [&](int goff_b) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wbase + goff_b, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    const int b_lane = (lane >> 5) * ROW + wn * (NT * 32) + (lane & 31);
+
+    constexpr int STEPS = SUBS * NV;
+    constexpr int DA = kWeightPrefetch;
+    float4 aq[DA + 1];
+    float b_cur[4][NT], b_nxt[4][NT];
+    const int nch = (p.nchunk_real + SUBS - 1) / SUBS;
+    load_chunk(0);
+#pragma unroll
+    for (int d = 0; d < DA; ++d) aq[d] = load_a(d * 1024);
+    for (int c = 0; c < nch; ++c) {
+        float* xsb = xs[c & 1];
+        store_chunk(xsb);
+        __syncthreads();
+        if (c + 1 < nch) load_chunk(c + 1);
+        const int gchunk_b = __builtin_amdgcn_readfirstlane((c * STEPS + DA) * 1024);
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) b_cur[pp][jn] = xsb[b_lane + 2 * pp * ROW + jn * 32 + G::off_of(0)];
+        static_for<STEPS>([&](auto st_c) __attribute__((always_inline)) {
+            constexpr int st = decltype(st_c)::value;
+            constexpr int A = G::acc_of(st % NV);
+            constexpr int NM = 4 * NT, NLDX = 1 + 4 * NT;
+            constexpr int sub_n = (st + 1) / NV, off_n = G::off_of((st + 1) % NV);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int pp = m / NT, jn = m % NT;
+                const float av = pp == 0 ? aq[0].x : pp == 1 ? aq[0].y : pp == 2 ? aq[0].z : aq[0].w;
+                acc[A][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[pp][jn], acc[A][jn], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < NLDX; ++k) {
+                    if (k * NM / NLDX == m) {
+                        if (k == 0) {
+                            aq[DA] = load_a(gchunk_b + st * 1024);
+                        } else if constexpr (st + 1 < STEPS) {
+                            const int pp2 = (k - 1) / NT, jn2 = (k - 1) % NT;
+                            b_nxt[pp2][jn2] = xsb[b_lane + (sub_n * kChunk + 2 * pp2) * ROW + jn2 * 32 + off_n];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < DA; ++d) aq[d] = aq[d + 1];
+            if constexpr (st + 1 < STEPS) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn) b_cur[pp][jn] = b_nxt[pp][jn];
+            }
+        });
+    }
+
+    // output transform + the shared fused epilogue: n-tile jn of the wave becomes two column sets, t0(n) and t0(n) + D
+#pragma unroll
+    for (int jn = 0; jn < NT; ++jn) {
+        f32x16 out[1][2];
+        out[0][0] = (acc[0][jn] + acc[1][jn]) + acc[2][jn];
+        out[0][1] = (acc[1][jn] - acc[2][jn]) - acc[3][jn];
+        const int n = n0 + wn * (NT * 32) + jn * 32 + (lane & 31);
+        const int q = n / DIL;
+        const int ta = 2 * DIL * q + (n - q * DIL);
+        const int coff[2] = {ta, ta + DIL};
+        const bool cok[2] = {ta < p.N, ta + DIL < p.N};
+        conv_epilogue_cols<1, 2>(p, out, b, mt0, coff, cok, lane);
+    }
+}
+
+template <int KS, int DIL>
+static bool launch_wino_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
+    const int grid = batch * p.m_blks * p.n_tiles;
+    switch (cfg) {
+        case WINO_128x64: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 4, 1, 2>), dim3(grid), dim3(256), 0, s, p); return true;
+        case WINO_64x64: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 2, 2, 1>), dim3(grid), dim3(256), 0, s, p); return true;
+        default: return false;
+    }
+}
+
+void wino_tile_dims(int cfg, int* m_blk, int* pairs) {
+    *m_blk = cfg == WINO_128x64 ? 128 : 64;
+    *pairs = 64;
+}
+
+bool launch_conv_wino(const ConvParams& p, int cfg, int batch, hipStream_t s) {
+    switch (p.ks * 8 + p.dil) {
+        case 3 * 8 + 1: return launch_wino_cfg<3, 1>(p, cfg, batch, s);
+        case 3 * 8 + 3: return launch_wino_cfg<3, 3>(p, cfg, batch, s);
+        case 3 * 8 + 5: return launch_wino_cfg<3, 5>(p, cfg, batch, s);
+        case 7 * 8 + 1: return launch_wino_cfg<7, 1>(p, cfg, batch, s);
+        case 7 * 8 + 3: return launch_wino_cfg<7, 3>(p, cfg, batch, s);
+        case 7 * 8 + 5: return launch_wino_cfg<7, 5>(p, cfg, batch, s);
+        case 11 * 8 + 1: return launch_wino_cfg<11, 1>(p, cfg, batch, s);
+        case 11 * 8 + 3: return launch_wino_cfg<11, 3>(p, cfg, batch, s);
+        case 11 * 8 + 5: return launch_wino_cfg<11, 5>(p, cfg, batch, s);
+        default: return false;
+    }
+}
+
+}  // namespace fv

@@ -65,6 +65,8 @@ static void load_knobs() {
     k.dwln_ng8 = std::getenv("FV_DWLN_NG8") != nullptr;
     k.dwln_rr = std::getenv("FV_DWLN_RR") != nullptr;
     k.old_dwln = std::getenv("FV_OLD_DWLN") != nullptr;
+    if (const char* v = std::getenv("FV_WINO")) k.wino = std::atoi(v);
+    if (const char* v = std::getenv("FV_WINO_MIN_M")) k.wino_min_m = std::atoi(v);
     g_knobs = k;
     g_knobs_loaded = true;
 }

@@ -25,6 +25,8 @@ struct Knobs {
     int pw = -2;          // FV_PW: forced gemm_pw configuration, -1 = "old" (the conv kernel), -2 = unset
     int pw_px = 0;        // FV_PW_PX: forced XCD row groups, 0 = unset
     bool dwln_ng8 = false, dwln_rr = false, old_dwln = false;   // FV_DWLN_NG8 / FV_DWLN_RR / FV_OLD_DWLN
+    int wino = 0;         // FV_WINO: 1 = Winograd F(2,3) tap groups for the dilated k = 3 / 7 / 11 convs (conv_wino.hip)
+    int wino_min_m = 128; // FV_WINO_MIN_M: narrowest layer (output rows) that takes it
 };
 const Knobs& knobs();
 
@@ -131,6 +133,8 @@ struct ConvLayer {
     // GEMM view
     int M = 0, ks = 0, pad_l = 0, nchunk = 0, nchunk_real = 0, m_pad = 0;
     float4* d_wp = nullptr;
+    float4* d_wpw = nullptr;   // Winograd-transformed weights in the same fragment order, nv virtual taps (conv_wino.hip); optional
+    int nv = 0;
     float4* d_wp16 = nullptr;  // 16x16x4-fragment layout, only for 16 -> 16 channel Conv1d (fused pair kernel)
     void* d_wph16 = nullptr;   // f16x3 mode, 16 -> 16 channel Conv1d: (wh, wl) planes of the two-samples-per-row layout (pair16_f16x3.hip)
     void* d_wph = nullptr;     // f16x3 mode: (wh, wl, wh * 2^-11) fp16 planes in 32x32x16 fragment order (optional)
@@ -234,6 +238,10 @@ bool launch_amp_conv(const ConvLayer& L, const float* x, float* y, const float* 
 // Tile configurations (block = 4 waves): rows = WM*MT*32, cols = WN*NT*32.
 enum TileCfg : int { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2, TILE_128x64 = 3, TILE_32x128 = 4, TILE_64x128 = 5, TILE_SPLITK_32x64 = 6, TILE_SPLITK_32x32 = 7, TILE_256x64 = 8, TILE_256x32 = 9, TILE_128x96 = 10, TILE_COUNT };
 void tile_dims(int cfg, int* m_blk, int* n_blk);
+// conv_wino.hip: Winograd F(2,3) variant of the dilated "same" convs; tiles = output rows x output PAIRS per workgroup
+enum WinoCfg : int { WINO_128x64 = 0, WINO_64x64 = 1, WINO_COUNT };
+void wino_tile_dims(int cfg, int* m_blk, int* pairs);
+bool launch_conv_wino(const ConvParams& p, int cfg, int batch, hipStream_t s);   // p.wp = the layer's d_wpw, p.n_tiles in pair columns
 
 // ---------------------------------------------------------------------------------------------
 // Small fused kernels (elementwise / narrow-output / reduction)
