@@ -265,6 +265,18 @@ def cpu_baseline(cfg, sd, clips: int, frames: int) -> dict:
 # ------------------------------------------------------------------------------------------------------------------
 # roofline
 # ------------------------------------------------------------------------------------------------------------------
+_WINO_PRODUCTS = {3: 4 / 6, 7: 10 / 14, 11: 16 / 22}   # matrix products per output pair: Winograd F(2,3) tap groups / direct sum
+
+
+def executed_flops(rec: dict) -> float:
+    """MFMA flops a launch really issues: the algorithmic (direct-sum) count, except for the Winograd convs (conv_wino_impl.h), which
+    compute the same outputs with 4 / 10 / 16 products per output pair instead of 6 / 14 / 22."""
+    k = rec["kernel"]
+    if k.startswith("conv_wino<k="):
+        return rec["flops_per_launch"] * _WINO_PRODUCTS[int(k[len("conv_wino<k="):].split()[0])]
+    return rec["flops_per_launch"]
+
+
 def roofline_from_profile(table: list[dict], repeats: int) -> dict:
     """Dominant kernel = largest total time in the forward.  `achieved` = algorithmic flops (or bytes) per launch divided
     by its average hipEvent duration."""
@@ -293,6 +305,12 @@ def roofline_from_profile(table: list[dict], repeats: int) -> dict:
             traffic = None
     if t_mfma >= t_hbm:
         out = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf}
+        ex = executed_flops(top)
+        if ex != top["flops_per_launch"]:
+            out.update({"executed": ex / t_s / 1e12, "frac_executed": ex / t_s / 1e12 / peak_tf, "executed_flops_per_launch": ex,
+                        "note": "achieved / frac count the ALGORITHMIC flops of the layer (2 C_in C_out k T B, the direct sum the reference "
+                                "computes); this kernel produces the same outputs from Winograd F(2,3) tap groups, so the matrix pipe issues "
+                                "executed_flops_per_launch: frac_executed is its utilisation against the fp32 MFMA peak"})
         if peak_tf != PEAK_MFMA_F32_TFLOPS:
             out["peak_note"] = "dense fp16 MFMA peak 2500 TFLOP/s / 3 products per MAC (f16x3 split)"
     else:
@@ -307,7 +325,11 @@ def roofline_from_profile(table: list[dict], repeats: int) -> dict:
 def step_roofline(table, repeats, ms_per_step, peak_tf=PEAK_MFMA_F32_TFLOPS) -> dict:
     flops = sum(r["flops_per_launch"] * (r["launches"] // repeats) for r in table)
     ach = flops / (ms_per_step * 1e-3) / 1e12
-    return {"flops_per_step": flops, "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf}
+    ex = sum(executed_flops(r) * (r["launches"] // repeats) for r in table)
+    out = {"flops_per_step": flops, "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf}
+    if ex != flops:   # Winograd convs in the step: algorithmic flops above, issued MFMA flops here
+        out.update({"executed_flops_per_step": ex, "frac_executed": ex / (ms_per_step * 1e-3) / 1e12 / peak_tf})
+    return out
 
 
 def time_engine(eng, mel, out, steps, warmup, dev) -> float:

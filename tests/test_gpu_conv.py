@@ -259,3 +259,39 @@ def test_fast_gelu_of_the_pointwise_gemm_against_the_exact_function():
     err = np.abs(y - exact)
     assert err.max() <= 1e-6, err.max()
     assert err[:, 0, :].max() <= 1e-6
+
+
+WINO_CASES = [
+    # (C, k, dil, B, T): ragged lengths (odd, below one block of 2 D samples, one sample), several row blocks, every tile variant
+    (128, 11, 1, 1, 517), (128, 7, 3, 2, 300), (128, 3, 5, 1, 131), (256, 11, 5, 1, 97), (256, 3, 1, 2, 200), (192, 7, 5, 1, 1000),
+    (64, 11, 3, 2, 700), (64, 7, 1, 1, 129), (64, 3, 3, 1, 64), (40, 7, 5, 1, 333), (128, 11, 5, 1, 9), (128, 7, 3, 1, 1),
+    (32, 11, 5, 2, 900), (32, 7, 3, 1, 77), (96, 11, 1, 1, 255), (32, 3, 1, 1, 2),
+]
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+def test_winograd_conv_matches_oracle(cfg, monkeypatch):
+    """conv_wino_impl.h through fv_conv_* with the kernel forced (FV_WINO=2) and every tile variant (FV_WINO_CFG): SiLU + bias + residual
+    and the plain conv against the CPU oracle; the direct-sum kernel on the same layer for scale (both sit ~1e-6 from the oracle)."""
+    from vocoder_amd import _lib
+    monkeypatch.setenv("FV_WINO", "2")
+    monkeypatch.setenv("FV_WINO_CFG", str(cfg))
+    _lib.reload_env()
+    try:
+        for (c, k, d, B, T) in WINO_CASES:
+            rng = np.random.default_rng(c * 1000 + k * 7 + d + T)
+            x = rng.normal(size=(B, c, T)).astype(np.float32)
+            w = (rng.normal(size=(c, c, k)) / np.sqrt(c * k)).astype(np.float32)
+            b = rng.normal(size=c).astype(np.float32)
+            pad = (k - 1) * d // 2
+            ref = orc.conv1d(orc.silu(x), w, b, dilation=d, padding=pad)
+            res = rng.normal(size=ref.shape).astype(np.float32)
+            y = _run(w, b, x, res, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
+            assert _lib.last_kernel().startswith("conv_wino<"), (_lib.last_kernel(), c, k, d)
+            _check(y, ref + res)
+            y2 = _run(w, None, x, None, dilation=d, padding=pad)
+            _check(y2, orc.conv1d(x, w, None, dilation=d, padding=pad))
+    finally:
+        monkeypatch.delenv("FV_WINO")
+        monkeypatch.delenv("FV_WINO_CFG")
+        _lib.reload_env()

@@ -872,8 +872,20 @@ def test_bench_runs_its_collectives_on_a_one_rank_rccl_group():
         assert j["output_finite"] and j["ms_per_step_eager"] > 0 and j["mixed_shapes"]["output_finite"]
 
 
+@pytest.fixture
+def direct_sums(monkeypatch):
+    """Bit-for-bit comparisons between launch sequences hold between kernels that add the same products in the same order: keep the
+    Winograd F(2,3) convs (conv_wino_impl.h, same results to ~1e-6 but other sums) out of both sides."""
+    from vocoder_amd import _lib
+    monkeypatch.setenv("FV_WINO", "0")
+    _lib.reload_env()
+    yield
+    monkeypatch.delenv("FV_WINO")
+    _lib.reload_env()
+
+
 @pytest.mark.parametrize("maxk", ["3", "11"])
-def test_bigvgan_fused_amp_convs_equal_the_activation_plus_conv_launches(maxk, monkeypatch):
+def test_bigvgan_fused_amp_convs_equal_the_activation_plus_conv_launches(maxk, monkeypatch, direct_sums):
     """amp_conv.hip (AMPBlock conv with its anti-aliased SnakeBeta fused in front, bigvgan.py:235-245) against the aa_snake + conv
     launches it replaces: the same arithmetic in the same order, so full-size tiles agree bit for bit; every kernel size (the
     default fuses k = 3 only), sequence ends inside a tile (replicate padding of both FIRs, zero padding of the conv), ragged T;
@@ -904,7 +916,7 @@ def test_bigvgan_fused_amp_convs_equal_the_activation_plus_conv_launches(maxk, m
     plain.close()
 
 
-def test_round3_fusions_are_bit_identical_to_the_launches_they_replace(monkeypatch):
+def test_round3_fusions_are_bit_identical_to_the_launches_they_replace(monkeypatch, direct_sums):
     """Round-3 engine paths against the launch sequences they replace, on a batch large enough to take them (C = 128 pairs need
     tiles >= 2 x CUs): k = 3 (c1, c2) pairs at C = 128 (FV_PAIR_MAXC=64 keeps them per layer) and the last stage's branch mean formed
     inside conv_post (FV_NO_POST_SUM3=1 keeps mean_of_three_kernel).  Same k-step order / same additions: bit for bit."""
@@ -925,3 +937,53 @@ def test_round3_fusions_are_bit_identical_to_the_launches_they_replace(monkeypat
         assert torch.equal(y, y2), (var, float((y - y2).abs().max()))
         eng.close()
     base.close()
+
+
+@pytest.mark.parametrize("model", ["hifigan", "bigvgan"])
+def test_winograd_convs_against_the_direct_sums_and_the_oracle(model, monkeypatch):
+    """conv_wino_impl.h (Winograd F(2,3) tap groups for the dilated k = 3 / 7 / 11 convs of launches that fill the chip) in the whole
+    forward: the B = 32 / 64 step takes it (profile), equals the direct-sum engine within 2e-5 of full scale (the north_star bar is 1e-4; both
+    are ~2e-6 from a float64 forward, tools/experiments/winograd_precision.py), is deterministic, and the same engine forced onto
+    the Winograd kernels for short clips (FV_WINO=2) stays within the bar of the CPU oracle."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, upsampler_config
+    if model == "hifigan":
+        cfg = dict(syn.HIFIGAN_V1_44K)
+        sd = syn.hifigan_state_dict(cfg, seed=9)
+        mk = lambda: _hifigan_engine(cfg, sd)   # noqa: E731
+        B, T, ref_fn = 32, 86, orc.hifigan_forward
+    else:
+        cfg = dict(syn.BIGVGAN_24K)
+        sd = syn.bigvgan_state_dict(cfg, 9)
+        mk = lambda: Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=sd)   # noqa: E731
+        B, T, ref_fn = 64, 47, orc.bigvgan_forward
+    x = torch.from_numpy(syn.synthetic_mel(B, 80, T, seed=55)).to(_dev())
+    try:
+        eng = mk()
+        y = eng(x).clone()
+        torch.cuda.synchronize()
+        prof = eng.profile(x, repeats=1)
+        wino = [r["kernel"] for r in prof if r["kernel"].startswith("conv_wino<")]
+        assert any("k=11" in k for k in wino) and any("k=7" in k for k in wino), [r["kernel"] for r in prof][:20]
+        assert torch.equal(eng(x), y)
+        monkeypatch.setenv("FV_WINO", "0")
+        _lib.reload_env()
+        direct = mk()   # (a fresh engine: the first one replays its captured launch sequence for this input)
+        y0 = direct(x).clone()
+        torch.cuda.synchronize()
+        assert not any(r["kernel"].startswith("conv_wino<") for r in direct.profile(x, repeats=1))
+        direct.close()
+        d = float((y - y0).abs().max())
+        assert 0 < d <= 2e-5, d
+        monkeypatch.setenv("FV_WINO", "2")
+        _lib.reload_env()
+        for b, t in ((2, 9), (1, 1), (3, 24)):
+            mel = syn.synthetic_mel(b, 80, t, seed=t)
+            ref = ref_fn(sd, cfg, mel)
+            err = np.abs(_fwd(eng, mel) - ref).max()
+            assert err <= TOL, (b, t, err)
+        assert any(r["kernel"].startswith("conv_wino<") for r in eng.profile(torch.from_numpy(syn.synthetic_mel(1, 80, 9, seed=1)).to(_dev()), repeats=1))
+        eng.close()
+    finally:
+        monkeypatch.delenv("FV_WINO", raising=False)
+        _lib.reload_env()

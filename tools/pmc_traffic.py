@@ -13,6 +13,10 @@ def key_of(kernel_name: str, grid_threads: int):
     if m:
         ks, dil, wm, wn, mt, nt = map(int, m.groups())
         return f"conv_mfma k={ks} d={dil} tile={wm * mt * 32}x{wn * nt * 32} grid={blocks}"
+    m = re.search(r"conv_wino_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", kernel_name)   # tile = rows x output PAIRS
+    if m:
+        ks, dil, wm, wn, nt = map(int, m.groups())
+        return f"conv_wino k={ks} d={dil} tile={wm * 32}x{wn * nt * 32}p grid={blocks}"
     m = re.search(r"conv_mfma_splitk_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", kernel_name)
     if m:
         return f"conv_mfma k={m.group(1)} d={m.group(2)} tile=splitK32x{32 * int(m.group(3))} grid={blocks}"
@@ -41,6 +45,9 @@ def bench_key(label: str):
     m = re.search(r"conv_mfma<\w+ k=(\d+) d=(\d+) tile=(\w+)>.*grid=(\d+)", label)
     if m:
         return f"conv_mfma k={m.group(1)} d={m.group(2)} tile={m.group(3)} grid={m.group(4)}"
+    m = re.search(r"conv_wino<k=(\d+) d=(\d+) tile=(\w+)>.*grid=(\d+)", label)
+    if m:
+        return f"conv_wino k={m.group(1)} d={m.group(2)} tile={m.group(3)} grid={m.group(4)}"
     m = re.search(r"conv_f16x3<k=(\d+) d=(\d+) tile=(\w+)>.*grid=(\d+)", label)
     if m:
         return f"conv_f16x3 k={m.group(1)} d={m.group(2)} tile={m.group(3)} grid={m.group(4)}"

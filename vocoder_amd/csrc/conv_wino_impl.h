@@ -20,6 +20,7 @@
 // accumulator plane; weights stream from L2 in the same packed fragment order with NV virtual taps per sub-chunk.  The transform
 // needs E / O of the neighbouring pair column: each wave stages whole channel rows, writes E / O, and reads the neighbours back
 // itself (LDS operations of one wave execute in order) — one workgroup barrier per chunk as before.
+#pragma once
 #include "conv_mfma_impl.h"
 
 namespace fv {
@@ -46,7 +47,10 @@ struct WinoGeom {
 };
 
 template <int KS, int DIL, int WM, int WN, int NT>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
+#ifndef FV_X_WINO_OCC1
+#define FV_X_WINO_OCC1 3
+#endif
+__global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino_kernel(const ConvParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     using G = WinoGeom<KS, DIL, WM, WN, NT>;
     constexpr int NV = G::NV, NBP = G::NBP, WD = G::WD, WR = G::WR, ROW = G::ROW, SUBS = G::SUBS, CH = G::CH, RPW = G::RPW, NE = G::NE;
@@ -144,7 +148,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     const int b_lane = (lane >> 5) * ROW + wn * (NT * 32) + (lane & 31);
 
     constexpr int STEPS = SUBS * NV;
-    constexpr int DA = kWeightPrefetch;
+#ifndef FV_X_WINO_DA
+#define FV_X_WINO_DA 3
+#endif
+    constexpr int DA = FV_X_WINO_DA;   // weight prefetch distance in virtual taps (4 NT MFMAs each)
     float4 aq[DA + 1];
     float b_cur[4][NT], b_nxt[4][NT];
     const int nch = (p.nchunk_real + SUBS - 1) / SUBS;
@@ -212,31 +219,24 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
 }
 
 template <int KS, int DIL>
-static bool launch_wino_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
+inline bool launch_wino_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
     const int grid = batch * p.m_blks * p.n_tiles;
     switch (cfg) {
         case WINO_128x64: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 4, 1, 2>), dim3(grid), dim3(256), 0, s, p); return true;
+        case WINO_128x32: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 4, 1, 1>), dim3(grid), dim3(256), 0, s, p); return true;
         case WINO_64x64: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 2, 2, 1>), dim3(grid), dim3(256), 0, s, p); return true;
+        case WINO_64x128: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 2, 2, 2>), dim3(grid), dim3(256), 0, s, p); return true;
+        case WINO_32x128: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 1, 4, 1>), dim3(grid), dim3(256), 0, s, p); return true;
         default: return false;
     }
 }
 
-void wino_tile_dims(int cfg, int* m_blk, int* pairs) {
-    *m_blk = cfg == WINO_128x64 ? 128 : 64;
-    *pairs = 64;
-}
-
-bool launch_conv_wino(const ConvParams& p, int cfg, int batch, hipStream_t s) {
-    switch (p.ks * 8 + p.dil) {
-        case 3 * 8 + 1: return launch_wino_cfg<3, 1>(p, cfg, batch, s);
-        case 3 * 8 + 3: return launch_wino_cfg<3, 3>(p, cfg, batch, s);
-        case 3 * 8 + 5: return launch_wino_cfg<3, 5>(p, cfg, batch, s);
-        case 7 * 8 + 1: return launch_wino_cfg<7, 1>(p, cfg, batch, s);
-        case 7 * 8 + 3: return launch_wino_cfg<7, 3>(p, cfg, batch, s);
-        case 7 * 8 + 5: return launch_wino_cfg<7, 5>(p, cfg, batch, s);
-        case 11 * 8 + 1: return launch_wino_cfg<11, 1>(p, cfg, batch, s);
-        case 11 * 8 + 3: return launch_wino_cfg<11, 3>(p, cfg, batch, s);
-        case 11 * 8 + 5: return launch_wino_cfg<11, 5>(p, cfg, batch, s);
+template <int KS>
+inline bool launch_wino_k(const ConvParams& p, int cfg, int batch, hipStream_t s) {
+    switch (p.dil) {
+        case 1: return launch_wino_cfg<KS, 1>(p, cfg, batch, s);
+        case 3: return launch_wino_cfg<KS, 3>(p, cfg, batch, s);
+        case 5: return launch_wino_cfg<KS, 5>(p, cfg, batch, s);
         default: return false;
     }
 }

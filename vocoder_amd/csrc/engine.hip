@@ -67,6 +67,7 @@ static void load_knobs() {
     k.old_dwln = std::getenv("FV_OLD_DWLN") != nullptr;
     if (const char* v = std::getenv("FV_WINO")) k.wino = std::atoi(v);
     if (const char* v = std::getenv("FV_WINO_MIN_M")) k.wino_min_m = std::atoi(v);
+    if (const char* v = std::getenv("FV_WINO_CFG")) k.wino_cfg = std::atoi(v);
     g_knobs = k;
     g_knobs_loaded = true;
 }

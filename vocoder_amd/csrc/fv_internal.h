@@ -25,8 +25,10 @@ struct Knobs {
     int pw = -2;          // FV_PW: forced gemm_pw configuration, -1 = "old" (the conv kernel), -2 = unset
     int pw_px = 0;        // FV_PW_PX: forced XCD row groups, 0 = unset
     bool dwln_ng8 = false, dwln_rr = false, old_dwln = false;   // FV_DWLN_NG8 / FV_DWLN_RR / FV_OLD_DWLN
-    int wino = 0;         // FV_WINO: 1 = Winograd F(2,3) tap groups for the dilated k = 3 / 7 / 11 convs (conv_wino.hip)
-    int wino_min_m = 128; // FV_WINO_MIN_M: narrowest layer (output rows) that takes it
+    int wino = 1;         // FV_WINO: 0 = direct sums only, 1 = Winograd F(2,3) tap groups for the dilated k = 3 / 7 / 11 convs of launches that
+                          // fill the chip (conv_wino_impl.h), 2 = for every eligible launch (tests)
+    int wino_min_m = 32;  // FV_WINO_MIN_M: narrowest layer (output rows) that takes it
+    int wino_cfg = -1;    // FV_WINO_CFG: forced tile (WinoCfg), -1 = by shape
 };
 const Knobs& knobs();
 
@@ -239,9 +241,11 @@ bool launch_amp_conv(const ConvLayer& L, const float* x, float* y, const float* 
 enum TileCfg : int { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2, TILE_128x64 = 3, TILE_32x128 = 4, TILE_64x128 = 5, TILE_SPLITK_32x64 = 6, TILE_SPLITK_32x32 = 7, TILE_256x64 = 8, TILE_256x32 = 9, TILE_128x96 = 10, TILE_COUNT };
 void tile_dims(int cfg, int* m_blk, int* n_blk);
 // conv_wino.hip: Winograd F(2,3) variant of the dilated "same" convs; tiles = output rows x output PAIRS per workgroup
-enum WinoCfg : int { WINO_128x64 = 0, WINO_64x64 = 1, WINO_COUNT };
-void wino_tile_dims(int cfg, int* m_blk, int* pairs);
-bool launch_conv_wino(const ConvParams& p, int cfg, int batch, hipStream_t s);   // p.wp = the layer's d_wpw, p.n_tiles in pair columns
+enum WinoCfg : int { WINO_128x64 = 0, WINO_128x32 = 1, WINO_64x64 = 2, WINO_64x128 = 3, WINO_32x128 = 4, WINO_COUNT };
+// p.wp = the layer's d_wpw, p.n_tiles in pair columns
+bool launch_conv_wino_k3(const ConvParams& p, int cfg, int batch, hipStream_t s);
+bool launch_conv_wino_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
+bool launch_conv_wino_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Small fused kernels (elementwise / narrow-output / reduction)
