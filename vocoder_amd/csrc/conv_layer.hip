@@ -516,7 +516,10 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         if (knobs().wino_cfg >= 0 && knobs().wino_cfg < WINO_COUNT) wcfg = knobs().wino_cfg;
         const int mb = wdims[wcfg][0], pairs = wdims[wcfg][1];
         const long long blocks = blocks_of(wcfg);
-        if (blocks >= 2 * num_cus() || knobs().wino >= 2) {   // (FV_WINO=2: tests force it on small launches)
+        // launches of at least half a workgroup per CU: measured per batch size (tools/sweep_wino_batch.py) — HiFiGAN-V1 B = 2 ... 32 -12 ... -16 %
+        // against the direct kernels with this gate, a single clip (86 workgroups at C = 128) +17 % without it
+        const long long min_blocks = knobs().wino_min_blocks >= 0 ? knobs().wino_min_blocks : num_cus() / 2;
+        if (blocks >= min_blocks || knobs().wino >= 2) {   // (FV_WINO=2: tests force it on small launches)
             p.wp = L.d_wpw;
             p.m_blks = (L.M + mb - 1) / mb;
             p.n_tiles = (int)((np + pairs - 1) / pairs);

@@ -33,18 +33,86 @@ struct WinoGeom {
     static constexpr int NBP = WN * NT * 32;           // output pairs per workgroup
     static constexpr int WD = NBP + 2 * DIL * (NG - 1);   // columns of a transformed plane (largest group shift: 2 D (NG - 1))
     static constexpr int WR = WD + DIL;                // columns of E / O (the transform reads column n + D)
-    static constexpr int ROW = 4 * WD + 2 * WR;        // floats per channel row
-    static constexpr int SUBS = 2 * 16 * ROW * 4 <= 65536 ? 2 : 1;
+    static constexpr int ROW = 6 * WR;                 // floats per channel row: six planes of WR columns (d0..d3 use the first WD)
+    // 8-channel sub-chunks per LDS chunk (= per workgroup barrier): as many as fit the budget that leaves three workgroups per CU
+#ifndef FV_X_WINO_LDS
+#define FV_X_WINO_LDS (53 * 1024)
+#endif
+#ifndef FV_X_WINO_SUBS_MAX
+#define FV_X_WINO_SUBS_MAX 4
+#endif
+    static constexpr int subs_fit(int s) { return (s > 1 && 2 * kChunk * s * ROW * 4 > FV_X_WINO_LDS) ? subs_fit(s / 2) : s; }
+    static constexpr int SUBS = subs_fit(FV_X_WINO_SUBS_MAX);
     static constexpr int CH = kChunk * SUBS;
     static constexpr int RPW = CH / 4;                 // channel rows staged by one wave
     static constexpr int NE = (RPW * WR + 63) / 64;    // (E, O) pairs per lane and chunk
     static constexpr int acc_of(int v) { return v < 4 * NG ? v % 4 : ((v - 4 * NG) % 2 == 0 ? 0 : 3); }
     static constexpr int off_of(int v) {               // LDS offset of virtual tap v inside a channel row
-        if (v < 4 * NG) return (v % 4) * WD + 2 * DIL * (v / 4);
+        if (v < 4 * NG) return (v % 4) * WR + 2 * DIL * (v / 4);
         const int s = (v - 4 * NG) / 2;
-        return (v - 4 * NG) % 2 == 0 ? 4 * WD + WR + (2 * s + 1) * DIL : 4 * WD + (2 * s + 2) * DIL;
+        return (v - 4 * NG) % 2 == 0 ? 5 * WR + (2 * s + 1) * DIL : 4 * WR + (2 * s + 2) * DIL;
     }
 };
+
+// conv_epilogue_cols' arithmetic (conv_mfma_impl.h) for dilation 1 and an even length: output pair n = samples (2n, 2n + 1) of a row,
+// moved with 8-byte buffer operations (half the vector-memory instructions, whole 8-byte segments per lane).
+__device__ __forceinline__ void wino_epilogue_d1(const ConvParams& p, const f32x16& y0, const f32x16& y1, int b, int mt, int n, int lane) {
+    const unsigned span = (unsigned)(p.y_bstride * 4);
+    const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
+    const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
+    const bool has_res = p.res != nullptr;
+    const bool accum = p.out_mode == OUT_ACCUM;
+    const bool cok = 2 * n < p.N;
+#pragma unroll
+    for (int rq0 = 0; rq0 < 4; rq0 += 2) {
+        unsigned off[8];
+        float v0[8], v1[8];
+        u32x2 rv[8], yo[8];
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+            const int rq = rq0 + r8 / 4, rr = r8 % 4;
+            const int m = mt * 32 + rr + 8 * rq + 4 * (lane >> 5);
+            const bool mok = m < p.M;
+            const int mc = mok ? m : 0;
+            const float bias = p.bias[mc];
+            const float gm = p.gamma ? p.gamma[mc] : 1.0f;
+            off[r8] = (mok && cok) ? (unsigned)(mc * p.N + 2 * n) * 4u : 0xFFFFFFF8u;
+            v0[r8] = fmaf(y0[rq * 4 + rr], p.acc_scale, bias) * gm;
+            v1[r8] = fmaf(y1[rq * 4 + rr], p.acc_scale, bias) * gm;
+        }
+        if (has_res) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rv[q] = __builtin_amdgcn_raw_buffer_load_b64(rrs, off[q], 0, 0);
+        }
+        if (accum) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) yo[q] = __builtin_amdgcn_raw_buffer_load_b64(yrs, off[q], 0, 0);
+        }
+        if (has_res) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                v0[q] += __uint_as_float(rv[q].x);
+                v1[q] += __uint_as_float(rv[q].y);
+            }
+        }
+        act_apply_all(v0, p.post_act, p.slope);
+        act_apply_all(v1, p.post_act, p.slope);
+        if (accum) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                v0[q] = (__uint_as_float(yo[q].x) + v0[q]) * p.out_scale;
+                v1[q] = (__uint_as_float(yo[q].y) + v1[q]) * p.out_scale;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            u32x2 o;
+            o.x = __float_as_uint(v0[q]);
+            o.y = __float_as_uint(v1[q]);
+            __builtin_amdgcn_raw_buffer_store_b64(o, yrs, off[q], 0, 0);
+        }
+    }
+}
 
 template <int KS, int DIL, int WM, int WN, int NT>
 #ifndef FV_X_WINO_OCC1
@@ -54,7 +122,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
     static_assert(WM * WN == 4, "4 waves per workgroup");
     using G = WinoGeom<KS, DIL, WM, WN, NT>;
     constexpr int NV = G::NV, NBP = G::NBP, WD = G::WD, WR = G::WR, ROW = G::ROW, SUBS = G::SUBS, CH = G::CH, RPW = G::RPW, NE = G::NE;
-    __shared__ float xs[2][CH * ROW];
+    __shared__ float xs[2][CH * ROW + 8];   // (+ 8: the transform of the last row's unused columns reads D floats past its O plane)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -79,24 +147,22 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
     // ---- staging plan: this wave owns channel rows wave * RPW .. + RPW - 1 of every chunk; lane element i = pair column
     // (lane + 64 i) % WR of row (lane + 64 i) / WR.  Byte offsets relative to the chunk's first row, 0xFFFFFFFF outside [0, Tin)
     // (raw buffer loads return 0 there, and for rows past C_in through the descriptor's size) ----
+    // Every lane element is staged unconditionally: elements past the wave's last one repeat it (same loads, same values, same LDS
+    // addresses), and columns >= WD get transformed values nobody reads — no per-element masks or branches in the staging code.
     unsigned voE[NE], voO[NE];
     int lo[NE];               // LDS float offset of (row, column) inside the chunk buffer
-    unsigned in_mask = 0, d_mask = 0;   // bit i: element exists / also has a transformed value (column < WD)
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         int e = lane + 64 * i;
-        const bool in = e < RPW * WR;
-        e = in ? e : RPW * WR - 1;
+        e = e < RPW * WR ? e : RPW * WR - 1;
         const int rr = e / WR, c = e - rr * WR;
         const int n = n0 + c;
         const int q = n / DIL;
         const int tE = 2 * DIL * q + (n - q * DIL) - p.pad_l, tO = tE + DIL;
         const int row = wave * RPW + rr;
-        voE[i] = (in && tE >= 0 && tE < p.Tin) ? (unsigned)(row * p.Tin + tE) * 4u : 0xFFFFFFFFu;
-        voO[i] = (in && tO >= 0 && tO < p.Tin) ? (unsigned)(row * p.Tin + tO) * 4u : 0xFFFFFFFFu;
+        voE[i] = (tE >= 0 && tE < p.Tin) ? (unsigned)(row * p.Tin + tE) * 4u : 0xFFFFFFFFu;
+        voO[i] = (tO >= 0 && tO < p.Tin) ? (unsigned)(row * p.Tin + tO) * 4u : 0xFFFFFFFFu;
         lo[i] = row * ROW + c;
-        in_mask |= in ? 1u << i : 0u;
-        d_mask |= (in && c < WD) ? 1u << i : 0u;
     }
     float sE[NE], sO[NE];
     auto load_chunk = [&](int c) {
@@ -115,25 +181,26 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
         act_apply_all(sO, p.pre_act, p.slope);
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            if (in_mask >> i & 1) {
-                dst[lo[i] + 4 * WD] = sE[i];
-                dst[lo[i] + 4 * WD + WR] = sO[i];
-            }
+            dst[lo[i] + 4 * WR] = sE[i];
+            dst[lo[i] + 5 * WR] = sO[i];
         }
         // the neighbours (column + D of the same row) were written by this wave: its LDS operations execute in order, the fence
         // only keeps the compiler from moving the reads above the writes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float e1[NE], o1[NE];
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            if (d_mask >> i & 1) {
-                const float e1 = dst[lo[i] + 4 * WD + DIL], o1 = dst[lo[i] + 4 * WD + WR + DIL];
-                dst[lo[i]] = sE[i] - e1;
-                dst[lo[i] + WD] = sO[i] + e1;
-                dst[lo[i] + 2 * WD] = e1 - sO[i];
-                dst[lo[i] + 3 * WD] = sO[i] - o1;
-            }
+            e1[i] = dst[lo[i] + 4 * WR + DIL];
+            o1[i] = dst[lo[i] + 5 * WR + DIL];
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            dst[lo[i]] = sE[i] - e1[i];
+            dst[lo[i] + WR] = sO[i] + e1[i];
+            dst[lo[i] + 2 * WR] = e1[i] - sO[i];
+            dst[lo[i] + 3 * WR] = sO[i] - o1[i];
         }
     };
 
@@ -203,13 +270,17 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
         });
     }
 
-    // output transform + the shared fused epilogue: n-tile jn of the wave becomes two column sets, t0(n) and t0(n) + D
+    // output transform + fused epilogue: n-tile jn of the wave becomes two column sets, t0(n) and t0(n) + D
 #pragma unroll
     for (int jn = 0; jn < NT; ++jn) {
         f32x16 out[1][2];
         out[0][0] = (acc[0][jn] + acc[1][jn]) + acc[2][jn];
         out[0][1] = (acc[1][jn] - acc[2][jn]) - acc[3][jn];
         const int n = n0 + wn * (NT * 32) + jn * 32 + (lane & 31);
+        if (DIL == 1 && (p.N & 1) == 0) {   // D = 1, even T: the pair is two adjacent samples, 8-byte aligned
+            wino_epilogue_d1(p, out[0][0], out[0][1], b, mt0, n, lane);
+            continue;
+        }
         const int q = n / DIL;
         const int ta = 2 * DIL * q + (n - q * DIL);
         const int coff[2] = {ta, ta + DIL};

@@ -68,6 +68,7 @@ static void load_knobs() {
     if (const char* v = std::getenv("FV_WINO")) k.wino = std::atoi(v);
     if (const char* v = std::getenv("FV_WINO_MIN_M")) k.wino_min_m = std::atoi(v);
     if (const char* v = std::getenv("FV_WINO_CFG")) k.wino_cfg = std::atoi(v);
+    if (const char* v = std::getenv("FV_WINO_MIN_BLOCKS")) k.wino_min_blocks = std::atoi(v);
     g_knobs = k;
     g_knobs_loaded = true;
 }

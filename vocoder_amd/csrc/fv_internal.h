@@ -29,6 +29,7 @@ struct Knobs {
                           // fill the chip (conv_wino_impl.h), 2 = for every eligible launch (tests)
     int wino_min_m = 32;  // FV_WINO_MIN_M: narrowest layer (output rows) that takes it
     int wino_cfg = -1;    // FV_WINO_CFG: forced tile (WinoCfg), -1 = by shape
+    int wino_min_blocks = -1;   // FV_WINO_MIN_BLOCKS: fewest workgroups of a launch that takes it, -1 = default
 };
 const Knobs& knobs();
 
