@@ -54,66 +54,6 @@ struct WinoGeom {
     }
 };
 
-// conv_epilogue_cols' arithmetic (conv_mfma_impl.h) for dilation 1 and an even length: output pair n = samples (2n, 2n + 1) of a row,
-// moved with 8-byte buffer operations (half the vector-memory instructions, whole 8-byte segments per lane).
-__device__ __forceinline__ void wino_epilogue_d1(const ConvParams& p, const f32x16& y0, const f32x16& y1, int b, int mt, int n, int lane) {
-    const unsigned span = (unsigned)(p.y_bstride * 4);
-    const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
-    const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
-    const bool has_res = p.res != nullptr;
-    const bool accum = p.out_mode == OUT_ACCUM;
-    const bool cok = 2 * n < p.N;
-#pragma unroll
-    for (int rq0 = 0; rq0 < 4; rq0 += 2) {
-        unsigned off[8];
-        float v0[8], v1[8];
-        u32x2 rv[8], yo[8];
-#pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) {
-            const int rq = rq0 + r8 / 4, rr = r8 % 4;
-            const int m = mt * 32 + rr + 8 * rq + 4 * (lane >> 5);
-            const bool mok = m < p.M;
-            const int mc = mok ? m : 0;
-            const float bias = p.bias[mc];
-            const float gm = p.gamma ? p.gamma[mc] : 1.0f;
-            off[r8] = (mok && cok) ? (unsigned)(mc * p.N + 2 * n) * 4u : 0xFFFFFFF8u;
-            v0[r8] = fmaf(y0[rq * 4 + rr], p.acc_scale, bias) * gm;
-            v1[r8] = fmaf(y1[rq * 4 + rr], p.acc_scale, bias) * gm;
-        }
-        if (has_res) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rv[q] = __builtin_amdgcn_raw_buffer_load_b64(rrs, off[q], 0, 0);
-        }
-        if (accum) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) yo[q] = __builtin_amdgcn_raw_buffer_load_b64(yrs, off[q], 0, 0);
-        }
-        if (has_res) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                v0[q] += __uint_as_float(rv[q].x);
-                v1[q] += __uint_as_float(rv[q].y);
-            }
-        }
-        act_apply_all(v0, p.post_act, p.slope);
-        act_apply_all(v1, p.post_act, p.slope);
-        if (accum) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                v0[q] = (__uint_as_float(yo[q].x) + v0[q]) * p.out_scale;
-                v1[q] = (__uint_as_float(yo[q].y) + v1[q]) * p.out_scale;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            u32x2 o;
-            o.x = __float_as_uint(v0[q]);
-            o.y = __float_as_uint(v1[q]);
-            __builtin_amdgcn_raw_buffer_store_b64(o, yrs, off[q], 0, 0);
-        }
-    }
-}
-
 template <int KS, int DIL, int WM, int WN, int NT>
 #ifndef FV_X_WINO_OCC1
 #define FV_X_WINO_OCC1 3
@@ -128,7 +68,10 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    int bid = blockIdx.x;
+    // Workgroup b runs on XCD b % 8: logical id = (b % 8) * (grid / 8) + b / 8 puts neighbouring tiles of a clip — which share the
+    // cache lines of their halo columns (a 32-pair tile is two lines wide) — on one XCD, i.e. behind one L2
+    int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (bid >= p.wg_total) return;
     const int n_tile = bid % p.n_tiles;
     bid /= p.n_tiles;
     const int m_blk = bid % p.m_blks;
@@ -270,17 +213,15 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
         });
     }
 
-    // output transform + fused epilogue: n-tile jn of the wave becomes two column sets, t0(n) and t0(n) + D
+    // output transform + the shared fused epilogue: n-tile jn of the wave becomes two column sets, t0(n) and t0(n) + D.
+    // (An 8-byte store per pair at D = 1 measured 1.75 x the HBM write bytes of the two 4-byte stores — 158 vs 90 MB per launch by
+    // WRITE_SIZE — and no time gain: not used.)
 #pragma unroll
     for (int jn = 0; jn < NT; ++jn) {
         f32x16 out[1][2];
         out[0][0] = (acc[0][jn] + acc[1][jn]) + acc[2][jn];
         out[0][1] = (acc[1][jn] - acc[2][jn]) - acc[3][jn];
         const int n = n0 + wn * (NT * 32) + jn * 32 + (lane & 31);
-        if (DIL == 1 && (p.N & 1) == 0) {   // D = 1, even T: the pair is two adjacent samples, 8-byte aligned
-            wino_epilogue_d1(p, out[0][0], out[0][1], b, mt0, n, lane);
-            continue;
-        }
         const int q = n / DIL;
         const int ta = 2 * DIL * q + (n - q * DIL);
         const int coff[2] = {ta, ta + DIL};
@@ -290,8 +231,10 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
 }
 
 template <int KS, int DIL>
-inline bool launch_wino_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
-    const int grid = batch * p.m_blks * p.n_tiles;
+inline bool launch_wino_cfg(const ConvParams& p0, int cfg, int batch, hipStream_t s) {
+    ConvParams p = p0;
+    p.wg_total = batch * p.m_blks * p.n_tiles;
+    const int grid = (p.wg_total + 7) / 8 * 8;
     switch (cfg) {
         case WINO_128x64: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 4, 1, 2>), dim3(grid), dim3(256), 0, s, p); return true;
         case WINO_128x32: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 4, 1, 1>), dim3(grid), dim3(256), 0, s, p); return true;
