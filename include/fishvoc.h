@@ -78,7 +78,8 @@ typedef enum fv_act {
 } fv_act;
 
 /* Arithmetic of the MFMA-bound conv layers.  The reference computes in fp32; FV_PRECISION_F32 reproduces that
- * with exact-fp32 matrix instructions and is the default.  FV_PRECISION_F16X3 is opt-in: each fp32 operand is split in two
+ * with fp32 matrix instructions (direct sums, or Winograd F(2,3) tap groups for the dilated ResBlock convs of launches that fill the
+ * chip: fp32 products and sums throughout, as close to a float64 forward as the direct sums) and is the default.  FV_PRECISION_F16X3 is opt-in: each fp32 operand is split in two
  * fp16 planes and three fp16 products accumulate in fp32 (error ~2^-22 per product instead of 2^-24; activations must
  * stay below 65504 in magnitude) — same API, same parity tolerance, several times the throughput. */
 typedef enum fv_precision {

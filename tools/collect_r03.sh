@@ -26,7 +26,8 @@ timeout 1200 python bench.py --profile-json $O/bench_kernels_hipevents.json > $O
 cd /tmp && export TMPDIR=/tmp
 # the roofline section of bench.py itself under the profiler (single stream, every launch comparable): its hipEvent averages and rocprofv3's agree
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ro -- python $R/bench.py --roofline-only > $O/bench_roofline_only.json 2> /dev/null
-cp $(ls -t $(find $O/prof_ro -name "*kernel_stats.csv") | head -1) $O/bench_roofline_only_kernel_stats.csv; rm -rf $O/prof_ro
+cp $(ls -t $(find $O/prof_ro -name "*kernel_stats.csv") | head -1) $O/bench_roofline_only_kernel_stats.csv
+python $R/tools/trace_stats_by_grid.py $O/prof_ro $O/bench_roofline_only_kernel_stats_by_grid.csv; rm -rf $O/prof_ro
 for m in hifigan bigvgan vocos; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -- python $R/tools/probe_model.py $m > $O/prof_$m.log 2>&1
   cp $(find $O/prof_$m -name "*kernel_stats.csv" | head -1) $O/${m}_kernel_stats_serialized.csv
