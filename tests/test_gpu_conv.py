@@ -269,7 +269,7 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
 def test_winograd_conv_matches_oracle(cfg, monkeypatch):
     """conv_wino_impl.h through fv_conv_* with the kernel forced (FV_WINO=2) and every tile variant (FV_WINO_CFG): SiLU + bias + residual
     and the plain conv against the CPU oracle; the direct-sum kernel on the same layer for scale (both sit ~1e-6 from the oracle)."""

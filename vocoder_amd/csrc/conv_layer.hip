@@ -144,7 +144,7 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
     FV_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
     if (!transposed && stride == 1 && (k == 3 || k == 7 || k == 11) && (dil == 1 || dil == 3 || dil == 5) && padding == (k - 1) / 2 * dil &&
         c_in >= 32 && c_in == c_out) {   // the ResBlock / AMPBlock convs (not conv_pre: a launch whose size decides the path per batch)
-        // Winograd F(2,3) tap groups (conv_wino.hip): groups at taps 0, 4, 8 -> four transformed weights each, the taps between them
+        // Winograd F(2,3) tap groups (conv_wino_impl.h): groups at taps 0, 4, 8 -> four transformed weights each, the taps between them
         // (3, 7) -> (+w, -w); virtual-tap order = WinoGeom::off_of / acc_of
         const int ng = (k + 1) / 4, ns = (k - 3) / 4;
         L.nv = 4 * ng + 2 * ns;
@@ -505,15 +505,19 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         }
     }
 
-    // Winograd F(2,3) tap groups for the dilated ResBlock / AMPBlock convs of launches that fill the chip (conv_wino.hip)
+    // Winograd F(2,3) tap groups for the dilated ResBlock / AMPBlock convs of launches that fill the chip (conv_wino_impl.h)
     if (knobs().wino && L.d_wpw && !p.x2 && L.M >= knobs().wino_min_m) {
-        static const int wdims[WINO_COUNT][2] = {{128, 64}, {128, 32}, {64, 64}, {64, 128}, {32, 128}};
+        static const int wdims[WINO_COUNT][2] = {{128, 32}, {64, 64}, {32, 128}, {128, 64}, {64, 128}};
         // 64 accumulator registers per wave (32 output pairs x 4 planes): three waves per SIMD; the 128 x 64-pair tile (two waves) measured
         // 8 % slower on the headline's C = 128 stage although it fetches each weight fragment half as often
         int wcfg = L.M > 64 ? WINO_128x32 : L.M > 32 ? WINO_64x64 : WINO_32x128;
         const long long np = (long long)L.dil * ((tout + 2 * L.dil - 1) / (2 * L.dil));   // pair columns: whole blocks of 2 D samples
         auto blocks_of = [&](int c) { return (long long)r.batch * ((L.M + wdims[c][0] - 1) / wdims[c][0]) * ((np + wdims[c][1] - 1) / wdims[c][1]); };
+#ifdef FV_X_WINO_NT2
         if (knobs().wino_cfg >= 0 && knobs().wino_cfg < WINO_COUNT) wcfg = knobs().wino_cfg;
+#else
+        if (knobs().wino_cfg >= 0 && knobs().wino_cfg <= WINO_32x128) wcfg = knobs().wino_cfg;
+#endif
         const int mb = wdims[wcfg][0], pairs = wdims[wcfg][1];
         const long long blocks = blocks_of(wcfg);
         // launches of at least half a workgroup per CU: measured per batch size (tools/sweep_wino_batch.py) — HiFiGAN-V1 B = 2 ... 32 -12 ... -16 %

@@ -70,7 +70,7 @@ __device__ __forceinline__ void act_apply_all(float (&v)[N], int act, float slop
 // scatter.  acc follows the 32x32 MFMA C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 // All global traffic goes through raw buffer ops on byte offsets relative to the output tensor (masked elements get offset
 // 0xFFFFFFFF: loads return 0, stores are dropped) — no 64-bit address arithmetic, no per-element branches.
-// (conv_epilogue_cols: the caller supplies each n-tile's column offset and validity — conv_wino.hip's columns are output pairs)
+// (conv_epilogue_cols: the caller supplies each n-tile's column offset and validity — conv_wino_impl.h's columns are output pairs)
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, f32x16 (&acc)[MT][NT], int b, int mt0, const int (&coff)[NT],
                                                    const bool (&cok)[NT], int lane) {

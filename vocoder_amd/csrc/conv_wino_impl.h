@@ -8,7 +8,7 @@
 // Tap groups {0,1,2}, {4,5,6}, {8,9,10} (group g reads pair column n + 2 g D), transformed inputs (four planes, computed once per staged
 // window and shared by all groups and output rows):
 //   d0 = E[n] - E[n+D]    d1 = O[n] + E[n+D]    d2 = E[n+D] - O[n]    d3 = O[n] - O[n+D]
-// transformed weights (host, in double, conv_layer.hip):  g0,  (g0+g1+g2)/2,  (g0-g1+g2)/2,  g2
+// transformed weights (host, in double, conv_layer.hip: conv_layer_create):  g0,  (g0+g1+g2)/2,  (g0-g1+g2)/2,  g2
 // four accumulator planes   m_p += G_p d_p   and   y[t0] = m0 + m1 + m2,   y[t0 + D] = m1 - m2 - m3.
 // The taps between the groups (3, 7) are plain products folded into the same accumulators: w_j O[n + q D] into m0 and
 // -w_j E[n + (q+1) D] into m3, q = (j-1)/2 (m0 only reaches the first output of the pair, m3 only the second, negated).
@@ -236,11 +236,13 @@ inline bool launch_wino_cfg(const ConvParams& p0, int cfg, int batch, hipStream_
     p.wg_total = batch * p.m_blks * p.n_tiles;
     const int grid = (p.wg_total + 7) / 8 * 8;
     switch (cfg) {
-        case WINO_128x64: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 4, 1, 2>), dim3(grid), dim3(256), 0, s, p); return true;
         case WINO_128x32: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 4, 1, 1>), dim3(grid), dim3(256), 0, s, p); return true;
         case WINO_64x64: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 2, 2, 1>), dim3(grid), dim3(256), 0, s, p); return true;
-        case WINO_64x128: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 2, 2, 2>), dim3(grid), dim3(256), 0, s, p); return true;
         case WINO_32x128: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 1, 4, 1>), dim3(grid), dim3(256), 0, s, p); return true;
+#ifdef FV_X_WINO_NT2
+        case WINO_128x64: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 4, 1, 2>), dim3(grid), dim3(256), 0, s, p); return true;
+        case WINO_64x128: hipLaunchKernelGGL((conv_wino_kernel<KS, DIL, 2, 2, 2>), dim3(grid), dim3(256), 0, s, p); return true;
+#endif
         default: return false;
     }
 }

@@ -28,7 +28,7 @@ struct Knobs {
     int wino = 1;         // FV_WINO: 0 = direct sums only, 1 = Winograd F(2,3) tap groups for the dilated k = 3 / 7 / 11 convs of launches that
                           // fill the chip (conv_wino_impl.h), 2 = for every eligible launch (tests)
     int wino_min_m = 32;  // FV_WINO_MIN_M: narrowest layer (output rows) that takes it
-    int wino_cfg = -1;    // FV_WINO_CFG: forced tile (WinoCfg), -1 = by shape
+    int wino_cfg = -1;    // FV_WINO_CFG: forced tile (WinoCfg 0 ... 2), -1 = by shape
     int wino_min_blocks = -1;   // FV_WINO_MIN_BLOCKS: fewest workgroups of a launch that takes it, -1 = default
 };
 const Knobs& knobs();
@@ -137,7 +137,7 @@ struct ConvLayer {
     // GEMM view
     int M = 0, ks = 0, pad_l = 0, nchunk = 0, nchunk_real = 0, m_pad = 0;
     float4* d_wp = nullptr;
-    float4* d_wpw = nullptr;   // Winograd-transformed weights in the same fragment order, nv virtual taps (conv_wino.hip); optional
+    float4* d_wpw = nullptr;   // Winograd-transformed weights in the same fragment order, nv virtual taps (conv_wino_impl.h); optional
     int nv = 0;
     float4* d_wp16 = nullptr;  // 16x16x4-fragment layout, only for 16 -> 16 channel Conv1d (fused pair kernel)
     void* d_wph16 = nullptr;   // f16x3 mode, 16 -> 16 channel Conv1d: (wh, wl) planes of the two-samples-per-row layout (pair16_f16x3.hip)
@@ -242,8 +242,10 @@ bool launch_amp_conv(const ConvLayer& L, const float* x, float* y, const float* 
 // Tile configurations (block = 4 waves): rows = WM*MT*32, cols = WN*NT*32.
 enum TileCfg : int { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2, TILE_128x64 = 3, TILE_32x128 = 4, TILE_64x128 = 5, TILE_SPLITK_32x64 = 6, TILE_SPLITK_32x32 = 7, TILE_256x64 = 8, TILE_256x32 = 9, TILE_128x96 = 10, TILE_COUNT };
 void tile_dims(int cfg, int* m_blk, int* n_blk);
-// conv_wino.hip: Winograd F(2,3) variant of the dilated "same" convs; tiles = output rows x output PAIRS per workgroup
-enum WinoCfg : int { WINO_128x64 = 0, WINO_128x32 = 1, WINO_64x64 = 2, WINO_64x128 = 3, WINO_32x128 = 4, WINO_COUNT };
+// conv_wino_impl.h: Winograd F(2,3) variant of the dilated "same" convs; tiles = output rows x output PAIRS per workgroup
+// (two-n-tile variants — 128 x 64 and 64 x 128 pairs, 128 accumulator registers, two waves per SIMD — measured 8 % slower: LOG R3.16;
+//  -DFV_X_WINO_NT2 builds them back in as configurations 3 and 4)
+enum WinoCfg : int { WINO_128x32 = 0, WINO_64x64 = 1, WINO_32x128 = 2, WINO_128x64 = 3, WINO_64x128 = 4, WINO_COUNT };
 // p.wp = the layer's d_wpw, p.n_tiles in pair columns
 bool launch_conv_wino_k3(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_wino_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
