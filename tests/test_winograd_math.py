@@ -1,0 +1,73 @@
+"""CPU: the arithmetic conv_wino_impl.h implements, restated in numpy (float64) against the oracle's direct conv — Winograd F(2,3) tap
+groups {0,1,2}, {4,5,6}, {8,9,10} on the dilated pair lattice plus the single taps 3, 7 folded into accumulators m0 / m3, with the
+virtual-tap order, plane offsets and weight transform of the kernel / conv_layer_create.  Exact in real arithmetic: float64 agrees
+to ~1e-12, so an indexing or sign error in the scheme cannot hide behind a tolerance."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+def virtual_taps(k):
+    """(plane, shift in units of D, accumulator, weight row) per virtual tap, in the kernel's order; planes 0..3 = d0..d3, 4 = E, 5 = O."""
+    ng, ns = (k + 1) // 4, (k - 3) // 4
+    taps = [(p, 2 * g, p, ("g", g, p)) for g in range(ng) for p in range(4)]
+    for s in range(ns):
+        taps += [(5, 2 * s + 1, 0, ("s", s, +1.0)), (4, 2 * s + 2, 3, ("s", s, -1.0))]
+    return taps
+
+
+def transformed_weights(w, k):
+    """(C_out, C_in, NV): what conv_layer_create packs for the kernel."""
+    out = []
+    for (_, _, _, src) in virtual_taps(k):
+        if src[0] == "g":
+            g0, g1, g2 = (w[..., 4 * src[1] + i] for i in range(3))
+            out.append([g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2][src[2]])
+        else:
+            out.append(src[2] * w[..., 4 * src[1] + 3])
+    return np.stack(out, axis=-1)
+
+
+def wino_conv1d(x, w, d):
+    B, C, T = x.shape
+    k = w.shape[-1]
+    pad = (k - 1) * d // 2
+    nq = -(-T // (2 * d))                      # blocks of 2 D samples
+    NP = nq * d                                # pair columns
+    halo = 2 * d * ((k + 1) // 4 - 1) + d      # largest shift + the transform's neighbour
+    xp = np.zeros((B, C, 2 * d * nq + 2 * halo + 2 * d + pad))
+    xp[..., pad:pad + T] = x                   # x'[tau] = x[tau - pad]
+    n = np.arange(NP + halo)
+    t0 = 2 * d * (n // d) + n % d
+    E, O = xp[..., t0], xp[..., t0 + d]
+    E1, O1 = np.roll(E, -d, axis=-1), np.roll(O, -d, axis=-1)
+    planes = [E - E1, O + E1, E1 - O, O - O1, E, O]
+    ww = transformed_weights(w, k)
+    m = [np.zeros((B, w.shape[0], NP)) for _ in range(4)]
+    for v, (pl, sh, acc, _) in enumerate(virtual_taps(k)):
+        m[acc] += np.einsum("oc,bcn->bon", ww[..., v], planes[pl][..., sh * d:sh * d + NP])
+    y = np.zeros((B, w.shape[0], 2 * d * nq))
+    tt = 2 * d * (np.arange(NP) // d) + np.arange(NP) % d
+    y[..., tt] = m[0] + m[1] + m[2]
+    y[..., tt + d] = m[1] - m[2] - m[3]
+    return y[..., :T]
+
+
+@pytest.mark.parametrize("k,d,T", [(3, 1, 17), (3, 5, 40), (7, 1, 64), (7, 3, 1), (7, 5, 333), (11, 1, 129), (11, 3, 50), (11, 5, 9), (11, 5, 700)])
+def test_pair_lattice_winograd_equals_the_direct_conv(k, d, T):
+    rng = np.random.default_rng(k * 100 + d * 10 + T)
+    x = rng.normal(size=(2, 6, T))
+    w = rng.normal(size=(5, 6, k))
+    ref = orc.conv1d(x.astype(np.float32), w.astype(np.float32), None, dilation=d, padding=(k - 1) * d // 2)
+    y = wino_conv1d(x.astype(np.float32).astype(np.float64), w.astype(np.float32).astype(np.float64), d)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())       # the float32 oracle's own rounding
+    # and exactly, against a float64 direct sum
+    xp = np.pad(x.astype(np.float32).astype(np.float64), ((0, 0), (0, 0), ((k - 1) * d // 2,) * 2))
+    direct = sum(np.einsum("oc,bct->bot", w.astype(np.float32).astype(np.float64)[..., j], xp[..., j * d:j * d + T]) for j in range(k))
+    assert np.abs(y - direct).max() <= 1e-11
+
+
+def test_products_per_output_pair():
+    assert [len(virtual_taps(k)) for k in (3, 7, 11)] == [4, 10, 16]       # against 6 / 14 / 22 for the direct sum
