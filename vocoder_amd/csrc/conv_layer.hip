@@ -505,6 +505,9 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         }
     }
 
+#if defined(FV_X_SPLITK_TS) || defined(FV_X_CONV_TS)
+    p.dbg_ts = g_sk_ts;
+#endif
     // Winograd F(2,3) tap groups for the dilated ResBlock / AMPBlock convs of launches that fill the chip (conv_wino_impl.h)
     if (knobs().wino && L.d_wpw && !p.x2 && L.M >= knobs().wino_min_m) {
         static const int wdims[WINO_COUNT][2] = {{128, 32}, {64, 64}, {32, 128}, {128, 64}, {64, 128}};
@@ -552,9 +555,6 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
             }
         }
     }
-#if defined(FV_X_SPLITK_TS) || defined(FV_X_CONV_TS)
-    p.dbg_ts = g_sk_ts;
-#endif
     int cfg = choose_tile(L.M, p.N, r.batch);
     // the stage-0 upsampler of a 1 s clip: 87 GEMM columns per item fill two thirds of a 128-column tile — 128 x 96 tiles (four waves
     // along M, three n-tiles each; instantiated for the two-tap polyphase convs only)

@@ -71,7 +71,10 @@ __device__ __forceinline__ void act_apply_all(float (&v)[N], int act, float slop
 // All global traffic goes through raw buffer ops on byte offsets relative to the output tensor (masked elements get offset
 // 0xFFFFFFFF: loads return 0, stores are dropped) — no 64-bit address arithmetic, no per-element branches.
 // (conv_epilogue_cols: the caller supplies each n-tile's column offset and validity — conv_wino_impl.h's columns are output pairs)
-template <int MT, int NT>
+#ifndef FV_X_EPI_ROWS
+#define FV_X_EPI_ROWS 8
+#endif
+template <int MT, int NT, int RG = FV_X_EPI_ROWS / 4>
 __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, f32x16 (&acc)[MT][NT], int b, int mt0, const int (&coff)[NT],
                                                    const bool (&cok)[NT], int lane) {
     // in flat mode the tensor spans all batch items (b == 0), otherwise one item
@@ -80,16 +83,13 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, f32x16 (
     const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
     const bool has_res = p.res != nullptr;
     const bool accum = p.out_mode == OUT_ACCUM;
-#ifndef FV_X_EPI_ROWS
-#define FV_X_EPI_ROWS 8
-#endif
     // RG row groups of 4 accumulator registers are processed together: their residual / accumulate operands are requested up
     // front, so an m-tile costs 16 / (4 RG) round trips to L2 / HBM instead of four.  Two groups (8 rows) fit the register
     // budget of three workgroups per CU; four (the whole m-tile) spill and measured +1.2 % on the headline step.  The gain of
     // two is small (-0.2 %): tools/probe_conv_timeline.py shows a 128 x 128 workgroup ~20 us in this function (12 us without a
     // residual), but that is bandwidth, not latency — every CU's workgroups start together, so the whole chip reads its
     // residual tiles and stores its outputs (2 x 49 MB at B = 32) in the same few microseconds, twice per launch.
-    constexpr int RG = FV_X_EPI_ROWS / 4;
+    // (conv_wino_impl.h passes RG = 4: its accumulator planes are dead by then, the whole m-tile's operands fit)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll

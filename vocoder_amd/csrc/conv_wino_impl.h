@@ -79,6 +79,10 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
     const int n0 = n_tile * NBP;
     const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
 
+    FV_CV_STAMP(0);
+#ifdef FV_X_CONV_TS
+    if (p.dbg_ts && threadIdx.x == 0) p.dbg_ts[(long long)blockIdx.x * 16 + 15] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);   // HW_ID, XCC_ID
+#endif
     f32x16 acc[4][NT];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
         float* xsb = xs[c & 1];
         store_chunk(xsb);
         __syncthreads();
+        if (c < 12) FV_CV_STAMP(1 + c);
         if (c + 1 < nch) load_chunk(c + 1);
         const int gchunk_b = __builtin_amdgcn_readfirstlane((c * STEPS + DA) * 1024);
 #pragma unroll
@@ -213,9 +218,64 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
         });
     }
 
+    FV_CV_STAMP(13);
     // output transform + the shared fused epilogue: n-tile jn of the wave becomes two column sets, t0(n) and t0(n) + D.
     // (An 8-byte store per pair at D = 1 measured 1.75 x the HBM write bytes of the two 4-byte stores — 158 vs 90 MB per launch by
     // WRITE_SIZE — and no time gain: not used.)
+#ifndef FV_X_WINO_NO_LEAN_EPI
+    // The common case — whole 32-row tiles, bias [+ residual], plain store (every ResBlock / AMPBlock conv of the three-stream forward) —
+    // without per-element offset registers: a row is the SGPR offset of the buffer instruction, the column the VGPR one (the range check
+    // covers the VGPR part, so a masked column stays masked).  All 16 bias and 32 residual operands of the wave's tile are requested
+    // before the output transform: one round trip instead of conv_epilogue_cols' two, and the transform runs under it.  Same
+    // arithmetic as the general path (fmaf(acc, 1, bias) + residual): bit-identical.
+    if (NT == 1 && p.M % 32 == 0 && p.gamma == nullptr && p.post_act == FV_ACT_NONE && p.out_mode == OUT_SET && p.acc_scale == 1.0f) {
+        if (mt0 * 32 >= p.M) return;
+        const unsigned span = (unsigned)(p.y_bstride * 4);
+        const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
+        const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
+        const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(p.bias, (unsigned)(p.M * 4));
+        const int n = n0 + wn * 32 + (lane & 31);
+        const int q = n / DIL;
+        const int ta = 2 * DIL * q + (n - q * DIL), tb = ta + DIL;
+        const int mrow = 4 * (lane >> 5);                                   // lane part of the row; + mt0 * 32 + (r & 3) + 8 * (r >> 2) in SGPRs
+        const unsigned va = ta < p.N ? (unsigned)(mrow * p.N + ta) * 4u : 0xFFFFFFFFu;
+        const unsigned vb = tb < p.N ? (unsigned)(mrow * p.N + tb) * 4u : 0xFFFFFFFFu;
+        float bias[16], ra[16], rb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            bias[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, mrow * 4, (mt0 * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+        if (p.res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = (mt0 * 32 + (r & 3) + 8 * (r >> 2)) * p.N * 4;
+                ra[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, va, so, 0));
+                rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, vb, so, 0));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ra[r] = rb[r] = 0.f;
+        }
+        const f32x16 y0 = (acc[0][0] + acc[1][0]) + acc[2][0];
+        const f32x16 y1 = (acc[1][0] - acc[2][0]) - acc[3][0];
+        const bool has_res = p.res != nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int so = (mt0 * 32 + (r & 3) + 8 * (r >> 2)) * p.N * 4;
+            float a = fmaf(y0[r], 1.0f, bias[r]), c = fmaf(y1[r], 1.0f, bias[r]);
+            if (has_res) {
+                a += ra[r];
+                c += rb[r];
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), yrs, va, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c), yrs, vb, so, 0);
+        }
+#ifdef FV_X_CONV_TS
+        __builtin_amdgcn_s_waitcnt(0);
+#endif
+        FV_CV_STAMP(14);
+        return;
+    }
+#endif
 #pragma unroll
     for (int jn = 0; jn < NT; ++jn) {
         f32x16 out[1][2];
@@ -228,6 +288,10 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
         const bool cok[2] = {ta < p.N, ta + DIL < p.N};
         conv_epilogue_cols<1, 2>(p, out, b, mt0, coff, cok, lane);
     }
+#ifdef FV_X_CONV_TS
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    FV_CV_STAMP(14);
 }
 
 template <int KS, int DIL>
