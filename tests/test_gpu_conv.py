@@ -295,3 +295,33 @@ def test_winograd_conv_matches_oracle(cfg, monkeypatch):
         monkeypatch.delenv("FV_WINO")
         monkeypatch.delenv("FV_WINO_CFG")
         _lib.reload_env()
+
+
+def test_winograd_conv_offsets_beyond_2_gib(monkeypatch):
+    """One batch item of 2.2 GB (C = 128, T = 4.3 M samples: byte offsets past 2^31, under the 4 GiB addressing span conv_layer_run
+    enforces): the Winograd kernel (staging offsets, SGPR row offsets of its epilogue) against the direct-sum kernel on the same
+    device tensors — first, middle and last columns of the first and last rows."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import FusedConv
+    C, T, k, d = 128, 4_300_000, 11, 5
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    x = torch.randn(1, C, T, device=_dev(), generator=g)
+    res = torch.randn(1, C, T, device=_dev(), generator=g)
+    w = torch.randn(C, C, k, generator=torch.Generator().manual_seed(4)) / (C * k) ** 0.5
+    conv = FusedConv(w, torch.zeros(C), dilation=d, padding=(k - 1) * d // 2, pre_act=_lib.FV_ACT_SILU)
+    try:
+        y1 = conv(x, res)
+        assert _lib.last_kernel().startswith("conv_wino<"), _lib.last_kernel()
+        monkeypatch.setenv("FV_WINO", "0")
+        _lib.reload_env()
+        y0 = conv(x, res)
+        assert _lib.last_kernel().startswith("conv_mfma<"), _lib.last_kernel()
+        torch.cuda.synchronize()
+        for sl in (slice(0, 4096), slice(T // 2 - 2048, T // 2 + 2048), slice(T - 4096, T)):
+            for rows in (slice(0, 2), slice(C - 2, C)):
+                dmax = float((y1[0, rows, sl] - y0[0, rows, sl]).abs().max())
+                assert dmax <= 2e-5, (sl, rows, dmax)
+        assert float((y1 - y0).abs().max()) <= 2e-5
+    finally:
+        monkeypatch.delenv("FV_WINO", raising=False)
+        _lib.reload_env()

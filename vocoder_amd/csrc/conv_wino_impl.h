@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
         if (p.res) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int so = (mt0 * 32 + (r & 3) + 8 * (r >> 2)) * p.N * 4;
+                const int so = (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);   // (< 4 GiB per item: conv_layer_run)
                 ra[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, va, so, 0));
                 rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, vb, so, 0));
             }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
         const bool has_res = p.res != nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int so = (mt0 * 32 + (r & 3) + 8 * (r >> 2)) * p.N * 4;
+            const int so = (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);
             float a = fmaf(y0[r], 1.0f, bias[r]), c = fmaf(y1[r], 1.0f, bias[r]);
             if (has_res) {
                 a += ra[r];
