@@ -13,7 +13,7 @@ if model == "hifigan":
 else:
     cfg = dict(syn.BIGVGAN_24K); sd = syn.bigvgan_state_dict(cfg, 0); kind = _lib.FV_MODEL_BIGVGAN; frames = 94
 GATES = [g for g in os.environ.get("GATES", "").split(",") if g]
-for B in ((1, 2, 5, 10, 20, 32) if GATES else (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
+for B in ((1, 2, 3, 4, 6, 8, 12, 16, 24, 32) if GATES else (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
     mel = torch.from_numpy(syn.synthetic_mel(B, 80, frames, 1)).cuda()
     res = []
     for mode in (GATES or ("0", "1", "2")):
