@@ -223,12 +223,13 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
     // (An 8-byte store per pair at D = 1 measured 1.75 x the HBM write bytes of the two 4-byte stores — 158 vs 90 MB per launch by
     // WRITE_SIZE — and no time gain: not used.)
 #ifndef FV_X_WINO_NO_LEAN_EPI
-    // The common case — whole 32-row tiles, bias [+ residual], plain store (every ResBlock / AMPBlock conv of the three-stream forward) —
+    // The common case — whole 32-row tiles, bias [+ residual] [+ post-activation], plain store (every ResBlock / AMPBlock conv of the
+    // three-stream forward) —
     // without per-element offset registers: a row is the SGPR offset of the buffer instruction, the column the VGPR one (the range check
     // covers the VGPR part, so a masked column stays masked).  All 16 bias and 32 residual operands of the wave's tile are requested
     // before the output transform: one round trip instead of conv_epilogue_cols' two, and the transform runs under it.  Same
     // arithmetic as the general path (fmaf(acc, 1, bias) + residual): bit-identical.
-    if (NT == 1 && p.M % 32 == 0 && p.gamma == nullptr && p.post_act == FV_ACT_NONE && p.out_mode == OUT_SET && p.acc_scale == 1.0f) {
+    if (NT == 1 && p.M % 32 == 0 && p.gamma == nullptr && p.out_mode == OUT_SET && p.acc_scale == 1.0f) {
         if (mt0 * 32 >= p.M) return;
         const unsigned span = (unsigned)(p.y_bstride * 4);
         const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
@@ -258,16 +259,23 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
         const f32x16 y0 = (acc[0][0] + acc[1][0]) + acc[2][0];
         const f32x16 y1 = (acc[1][0] - acc[2][0]) - acc[3][0];
         const bool has_res = p.res != nullptr;
+        float oa[16], ob[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            oa[r] = fmaf(y0[r], 1.0f, bias[r]);
+            ob[r] = fmaf(y1[r], 1.0f, bias[r]);
+            if (has_res) {
+                oa[r] += ra[r];
+                ob[r] += rb[r];
+            }
+        }
+        act_apply_all(oa, p.post_act, p.slope);   // (c1 of a ResBlock pair carries the SiLU in front of c2: hifigan.py:104-106)
+        act_apply_all(ob, p.post_act, p.slope);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int so = (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);
-            float a = fmaf(y0[r], 1.0f, bias[r]), c = fmaf(y1[r], 1.0f, bias[r]);
-            if (has_res) {
-                a += ra[r];
-                c += rb[r];
-            }
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), yrs, va, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c), yrs, vb, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oa[r]), yrs, va, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ob[r]), yrs, vb, so, 0);
         }
 #ifdef FV_X_CONV_TS
         __builtin_amdgcn_s_waitcnt(0);
