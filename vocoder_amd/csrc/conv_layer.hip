@@ -143,15 +143,15 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
     FV_HIP_CHECK(hipMemcpy(L.d_wp, packed.data(), L.wp_bytes, hipMemcpyHostToDevice));
     FV_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
     if (!transposed && stride == 1 && (k == 3 || k == 7 || k == 11) && (dil == 1 || dil == 3 || dil == 5) && padding == (k - 1) / 2 * dil &&
-        c_in >= 32 && c_in == c_out) {   // the ResBlock / AMPBlock convs (not conv_pre: a launch whose size decides the path per batch)
+        c_in >= 16 && c_in == c_out) {   // the ResBlock / AMPBlock convs (not conv_pre: a launch whose size decides the path per batch)
         // Winograd F(2,3) tap groups (conv_wino_impl.h): groups at taps 0, 4, 8 -> four transformed weights each, the taps between them
         // (3, 7) -> (+w, -w); virtual-tap order = WinoGeom::off_of / acc_of
         const int ng = (k + 1) / 4, ns = (k - 3) / 4;
-        L.nv = 4 * ng + 2 * ns;
-        std::vector<float> ww((size_t)c_out * c_in * L.nv);
+        const int nv = 4 * ng + 2 * ns;
+        std::vector<float> ww((size_t)c_out * c_in * nv);
         for (size_t oc = 0; oc < (size_t)c_out * c_in; ++oc) {
             const float* w = &wc[oc * k];
-            float* o = &ww[oc * L.nv];
+            float* o = &ww[oc * nv];
             for (int g = 0; g < ng; ++g) {
                 const double g0 = w[4 * g], g1 = w[4 * g + 1], g2 = w[4 * g + 2];
                 o[4 * g + 0] = (float)g0;
@@ -164,10 +164,31 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
                 o[4 * ng + 2 * s2 + 1] = -w[4 * s2 + 3];
             }
         }
-        std::vector<float> pw;
-        pack_conv_weights(ww, L.M, c_in, L.nv, L.m_pad, L.nchunk, pw);
-        FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw, pw.size() * sizeof(float)));
-        FV_HIP_CHECK(hipMemcpy(L.d_wpw, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (c_in >= 32) {
+            L.nv = nv;
+            std::vector<float> pw;
+            pack_conv_weights(ww, L.M, c_in, L.nv, L.m_pad, L.nchunk, pw);
+            FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw, pw.size() * sizeof(float)));
+            FV_HIP_CHECK(hipMemcpy(L.d_wpw, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        if (c_in == 16 || c_in == 32) {
+            // pair_wino_impl.h: A fragments of v_mfma_f32_16x16x4_f32 (row = lane & 15, k = lane >> 4), one float4 per lane = four MFMAs.
+            //   C = 16: fragment v            .{x,y,z,w}[s]       = W'[lane & 15][4 s + (lane >> 4)][v]                      (16 channels)
+            //   C = 32: fragment sb * nv + v  .{x,y,z,w}[2 s + mt] = W'[16 mt + (lane & 15)][8 sb + 4 s + (lane >> 4)][v]   (8 channels, both m-tiles)
+            // + 8 zero fragments: the kernels' weight ring runs a few fragments past the end
+            const int mt_n = c_in / 16, fch = 16 / mt_n, nfr = c_in / fch * nv;
+            std::vector<float> p16((size_t)(nfr + 8) * 64 * 4, 0.f);
+            for (int sb = 0; sb < c_in / fch; ++sb)
+                for (int v = 0; v < nv; ++v)
+                    for (int l = 0; l < 64; ++l)
+                        for (int q = 0; q < 4; ++q) {
+                            const int s = mt_n == 2 ? q / 2 : q, mt = mt_n == 2 ? q % 2 : 0;
+                            const int co = 16 * mt + (l & 15), ci = fch * sb + 4 * s + (l >> 4);
+                            p16[(((size_t)sb * nv + v) * 64 + l) * 4 + q] = ww[((size_t)co * c_in + ci) * nv + v];
+                        }
+            FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw16, p16.size() * sizeof(float)));
+            FV_HIP_CHECK(hipMemcpy(L.d_wpw16, p16.data(), p16.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     if (with_f16x3 && f16x3_eligible(transposed, c_in, L.M, L.ks, L.dil)) {
         L.nch16 = (c_in + 15) / 16;
@@ -223,6 +244,8 @@ void conv_layer_destroy(ConvLayer& L) {
     if (L.d_wp16) (void)hipFree(L.d_wp16);
     if (L.d_wpw) (void)hipFree(L.d_wpw);
     L.d_wpw = nullptr;
+    if (L.d_wpw16) (void)hipFree(L.d_wpw16);
+    L.d_wpw16 = nullptr;
     if (L.d_wph) (void)hipFree(L.d_wph);
     if (L.d_wph16) (void)hipFree(L.d_wph16);
     L.d_wph16 = nullptr;
@@ -750,6 +773,10 @@ static fv_status conv_pair16_run_f16x3(const ConvLayer& c1, const ConvLayer& c2,
     return FV_OK;
 }
 
+bool pair_wino_supported(int C, int ks, int dil) {
+    return (C == 16 || C == 32) && (ks == 3 || ks == 7 || ks == 11) && (dil == 1 || dil == 3 || dil == 5);
+}
+
 fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x, float* y, int batch, int t, int out_mode,
                         float out_scale, hipStream_t stream) {
     const int C = c1.c_in;
@@ -764,6 +791,41 @@ fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x
     if (x == y) {
         set_error("conv_pair_run: output must not alias the input (halo reads)");
         return FV_ERR_INVALID;
+    }
+    if (knobs().pair_wino && c1.d_wpw16 && c2.d_wpw16 && pair_wino_supported(C, c1.k, c1.dil)) {
+        // Winograd F(2,3) tap groups in both convs (pair_wino_impl.h)
+        PairParams p;
+        std::memset(&p, 0, sizeof(p));
+        p.x = x;
+        p.y = y;
+        p.w1 = c1.d_wpw16;
+        p.w2 = c2.d_wpw16;
+        p.b1 = c1.d_bias;
+        p.b2 = c2.d_bias;
+        p.T = t;
+        p.out_mode = out_mode;
+        p.out_scale = out_scale;
+        const int prof_idx = prof_begin(stream);
+        const bool ok = c1.k == 3 ? launch_pair_wino_k3(p, C, c1.dil, batch, stream)
+                        : c1.k == 7 ? launch_pair_wino_k7(p, C, c1.dil, batch, stream) : launch_pair_wino_k11(p, C, c1.dil, batch, stream);
+        if (!ok) {
+            if (dynamic_lds_refused()) return FV_ERR_HIP;
+            set_error("conv_pair_run: no Winograd pair kernel for (C=%d k=%d d=%d)", C, c1.k, c1.dil);
+            return FV_ERR_UNSUPPORTED;
+        }
+        static thread_local char name[96];
+        std::snprintf(name, sizeof(name), "pair_wino<k=%d d=%d C=%d>", c1.k, c1.dil, C);
+        set_last_kernel(name);
+        if (prof_idx >= 0) {
+            const int tt = 2 * (64 / c1.dil * c1.dil) - (c1.k - 1);   // PWGeom::TT
+            char lbl[128];
+            std::snprintf(lbl, sizeof(lbl), "%s grid=%d", name, batch * ((t + tt - 1) / tt));
+            const double macs = 2.0 * C * C * c1.k * (double)t * batch;   // ALGORITHMIC (direct-sum) MACs of the two convs
+            const double elems = (out_mode == OUT_ACCUM ? 3.0 : 2.0) * C * (double)t * batch;
+            prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * 4.0 + 2.0 * C * C * c1.k * 4.0);
+        }
+        FV_HIP_CHECK(hipGetLastError());
+        return FV_OK;
     }
     PairParams p;
     std::memset(&p, 0, sizeof(p));

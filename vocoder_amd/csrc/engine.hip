@@ -9,12 +9,14 @@
 //                                       modules/generators/unify.py:18-33 + encoders/convnext.py:206-214
 //                                       + generators/vocos.py:43-69 (Vocos)
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <string>
 
@@ -53,28 +55,38 @@ bool ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long* done_
     if (dev >= 0 && dev < 64) __atomic_fetch_or(done_mask, 1ull << dev, __ATOMIC_RELEASE);   // devices >= 64: set every time
     return true;
 }
-static Knobs g_knobs;
-static bool g_knobs_loaded = false;
-static void load_knobs() {
-    Knobs k;
+// The knob set is immutable once published: knobs() is one acquire load on the launch path, fv_reload_env() publishes a fresh
+// copy (the old one is leaked on purpose — a concurrent forward may still be reading it; a harness reloads a handful of times)
+static std::atomic<const Knobs*> g_knobs{nullptr};
+static std::once_flag g_knobs_once;
+static const Knobs* load_knobs() {
+    Knobs* k = new Knobs();
     if (const char* v = std::getenv("FV_PW")) {
         const int n = std::atoi(v);
-        k.pw = (v[0] == 'o' || n < 0 || n >= GEMM_PW_COUNT) ? -1 : n;
+        k->pw = (v[0] == 'o' || n < 0 || n >= GEMM_PW_COUNT) ? -1 : n;
     }
-    if (const char* v = std::getenv("FV_PW_PX")) k.pw_px = std::atoi(v);
-    k.dwln_ng8 = std::getenv("FV_DWLN_NG8") != nullptr;
-    k.dwln_rr = std::getenv("FV_DWLN_RR") != nullptr;
-    k.old_dwln = std::getenv("FV_OLD_DWLN") != nullptr;
-    if (const char* v = std::getenv("FV_WINO")) k.wino = std::atoi(v);
-    if (const char* v = std::getenv("FV_WINO_MIN_M")) k.wino_min_m = std::atoi(v);
-    if (const char* v = std::getenv("FV_WINO_CFG")) k.wino_cfg = std::atoi(v);
-    if (const char* v = std::getenv("FV_WINO_MIN_BLOCKS")) k.wino_min_blocks = std::atoi(v);
-    g_knobs = k;
-    g_knobs_loaded = true;
+    if (const char* v = std::getenv("FV_PW_PX")) k->pw_px = std::atoi(v);
+    k->dwln_ng8 = std::getenv("FV_DWLN_NG8") != nullptr;
+    k->dwln_rr = std::getenv("FV_DWLN_RR") != nullptr;
+    k->old_dwln = std::getenv("FV_OLD_DWLN") != nullptr;
+    if (const char* v = std::getenv("FV_WINO")) k->wino = std::atoi(v);
+    if (const char* v = std::getenv("FV_WINO_MIN_M")) k->wino_min_m = std::atoi(v);
+    if (const char* v = std::getenv("FV_WINO_CFG")) k->wino_cfg = std::atoi(v);
+    if (const char* v = std::getenv("FV_WINO_MIN_BLOCKS")) k->wino_min_blocks = std::atoi(v);
+    if (const char* v = std::getenv("FV_PAIR_WINO")) k->pair_wino = std::atoi(v);
+    return k;
 }
 const Knobs& knobs() {
-    if (!g_knobs_loaded) load_knobs();
-    return g_knobs;
+    const Knobs* k = g_knobs.load(std::memory_order_acquire);
+    if (!k) {
+        std::call_once(g_knobs_once, [] { g_knobs.store(load_knobs(), std::memory_order_release); });
+        k = g_knobs.load(std::memory_order_acquire);
+    }
+    return *k;
+}
+static void reload_knobs() {
+    (void)knobs();   // (the first-use initialisation has happened: nothing can overwrite the copy published below)
+    g_knobs.store(load_knobs(), std::memory_order_release);
 }
 
 int num_cus() {
@@ -2044,7 +2056,7 @@ FV_API void fv_conv_destroy(fv_conv* c) {
     delete c;
 }
 
-FV_API void fv_reload_env(void) { fv::load_knobs(); }
+FV_API void fv_reload_env(void) { fv::reload_knobs(); }
 FV_API const char* fv_last_error(void) { return g_err.c_str(); }
 FV_API int32_t fv_abi_version(void) { return FV_ABI_VERSION; }
 FV_API const char* fv_last_kernel(void) { return g_kernel.c_str(); }

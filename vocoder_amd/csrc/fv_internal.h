@@ -30,6 +30,7 @@ struct Knobs {
     int wino_min_m = 32;  // FV_WINO_MIN_M: narrowest layer (output rows) that takes it
     int wino_cfg = -1;    // FV_WINO_CFG: forced tile (WinoCfg 0 ... 2), -1 = by shape
     int wino_min_blocks = -1;   // FV_WINO_MIN_BLOCKS: fewest workgroups of a launch that takes it, -1 = default
+    int pair_wino = 1;    // FV_PAIR_WINO: 0 = the fused (c1, c2) pairs run direct sums (resblock_pair.hip), 1 = Winograd tap groups where a kernel exists
 };
 const Knobs& knobs();
 
@@ -140,6 +141,7 @@ struct ConvLayer {
     float4* d_wpw = nullptr;   // Winograd-transformed weights in the same fragment order, nv virtual taps (conv_wino_impl.h); optional
     int nv = 0;
     float4* d_wp16 = nullptr;  // 16x16x4-fragment layout, only for 16 -> 16 channel Conv1d (fused pair kernel)
+    float4* d_wpw16 = nullptr; // Winograd-transformed weights in 16x16x4 fragment order, C -> C with C in {16, 32} (pair_wino_impl.h); optional
     void* d_wph16 = nullptr;   // f16x3 mode, 16 -> 16 channel Conv1d: (wh, wl) planes of the two-samples-per-row layout (pair16_f16x3.hip)
     void* d_wph = nullptr;     // f16x3 mode: (wh, wl, wh * 2^-11) fp16 planes in 32x32x16 fragment order (optional)
     float w_scale = 1.f;       // s_w: power of two folded into those planes
@@ -230,6 +232,11 @@ bool pair_supported(int C, int ks, int dil);
 
 bool pair_f16x3_supported(const ConvLayer& c1, const ConvLayer& c2);   // wide SiLU pairs of the f16x3 precision mode
 bool launch_resblock_pair(const PairParams& p, int C, int ks, int dil, int batch, hipStream_t s);
+// Winograd F(2,3) form of the same pair (pair_wino_impl.h): p.w1 / p.w2 = the layers' d_wpw16; C in {16, 32}, dil in {1, 3, 5}
+bool pair_wino_supported(int C, int ks, int dil);
+bool launch_pair_wino_k3(const PairParams& p, int C, int dil, int batch, hipStream_t s);
+bool launch_pair_wino_k7(const PairParams& p, int C, int dil, int batch, hipStream_t s);
+bool launch_pair_wino_k11(const PairParams& p, int C, int dil, int batch, hipStream_t s);
 fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x, float* y, int batch, int t, int out_mode,
                         float out_scale, hipStream_t stream);
 

@@ -1,0 +1,413 @@
+// Fused ResBlock (c1, c2) pair on Winograd F(2,3) tap groups for the narrow stages (C = 16 / 32):
+//
+//     y = x + c2( silu( c1( silu(x) ) ) )          (one iteration of ResBlock1.forward,
+//                                                    fish_vocoder/modules/generators/hifigan.py:102-107)
+//
+// in ONE launch, with 16 / 10 / 4 matrix products per output pair and (c_out, c_in) instead of 22 / 14 / 6 (k = 11 / 7 / 3) in BOTH
+// convs.  resblock_pair.hip (direct sums) showed these stages bound by instruction issue: the fp32 matrix instruction and the fp32
+// vector ALU share the SIMD's datapath (profiles/r04a_pair_pmc.txt: SQ_ACTIVE_INST_VALU + SQ_VALU_MFMA_BUSY_CYCLES ~ 0.94 of the SIMD
+// time at C = 16), so this kernel cuts both terms: a third fewer MFMAs, and a staging / epilogue code with no per-element address,
+// clamp or mask arithmetic (every LDS / global address is a per-lane base + an immediate; range checks are the buffer descriptors').
+//
+// Pair lattice (conv_wino_impl.h): with dilation D outputs pair up as (u, u + D); pair column n = q D + r <-> u0(n) = 2 D q + r.
+// One workgroup = 4 wavefronts, one batch item, NBP = 64 pair columns (16 per wave): c1 produces the W1 = 2 * (64 / D * D) contiguous
+// samples [t0 - H2, t0 - H2 + W1), c2 the TT = W1 - (KS - 1) final samples [t0, t0 + TT) on the D = 1 lattice.
+//   phase 0   silu(x) window -> LDS as E / O planes on c1's lattice (all C channels), raw centre columns -> LDS (residual operand)
+//   per conv  for each chunk of CH channels:  transform E / O -> d0..d3 planes (LDS -> LDS), barrier, MFMA loop over virtual taps
+//             (tap groups read the d planes, the single taps 3 / 7 read E / O directly; v_mfma_f32_16x16x4_f32, weights straight
+//             from L2 in fragment order, DA fragments ahead)
+//   c1 epilogue   output transform, SiLU (bias sits in the accumulators from the start), -> E / O planes of c2's lattice (overlaying c1's)
+//   c2 epilogue   output transform, + raw x from LDS, -> HBM
+// HBM traffic = the x window once + y once, as for the direct pair kernel.
+#pragma once
+#include "conv_mfma_impl.h"
+
+namespace fv {
+
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+
+constexpr int pw_up(int v, int m, int r) { return v + ((r - v % m) % m + m) % m; }   // smallest x >= v with x % m == r
+
+#ifndef FV_X_PW_DA
+#define FV_X_PW_DA 4
+#endif
+
+template <int KS, int DIL, int C, int CH>
+struct PWGeom {
+    static_assert(C == 16 || C == 32, "16x16x4 kernel: one or two 16-row m-tiles");
+    static_assert(CH == 8 || CH == 16, "chunk = 8 or 16 channels");
+    static_assert(C % CH == 0 && CH * (C / 16) >= 16, "a chunk holds whole weight fragments");
+    static constexpr int KSZ = KS;
+    static constexpr int MT = C / 16;                    // 16-row m-tiles per wave (every wave owns all rows)
+    static constexpr int U = MT == 2 ? 1 : 2;            // weight fragments (one float4 per lane = 4 MFMAs) per macro-step
+    static constexpr int FCH = 16 / MT;                  // channels one weight fragment covers
+    static constexpr int KST = FCH / 4;                  // MFMA k-steps (4 channels each) per fragment
+    static constexpr int NG = (KS + 1) / 4, NS = (KS - 3) / 4, NV = 4 * NG + 2 * NS;
+    static constexpr int NBP = 64;                       // pair columns per workgroup
+    static constexpr int NU = NBP / DIL * DIL;           // ... of whole 2 D-sample blocks
+    static constexpr int W1 = 2 * NU, TT = W1 - (KS - 1);
+    static constexpr int H1 = (KS - 1) / 2 * DIL, H2 = (KS - 1) / 2, HP = H1 + H2;
+    static constexpr int WD1 = NBP + 2 * DIL * (NG - 1), WR1 = WD1 + DIL;   // d-plane / E-O plane columns of c1
+    static constexpr int WD2 = NBP + 2 * (NG - 1), WR2 = WD2 + 1;           // ... of c2 (dilation 1)
+    static constexpr int NQ1 = (WR1 + DIL - 1) / DIL;    // 2 D-sample blocks staged
+    static constexpr int NP1 = 2 * DIL * NQ1;            // staged positions per channel row
+    static constexpr int PE = pw_up(DIL * NQ1, 16, 8);   // E / O plane stride: row stride 2 PE == 16 (mod 32): the 16x16x4 B-fragment read
+    static constexpr int PD = pw_up(WD1, 8, 4);          // d plane stride:     row stride 4 PD == 16 (mod 32)  puts lanes 0-15 / 16-31 on disjoint banks
+    static constexpr int SE = 2 * PE, SD = 4 * PD;
+    static constexpr int XS = TT + 2;                    // raw-tile row stride (column TT: dump for the window's halo positions)
+    static constexpr int EO_F = C * SE, D_F = CH * SD, XR_F = C * XS + 16;
+    static constexpr int TRASH = EO_F + D_F + XR_F;      // one float nobody reads
+    static constexpr int LDS_FLOATS = TRASH + 4;
+    static constexpr int NF4 = CH / FCH * NV;            // weight fragments per chunk
+    static constexpr int NMS = NF4 / U;                  // macro-steps per chunk
+    static_assert(NF4 % U == 0, "whole macro-steps");
+};
+
+// Virtual tap v of a conv with dilation DX on strides (PE, PD): which accumulator plane it feeds, and where its B operand sits
+// relative to (channel row, pair column n): a d plane at a group shift, or the E / O plane for the single taps 3, 7
+template <int KS, int DX, int PE, int PD>
+struct PWTap {
+    static constexpr int NG = (KS + 1) / 4;
+    static constexpr bool from_eo(int v) { return v >= 4 * NG; }
+    static constexpr int acc_of(int v) { return v < 4 * NG ? v % 4 : ((v - 4 * NG) % 2 == 0 ? 0 : 3); }
+    static constexpr int off_of(int v) {
+        if (v < 4 * NG) return (v % 4) * PD + 2 * DX * (v / 4);
+        const int s = (v - 4 * NG) / 2;
+        return (v - 4 * NG) % 2 == 0 ? PE + (2 * s + 1) * DX : (2 * s + 2) * DX;   // + w O[n + (2s+1) D] -> m0,  - w E[n + (2s+2) D] -> m3
+    }
+};
+
+__device__ __forceinline__ float pw_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// E / O planes (rows eo .. eo + CH - 1) -> d0..d3 planes of the chunk buffer.  TPR threads per channel row, consecutive columns.
+template <class G, int DX, int WD>
+__device__ __forceinline__ void pw_transform(const float* __restrict__ eo, float* __restrict__ d, int tid) {
+    constexpr int CHn = G::D_F / G::SD;
+    constexpr int TPR = 256 / CHn, SLOTS = (WD + TPR - 1) / TPR;
+    const int row = tid / TPR, c0 = tid % TPR;
+    const float* e = eo + row * G::SE + c0;
+    float* dd = d + row * G::SD + c0;
+    float E[SLOTS], E1[SLOTS], O[SLOTS], O1[SLOTS];
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        E[j] = e[TPR * j];
+        E1[j] = e[TPR * j + DX];
+        O[j] = e[G::PE + TPR * j];
+        O1[j] = e[G::PE + TPR * j + DX];
+    }
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        if (TPR * (j + 1) <= WD || c0 + TPR * j < WD) {
+            dd[TPR * j] = E[j] - E1[j];
+            dd[G::PD + TPR * j] = O[j] + E1[j];
+            dd[2 * G::PD + TPR * j] = E1[j] - O[j];
+            dd[3 * G::PD + TPR * j] = O[j] - O1[j];
+        }
+    }
+}
+
+// MFMA loop over one chunk: NF4 weight fragments, four 16x16x4 MFMAs each.  dl / el: the lane's base into the d planes / the chunk's
+// E-O rows (k-quarter row and pair column folded in).  aq: weight ring, fragments [f, f + DA) of the conv on entry and on exit.
+template <class G, int DX>
+__device__ __forceinline__ void pw_gemm_chunk(f32x4w (&acc)[4][G::MT], const float* __restrict__ dl, const float* __restrict__ el,
+                                              const __amdgpu_buffer_rsrc_t wrs, int wvoff, int wsoff, float4 (&aq)[FV_X_PW_DA + G::U]) {
+    constexpr int DA = FV_X_PW_DA, U = G::U, KST = G::KST, MT = G::MT, NV = G::NV;
+    using TP = PWTap<G::KSZ, DX, G::PE, G::PD>;
+    constexpr int NB = U * KST;       // B registers per macro-step
+    constexpr int NM = 4 * U;         // MFMAs per macro-step
+    float b_cur[NB], b_nxt[NB];
+    auto b_addr = [&](int f, int s) __attribute__((always_inline)) -> const float* {   // fragment f of the chunk, k-step s
+        const int sb = f / NV, v = f % NV;
+        const int rowc = sb * G::FCH + 4 * s;
+        return TP::from_eo(v) ? el + rowc * G::SE + TP::off_of(v) : dl + rowc * G::SD + TP::off_of(v);
+    };
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_cur[i] = *b_addr(i / KST, i % KST);
+    static_for<G::NMS>([&](auto ms_c) __attribute__((always_inline)) {
+        constexpr int ms = decltype(ms_c)::value;
+        constexpr int f0 = ms * U;
+        constexpr int NLDX = U + NB;   // memory operations of this macro-step: U weight loads (DA fragments ahead), NB LDS reads (next macro-step)
+        // each of them is requested BETWEEN two MFMAs: an in-order wave hides a memory instruction's issue time only under a matrix
+        // instruction that is already executing (conv_mfma_impl.h)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            // MT == 2: (s0, mt0) (s0, mt1) (s1, mt0) (s1, mt1) of one fragment; MT == 1: the k-steps of two fragments alternate (their
+            // accumulator planes differ: a 16x16x4 MFMA has 40 cycles of dependent latency against 32 of issue)
+            const int u = MT == 2 ? 0 : m % 2;
+            const int s = m / 2;
+            const int mt = MT == 2 ? m % 2 : 0;
+            const int comp = MT == 2 ? m : m / 2;
+            const int A = TP::acc_of((f0 + u) % NV);
+            const float4 a4 = u == 0 ? aq[0] : aq[U - 1];
+            const float av = comp == 0 ? a4.x : comp == 1 ? a4.y : comp == 2 ? a4.z : a4.w;
+            // The matrix instruction is a pure value to the instruction selector, which is free to float it past the (ordered) memory
+            // operations and scheduling barriers around it — and did: every MFMA of c1 ended up behind all of the chunk's loads, 112
+            // operands live.  Two empty volatile asm statements (ordered like the loads) pin it: its B operand passes through one
+            // before it, its result through one after it.
+            float bv = b_cur[u * KST + s];
+            asm volatile("" : "+v"(bv));
+            acc[A][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[A][mt], 0, 0, 0);
+            asm volatile("" : "+v"(acc[A][mt]));
+#pragma unroll
+            for (int k = 0; k < NLDX; ++k) {
+                if (k * NM / NLDX == m) {
+                    if (k < U) {
+                        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff + (f0 + k) * 1024, 0);
+                        const float4 wv = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+                        if (k == 0) aq[DA] = wv; else aq[DA + U - 1] = wv;
+                    } else if (ms + 1 < G::NMS) {
+                        b_nxt[k - U] = *b_addr(f0 + U + (k - U) / KST, (k - U) % KST);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < DA; ++d) aq[d] = aq[d + U];
+        if (ms + 1 < G::NMS) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) b_cur[i] = b_nxt[i];
+        }
+    });
+}
+
+template <int KS, int DIL, int C, int CH>
+__global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p) {
+    using G = PWGeom<KS, DIL, C, CH>;
+    constexpr int MT = G::MT, DA = FV_X_PW_DA, U = G::U, NCHK = C / CH;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* EO = lds;
+    float* Db = lds + G::EO_F;
+    float* Xr = lds + G::EO_F + G::D_F;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // a clip's neighbouring tiles on one XCD (they share the cache lines of their halo columns): resblock_pair.hip
+    const int lid = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (lid >= p.n_tiles * p.batch) return;
+    const int tile = lid % p.n_tiles, b = lid / p.n_tiles;
+    const int t0 = tile * G::TT;
+    const int T = p.T;
+    const float* __restrict__ xb = p.x + (long long)b * C * T;
+
+    // weight rings: c1's first fragments are requested before anything else
+    const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 0x7fffffff, 0x00020000);
+    const int wvoff = lane * 16;
+    float4 aq[DA + U];
+    auto load_w = [&](const __amdgpu_buffer_rsrc_t rs, int f) __attribute__((always_inline)) {
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, wvoff, f * 1024, 0);
+        return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    };
+#pragma unroll
+    for (int d = 0; d < DA; ++d) aq[d] = load_w(w1rs, d);
+
+    // ---- phase 0: silu(x) window -> E / O planes of c1's lattice; raw centre columns -> Xr ----
+    {
+        constexpr int NFULL = G::NP1 / 64, TAILW = G::NP1 % 64, RPW = C / 4, NTAIL = (RPW * TAILW + 63) / 64;
+        const int ws = t0 - G::HP;
+        const int row0 = wave * RPW;
+        auto eo_of = [&](int pp) {   // position of the window -> offset inside a channel row's E / O planes
+            const int q = pp / (2 * DIL), rem = pp - 2 * DIL * q;
+            const int hi = rem >= DIL ? 1 : 0;
+            return hi * G::PE + q * DIL + rem - hi * DIL;
+        };
+        auto xr_of = [&](int pp) {
+            const int c = pp - G::HP;
+            return (c >= 0 && c < G::TT) ? c : G::TT;
+        };
+        float v[RPW][NFULL > 0 ? NFULL : 1];
+        float vt[NTAIL > 0 ? NTAIL : 1];
+        int eo_off[NFULL > 0 ? NFULL : 1], xr_off[NFULL > 0 ? NFULL : 1];
+        unsigned voff[NFULL > 0 ? NFULL : 1];
+#pragma unroll
+        for (int i = 0; i < NFULL; ++i) {
+            const int pp = lane + 64 * i;
+            eo_off[i] = row0 * G::SE + eo_of(pp);
+            xr_off[i] = row0 * G::XS + xr_of(pp);
+            voff[i] = (unsigned)(ws + pp) * 4u;   // negative positions wrap past the descriptor's size: the load returns 0
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (long long)(row0 + rr) * T), 0, (unsigned)T * 4u, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NFULL; ++i) v[rr][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff[i], 0, 0));
+        }
+        // the last TAILW positions of the wave's rows, flattened over (row, position): whole lanes instead of RPW part-filled slots
+        int eo_t[NTAIL > 0 ? NTAIL : 1], xr_t[NTAIL > 0 ? NTAIL : 1];
+        if constexpr (NTAIL > 0) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)(C * T) * 4u, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NTAIL; ++j) {
+                const int e = lane + 64 * j;
+                const bool ok = e < RPW * TAILW;
+                const int rr = e / TAILW, pp = NFULL * 64 + e - rr * TAILW;
+                const int tpos = ws + pp;
+                const bool in = ok && tpos >= 0 && tpos < T;
+                eo_t[j] = ok ? (row0 + rr) * G::SE + eo_of(pp) : G::TRASH;
+                const int xc = xr_of(pp);
+                xr_t[j] = ok ? (row0 + rr) * G::XS + xc : G::TRASH - G::EO_F - G::D_F;   // (Xr-relative)
+                vt[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, in ? (unsigned)((row0 + rr) * T + tpos) * 4u : 0xFFFFFFFFu, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int i = 0; i < NFULL; ++i) {
+                EO[eo_off[i] + rr * G::SE] = pw_silu(v[rr][i]);   // silu(0) == 0: the conv's zero padding
+                Xr[xr_off[i] + rr * G::XS] = v[rr][i];
+            }
+        if constexpr (NTAIL > 0) {
+#pragma unroll
+            for (int j = 0; j < NTAIL; ++j) {
+                EO[eo_t[j]] = pw_silu(vt[j]);
+                Xr[xr_t[j]] = vt[j];
+            }
+        }
+    }
+
+    // accumulators: the bias rides in m0 (+b) and m3 (-b): y0 = m0 + m1 + m2, y1 = m1 - m2 - m3
+    const int krow = lane >> 4;               // C / D layout of 16x16x4: row = 4 (lane >> 4) + reg, column = lane & 15
+    const int ncol = 16 * wave + (lane & 15);
+    f32x4w acc[4][MT];
+    auto init_acc = [&](const float* __restrict__ bias) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const f32x4w bv = *(const f32x4w*)(bias + 16 * i + 4 * krow);
+            acc[0][i] = bv;
+            acc[3][i] = -bv;
+            acc[1][i] = f32x4w{0.f, 0.f, 0.f, 0.f};
+            acc[2][i] = f32x4w{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    init_acc(p.b1);
+    const float* dl = Db + krow * G::SD + ncol;
+    const float* el = EO + krow * G::SE + ncol;
+    __syncthreads();
+
+    // ---- c1 ----
+    for (int c = 0; c < NCHK; ++c) {
+        pw_transform<G, DIL, G::WD1>(EO + c * CH * G::SE, Db, tid);
+        __syncthreads();
+        pw_gemm_chunk<G, DIL>(acc, dl, el + c * CH * G::SE, w1rs, wvoff, __builtin_amdgcn_readfirstlane((c * G::NF4 + DA) * 1024), aq);
+        __syncthreads();   // the chunk buffer (next transform) and the E / O planes (c1 epilogue) are free again
+    }
+    // c2's first weight fragments travel while the epilogue runs (the ring holds c1's overrun fragments: zeros, never used)
+#pragma unroll
+    for (int d = 0; d < DA; ++d) aq[d] = load_w(w2rs, d);
+
+    // ---- c1 epilogue: silu(c1 + b1) -> E / O planes of c2's lattice (mid[u], u = position - (t0 - H2): E2[u >> 1] / O2[u >> 1]) ----
+    {
+        const int q = ncol / DIL, r = ncol - q * DIL;
+        const int u0 = 2 * DIL * q + r, u1 = u0 + DIL;
+        float* w0 = EO + 4 * krow * G::SE + (u0 & 1) * G::PE + (u0 >> 1);
+        float* w1 = EO + 4 * krow * G::SE + (u1 & 1) * G::PE + (u1 >> 1);
+        const int ts = t0 - G::H2;
+        const bool edge = ts < 0 || ts + 2 * G::NBP + DIL > T;   // wave-uniform: only a row's first / last tiles zero positions outside [0, T)
+        float k0 = 1.f, k1 = 1.f;
+        if (edge) {
+            k0 = (ts + u0 >= 0 && ts + u0 < T) ? 1.f : 0.f;
+            k1 = (ts + u1 >= 0 && ts + u1 < T) ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const f32x4w y0 = (acc[0][i] + acc[1][i]) + acc[2][i];
+            const f32x4w y1 = (acc[1][i] - acc[2][i]) - acc[3][i];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float s0 = pw_silu(y0[rg]), s1 = pw_silu(y1[rg]);
+                if (edge) {
+                    s0 *= k0;
+                    s1 *= k1;
+                }
+                w0[(16 * i + rg) * G::SE] = s0;
+                w1[(16 * i + rg) * G::SE] = s1;
+            }
+        }
+    }
+    init_acc(p.b2);
+    __syncthreads();
+
+    // ---- c2 (dilation 1) ----
+    for (int c = 0; c < NCHK; ++c) {
+        pw_transform<G, 1, G::WD2>(EO + c * CH * G::SE, Db, tid);
+        __syncthreads();
+        pw_gemm_chunk<G, 1>(acc, dl, el + c * CH * G::SE, w2rs, wvoff, __builtin_amdgcn_readfirstlane((c * G::NF4 + DA) * 1024), aq);
+        if (c + 1 < NCHK) __syncthreads();
+    }
+
+    // ---- c2 epilogue: + raw x (LDS) -> y ----
+    {
+        const int tl = 2 * ncol;                       // first of the lane's two output columns inside the tile
+        const int t = t0 + tl;
+        const unsigned va = (tl < G::TT && t < T) ? (unsigned)(4 * krow * T + t) * 4u : 0xFFFFFFFFu;
+        const unsigned vb = (tl + 1 < G::TT && t + 1 < T) ? (unsigned)(4 * krow * T + t + 1) * 4u : 0xFFFFFFFFu;
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)b * C * T), 0, (unsigned)(C * T) * 4u, 0x00020000);
+        const float* xl = Xr + 4 * krow * G::XS + (tl < G::TT ? tl : 0);
+        const bool accum = p.out_mode == OUT_ACCUM;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const f32x4w y0 = (acc[0][i] + acc[1][i]) + acc[2][i];
+            const f32x4w y1 = (acc[1][i] - acc[2][i]) - acc[3][i];
+            float o0[4], o1[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x2w xr = *(const f32x2w*)(xl + (16 * i + rg) * G::XS);
+                o0[rg] = y0[rg] + xr.x;
+                o1[rg] = y1[rg] + xr.y;
+            }
+            if (accum) {
+                float a0[4], a1[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int so = __builtin_amdgcn_readfirstlane((16 * i + rg) * T * 4);
+                    a0[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, va, so, 0));
+                    a1[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, vb, so, 0));
+                }
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    o0[rg] = (a0[rg] + o0[rg]) * p.out_scale;
+                    o1[rg] = (a1[rg] + o1[rg]) * p.out_scale;
+                }
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int so = __builtin_amdgcn_readfirstlane((16 * i + rg) * T * 4);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0[rg]), yrs, va, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1[rg]), yrs, vb, so, 0);
+            }
+        }
+    }
+}
+
+template <int KS, int DIL, int C, int CH>
+inline bool launch_pair_wino16_one(const PairParams& p, int batch, hipStream_t s) {
+    using G = PWGeom<KS, DIL, C, CH>;
+    PairParams q = p;
+    q.n_tiles = (p.T + G::TT - 1) / G::TT;
+    q.batch = batch;
+    const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+    if (!FV_ENSURE_DYN_LDS((pair_wino16_kernel<KS, DIL, C, CH>), lds)) return false;
+    hipLaunchKernelGGL((pair_wino16_kernel<KS, DIL, C, CH>), dim3((batch * q.n_tiles + 7) / 8 * 8), dim3(256), lds, s, q);
+    return true;
+}
+
+#ifndef FV_X_PW_CH32
+#define FV_X_PW_CH32 8
+#endif
+
+template <int KS>
+inline bool launch_pair_wino16_k(const PairParams& p, int C, int dil, int batch, hipStream_t s) {
+#define FV_PW_CASE(D)                                                                      \
+    if (dil == D) {                                                                        \
+        if (C == 16) return launch_pair_wino16_one<KS, D, 16, 16>(p, batch, s);            \
+        if (C == 32) return launch_pair_wino16_one<KS, D, 32, FV_X_PW_CH32>(p, batch, s);  \
+    }
+    FV_PW_CASE(1) FV_PW_CASE(3) FV_PW_CASE(5)
+#undef FV_PW_CASE
+    return false;
+}
+
+}  // namespace fv
