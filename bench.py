@@ -14,8 +14,10 @@ Lightning's one-process-per-device launch, configs/trainer/default.yaml:6-9).
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline        — the dominant kernel of the forward (by total time), timed live with hipEvents on the launch stream by
-                    the engine's per-launch profiler (fv_profile_*), algorithmic flops per launch / avg duration vs the
-                    fp32-MFMA peak (or bytes vs HBM peak when that is the binding roof);
+                    the engine's per-launch profiler (fv_profile_*): `achieved` / `frac` = matrix flops the kernel ISSUES per launch /
+                    avg duration vs the fp32-MFMA peak (a hardware fraction, <= 1; bytes vs the HBM peak when that roof binds);
+                    a Winograd kernel issues fewer products than the layer's direct sum — the algorithmic rate (what the reference
+                    computes, over the same time) is carried as `algorithmic_tflops`, the ratio as `algorithmic_speedup`;
   with_collectives— the same K steps with config[4]'s "result collection over RCCL" inside the timed region: rank 0 owns the
                     global batch, every step = broadcast mels -> forward on the rank's shard -> all_gather waveforms; not the
                     headline value;
@@ -269,11 +271,12 @@ _WINO_PRODUCTS = {3: 4 / 6, 7: 10 / 14, 11: 16 / 22}   # matrix products per out
 
 
 def executed_flops(rec: dict) -> float:
-    """MFMA flops a launch really issues: the algorithmic (direct-sum) count, except for the Winograd convs (conv_wino_impl.h), which
-    compute the same outputs with 4 / 10 / 16 products per output pair instead of 6 / 14 / 22."""
+    """MFMA flops a launch really issues: the algorithmic (direct-sum) count, except for the Winograd kernels (conv_wino_impl.h,
+    pair_wino_impl.h), which compute the same outputs with 4 / 10 / 16 products per output pair instead of 6 / 14 / 22."""
     k = rec["kernel"]
-    if k.startswith("conv_wino<k="):
-        return rec["flops_per_launch"] * _WINO_PRODUCTS[int(k[len("conv_wino<k="):].split()[0])]
+    for pre in ("conv_wino<k=", "pair_wino<k="):
+        if k.startswith(pre):
+            return rec["flops_per_launch"] * _WINO_PRODUCTS[int(k[len(pre):].split()[0])]
     return rec["flops_per_launch"]
 
 
@@ -304,13 +307,17 @@ def roofline_from_profile(table: list[dict], repeats: int) -> dict:
         except Exception:
             traffic = None
     if t_mfma >= t_hbm:
-        out = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf}
+        # `achieved` / `frac` = flops the matrix pipe ISSUES per second against its dense peak (a hardware fraction, <= 1).  For a Winograd
+        # kernel that is fewer than the layer's algorithmic flops: the direct sum the reference computes is carried next to it as
+        # algorithmic_tflops, and algorithmic_speedup = algorithmic / issued products (22/16, 14/10, 6/4)
         ex = executed_flops(top)
+        ex_tf = ex / t_s / 1e12
+        out = {"bound": "mfma", "achieved": ex_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ex_tf / peak_tf,
+               "issued_flops_per_launch": ex, "algorithmic_tflops": tf, "algorithmic_speedup": top["flops_per_launch"] / ex}
         if ex != top["flops_per_launch"]:
-            out.update({"executed": ex / t_s / 1e12, "frac_executed": ex / t_s / 1e12 / peak_tf, "executed_flops_per_launch": ex,
-                        "note": "achieved / frac count the ALGORITHMIC flops of the layer (2 C_in C_out k T B, the direct sum the reference "
-                                "computes); this kernel produces the same outputs from Winograd F(2,3) tap groups, so the matrix pipe issues "
-                                "executed_flops_per_launch: frac_executed is its utilisation against the fp32 MFMA peak"})
+            out["note"] = ("achieved / frac count the matrix products the kernel issues (Winograd F(2,3) tap groups: issued_flops_per_launch); "
+                           "algorithmic_tflops counts the layer's direct sum 2 C_in C_out k T B (flops_per_launch) over the same time and "
+                           "may exceed the peak")
         if peak_tf != PEAK_MFMA_F32_TFLOPS:
             out["peak_note"] = "dense fp16 MFMA peak 2500 TFLOP/s / 3 products per MAC (f16x3 split)"
     else:
@@ -323,13 +330,13 @@ def roofline_from_profile(table: list[dict], repeats: int) -> dict:
 
 
 def step_roofline(table, repeats, ms_per_step, peak_tf=PEAK_MFMA_F32_TFLOPS) -> dict:
+    """Whole step against the MFMA roof: `frac` = issued matrix flops / time / peak (<= 1); the algorithmic (direct-sum) flops of the same
+    step are carried as algorithmic_tflops (they exceed the issued ones where Winograd kernels run)."""
     flops = sum(r["flops_per_launch"] * (r["launches"] // repeats) for r in table)
-    ach = flops / (ms_per_step * 1e-3) / 1e12
     ex = sum(executed_flops(r) * (r["launches"] // repeats) for r in table)
-    out = {"flops_per_step": flops, "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf}
-    if ex != flops:   # Winograd convs in the step: algorithmic flops above, issued MFMA flops here
-        out.update({"executed_flops_per_step": ex, "frac_executed": ex / (ms_per_step * 1e-3) / 1e12 / peak_tf})
-    return out
+    ach = ex / (ms_per_step * 1e-3) / 1e12
+    return {"flops_per_step": flops, "issued_flops_per_step": ex, "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
+            "algorithmic_tflops": flops / (ms_per_step * 1e-3) / 1e12, "algorithmic_speedup": flops / ex}
 
 
 def time_engine(eng, mel, out, steps, warmup, dev) -> float:

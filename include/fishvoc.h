@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 2
+#define FV_ABI_VERSION 3
 
 /* every entry point below is exported with default visibility (the library is built -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -179,12 +179,37 @@ FV_API void fv_destroy(fv_engine* e);
  * are packed at finalize; later -> FV_ERR_STATE).  No reference counterpart: torch runs this path in fp32 only. */
 FV_API fv_status fv_set_precision(fv_engine* e, int32_t precision);
 
+/* How the fp32 conv layers form their sums (FV_PRECISION_F32 only; no reference counterpart: torch picks its own convolution algorithm per
+ * call).  Every choice computes in fp32 and stays well inside the parity bar (whole forwards differ by <= 2e-5 of full scale between them);
+ * what changes is the LAST BITS of a clip's output and the speed:
+ *   FV_CONV_ALGO_AUTO      per launch, whatever is fastest: Winograd F(2,3) tap groups for the dilated k = 3 / 7 / 11 ResBlock / AMPBlock convs of
+ *                          launches that fill the chip (>= CUs / 2 workgroups: depends on batch size, clip length and the device's CU count),
+ *                          direct sums otherwise; the fused (c1, c2) pairs of the narrow stages use Winograd whenever a kernel exists.  Default.
+ *   FV_CONV_ALGO_DIRECT    direct sums everywhere.
+ *   FV_CONV_ALGO_WINOGRAD  Winograd wherever a kernel exists, whatever the launch size.
+ * fv_set_batch_invariant(e, 1) additionally makes EVERY kernel choice a function of the layer shape alone (C, k, dilation) — never of the
+ * batch size, the clip length or the device partition: no split-K latency kernels, the fused pairs and the pointwise GEMM wherever their
+ * shape allows, and (under FV_CONV_ALGO_AUTO) Winograd wherever a kernel exists.  A clip's output is then bit-identical whichever other clips
+ * share its batch — e.g. a 37-clip batch sharded 5/5/5/5/5/4/4/4 over 8 GPUs equals the single-GPU batch bit for bit — at the price of
+ * single-clip latency (the launch-size gates exist because small launches are faster on the direct / split-K kernels).  Without it, batches
+ * that differ in size may differ in the last bits (<= 2e-5 of full scale; tests/test_gpu_models.py pins the bound).
+ * Both may be called at any time; captured graphs are dropped. */
+typedef enum fv_conv_algo {
+    FV_CONV_ALGO_AUTO = 0,
+    FV_CONV_ALGO_DIRECT = 1,
+    FV_CONV_ALGO_WINOGRAD = 2
+} fv_conv_algo;
+FV_API fv_status fv_set_conv_algorithm(fv_engine* e, int32_t algo);
+FV_API fv_status fv_set_batch_invariant(fv_engine* e, int32_t enable);
+
 /* hipGraph replay of the static launch sequence (on by default; a call with the same buffers / shape / stream as an
  * earlier one replays a captured graph).  enable = 0 makes every fv_forward* enqueue its kernels eagerly — what a server
  * that never sees the same (buffers, batch, frames) twice gets.  May be called at any time.  No reference counterpart. */
 FV_API fv_status fv_set_graph_replay(fv_engine* e, int32_t enable);
 
-/* Kernel-selection knobs for experiments (FV_PW, FV_PW_PX, FV_DWLN_NG8, FV_DWLN_RR, FV_OLD_DWLN) are read from the environment
+/* Kernel-selection knobs for experiments (FV_PW, FV_PW_PX, FV_DWLN_NG8, FV_DWLN_RR, FV_OLD_DWLN; FV_WINO = 0 / 1 / 2 — the process-wide default
+ * of fv_set_conv_algorithm: direct / auto / Winograd —, FV_WINO_MIN_M, FV_WINO_CFG, FV_WINO_MIN_BLOCKS, FV_PAIR_WINO: these change which sums are
+ * formed, i.e. the last bits of the output) are read from the environment
  * ONCE per process (no getenv on the launch path); a harness that changes them afterwards calls this to re-read them.
  * Not for production use; not thread-safe against concurrent forwards.  No reference counterpart. */
 FV_API void fv_reload_env(void);
@@ -254,6 +279,8 @@ FV_API fv_status fv_conv_pair_forward(fv_conv* c1, fv_conv* c2, const float* d_x
 /* fv_precision for the following fv_conv_forward calls on this layer; layers the split-fp16 kernels do not cover
  * (transposed, C_in < 32, kernel size not in {3, 7, 11}) keep running in fp32. */
 FV_API fv_status fv_conv_set_precision(fv_conv* c, int32_t precision);
+/* fv_conv_algo for the following fv_conv_forward / fv_conv_pair_forward calls on this layer (for a pair: c1's setting). */
+FV_API fv_status fv_conv_set_algorithm(fv_conv* c, int32_t algo);
 FV_API void fv_conv_destroy(fv_conv* c);
 
 /* -------- per-launch timing (measurement aid; bench.py's roofline leg) --------

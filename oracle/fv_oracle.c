@@ -220,6 +220,26 @@ FVO_API void fvo_conv_transpose1d(const float* x, const float* w, const float* b
         float* xr = (float*)malloc((size_t)B * Cin * Tin * sizeof(float));
         const int Tc = Tin + kp - 1;                               /* conv output length with padding kp-1 on both sides */
         float* u = (float*)malloc((size_t)B * Cout * Tc * sizeof(float));
+        if (!wp || !xr || !u) {
+            /* out of memory for the phase buffers: the plain gather form of the same sums (ci ascending, tap ascending, one
+             * fused multiply-add per product — the whole file is compiled with -ffp-contract=fast, see the Makefile) */
+            free(wp);
+            free(xr);
+            free(u);
+            for (int b = 0; b < B; ++b)
+                for (int co = 0; co < Cout; ++co)
+                    for (int q = q_lo; q < q_hi; ++q) {
+                        float acc = bias ? bias[co] : 0.0f;
+                        for (int ci = 0; ci < Cin; ++ci)
+                            for (int m = 0; m < kp; ++m) {
+                                const int i = q - m;
+                                if (i >= 0 && i < Tin)
+                                    acc = __builtin_fmaf(w[((int64_t)ci * Cout + co) * k + r + m * stride], x[((int64_t)b * Cin + ci) * Tin + i], acc);
+                            }
+                        y[((int64_t)b * Cout + co) * Tout + q * stride + r - pad] = acc;
+                    }
+            continue;
+        }
         for (int co = 0; co < Cout; ++co)
             for (int ci = 0; ci < Cin; ++ci)
                 for (int m = 0; m < kp; ++m) wp[((int64_t)co * Cin + ci) * kp + m] = w[((int64_t)ci * Cout + co) * k + r + m * stride];

@@ -25,6 +25,11 @@ def _run(w, b, x, res=None, **kw):
     return y.cpu().numpy()
 
 
+def _last_kernel():
+    from vocoder_amd import _lib
+    return _lib.last_kernel()
+
+
 def _check(y, ref, atol=1e-4):
     assert y.shape == ref.shape, (y.shape, ref.shape)
     err = np.abs(y - ref).max()
@@ -178,6 +183,37 @@ def test_fused_resblock_pair_matches_oracle(C, k, d, B, T):
     y = c1.pair(c2, torch.from_numpy(x).to(_dev()))
     torch.cuda.synchronize()
     _check(y.cpu().numpy(), ref)
+
+
+PAIR_WINO_CASES = [(C, k, d) for C in (16, 32) for k in (3, 7, 11) for d in (1, 3, 5)]
+
+
+@pytest.mark.parametrize("C,k,d", PAIR_WINO_CASES)
+def test_winograd_pair_matches_oracle_and_direct_pair(C, k, d):
+    """pair_wino_impl.h: every (C, k, dilation) variant of the Winograd fused pair on ragged shapes — several tiles with a ragged last one,
+    a row shorter than one tile, T = 1 and an odd T — against the CPU oracle (reference hifigan.py:102-107), and against the direct-sum pair
+    kernel selected through the C ABI (fv_conv_set_algorithm): same outputs to fp32 rounding, other sums."""
+    from vocoder_amd.engine import FusedConv
+    rng = np.random.default_rng(7 * C + 13 * k + d)
+    w1 = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    w2 = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    b1 = rng.normal(size=C).astype(np.float32)
+    b2 = rng.normal(size=C).astype(np.float32)
+    c1 = FusedConv(w1, b1, dilation=d, padding=(k * d - d) // 2)
+    c2 = FusedConv(w2, b2, padding=(k - 1) // 2)
+    for B, T in ((2, 1000 + 37 * d), (1, 61), (3, 1), (1, 2 * 128 - k)):
+        x = rng.normal(size=(B, C, T)).astype(np.float32)
+        xt = orc.conv1d(orc.silu(x), w1, b1, dilation=d, padding=(k * d - d) // 2)
+        ref = x + orc.conv1d(orc.silu(xt), w2, b2, padding=(k - 1) // 2)
+        xd = torch.from_numpy(x).to(_dev())
+        y = c1.set_algorithm("auto").pair(c2, xd)
+        torch.cuda.synchronize()
+        assert _last_kernel().startswith("pair_wino<"), _last_kernel()
+        _check(y.cpu().numpy(), ref)
+        yd = c1.set_algorithm("direct").pair(c2, xd)
+        torch.cuda.synchronize()
+        assert _last_kernel().startswith("resblock_pair<"), _last_kernel()
+        assert float((y - yd).abs().max()) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
 
 
 def test_fused_pair_rejects_unsupported_shapes():

@@ -987,3 +987,46 @@ def test_winograd_convs_against_the_direct_sums_and_the_oracle(model, monkeypatc
     finally:
         monkeypatch.delenv("FV_WINO", raising=False)
         _lib.reload_env()
+
+
+def test_ragged_shards_against_the_global_batch_and_the_batch_invariant_switch():
+    """Utterance sharding with a ragged split (37 one-second clips over 8 ranks: 5,5,5,5,5,4,4,4 — vocoder_amd.sharding.shard_slice; the
+    reference's 8-device launch is configs/trainer/default.yaml:6-9).  The default engine chooses direct sums or Winograd tap groups per
+    LAUNCH (>= CUs / 2 workgroups), so a 4-clip shard and the 37-clip batch may add a clip's products in another order: the outputs agree to
+    <= 2e-5 of full scale (the parity bar is 1e-4).  With fv_set_batch_invariant every kernel choice follows from the layer shape alone and
+    the shards equal the global batch — and a clip run alone — BIT FOR BIT; fv_set_conv_algorithm(direct) + batch-invariant likewise."""
+    from vocoder_amd.sharding import shard_sizes, shard_slice
+    cfg = dict(syn.HIFIGAN_V1_44K)
+    sd = syn.hifigan_state_dict(cfg, seed=21)
+    B, W = 37, 8
+    assert shard_sizes(B, W) == [5, 5, 5, 5, 5, 4, 4, 4]
+    x = torch.from_numpy(syn.synthetic_mel(B, 80, 86, seed=99)).to(_dev())
+    eng = _hifigan_engine(cfg, sd)
+    y = eng(x).clone()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for r in (0, 4, 5, 7):
+        sl = shard_slice(B, W, r)
+        ys = eng(x[sl])
+        torch.cuda.synchronize()
+        worst = max(worst, float((ys - y[sl]).abs().max()))
+    assert worst <= 2e-5, worst
+    for algo in ("auto", "direct"):
+        eng.set_conv_algorithm(algo)
+        eng.set_batch_invariant(True)
+        yi = eng(x).clone()
+        torch.cuda.synchronize()
+        assert float((yi - y).abs().max()) <= 2e-5
+        for r in range(W):
+            sl = shard_slice(B, W, r)
+            ys = eng(x[sl])
+            torch.cuda.synchronize()
+            assert torch.equal(ys, yi[sl]), (algo, r, float((ys - yi[sl]).abs().max()))
+        y1 = eng(x[17:18])
+        torch.cuda.synchronize()
+        assert torch.equal(y1, yi[17:18]), algo
+        prof = [r["kernel"] for r in eng.profile(x[:4], repeats=1)]
+        assert not any("splitK" in k for k in prof), prof[:10]
+        assert any(k.startswith("conv_wino<") for k in prof) == (algo == "auto"), prof[:10]
+        eng.set_batch_invariant(False)
+    eng.close()

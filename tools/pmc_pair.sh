@@ -12,9 +12,9 @@ for d in ("a","b","c"):
     f=max(glob.glob("$R/gpurun_out/pmc_pair_%s/*/*_counter_collection.csv"%d), key=os.path.getmtime)
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "resblock_pair" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "pair" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for c,v in agg.items(): print("%-28s n=%d mean=%.4g"%(c,len(v),sum(v)/len(v)))
     kt=max(glob.glob("$R/gpurun_out/pmc_pair_%s/*/*_kernel_trace.csv"%d), key=os.path.getmtime)
-    ds=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in csv.DictReader(open(kt)) if "resblock_pair" in r["Kernel_Name"]]
+    ds=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in csv.DictReader(open(kt)) if "pair" in r["Kernel_Name"]]
     print("duration us", sum(ds)/len(ds), len(ds))
 PY

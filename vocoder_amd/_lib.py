@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # FV_LIB_PATH points the loader at an experimental build (A/B kernel variants); default = the in-tree library
 LIB_PATH = os.environ.get("FV_LIB_PATH") or os.path.join(CSRC, "libfishvoc_hip.so")
 
-FV_ABI_VERSION = 2
+FV_ABI_VERSION = 3
 FV_MAX_STAGES = 8
 FV_MAX_KERNELS = 8
 FV_MAX_DILATIONS = 3
@@ -24,6 +24,8 @@ FV_MODEL_LOGMEL = 7
 FV_MODEL_REFINEGAN = 8
 FV_PRECISION_F32, FV_PRECISION_F16X3 = 0, 1
 PRECISIONS = {"f32": FV_PRECISION_F32, "f16x3": FV_PRECISION_F16X3}
+FV_CONV_ALGO_AUTO, FV_CONV_ALGO_DIRECT, FV_CONV_ALGO_WINOGRAD = 0, 1, 2
+CONV_ALGOS = {"auto": FV_CONV_ALGO_AUTO, "direct": FV_CONV_ALGO_DIRECT, "winograd": FV_CONV_ALGO_WINOGRAD}
 FV_ACT_NONE, FV_ACT_SILU, FV_ACT_LEAKY_RELU, FV_ACT_GELU, FV_ACT_TANH, FV_ACT_LOG_CLAMP = 0, 1, 2, 3, 4, 5
 
 EXPORTS = (
@@ -32,7 +34,7 @@ EXPORTS = (
     "fv_conv_forward", "fv_conv_destroy", "fv_last_error", "fv_abi_version", "fv_last_kernel",
     "fv_profile_begin", "fv_profile_end", "fv_conv_pair_forward", "fv_forward_template",
     "fv_set_precision", "fv_conv_set_precision", "fv_refinegan_noise_elems", "fv_forward_refinegan",
-    "fv_set_graph_replay", "fv_reload_env",
+    "fv_set_graph_replay", "fv_reload_env", "fv_set_conv_algorithm", "fv_set_batch_invariant", "fv_conv_set_algorithm",
 )
 
 _i32 = ctypes.c_int32
@@ -143,6 +145,12 @@ def lib() -> ctypes.CDLL:
     L.fv_reload_env.restype = None
     L.fv_set_graph_replay.argtypes = [vp, _i32]
     L.fv_set_graph_replay.restype = _i32
+    L.fv_set_conv_algorithm.argtypes = [vp, _i32]
+    L.fv_set_conv_algorithm.restype = _i32
+    L.fv_set_batch_invariant.argtypes = [vp, _i32]
+    L.fv_set_batch_invariant.restype = _i32
+    L.fv_conv_set_algorithm.argtypes = [vp, _i32]
+    L.fv_conv_set_algorithm.restype = _i32
     L.fv_conv_set_precision.argtypes = [vp, _i32]
     L.fv_conv_set_precision.restype = _i32
     L.fv_profile_begin.argtypes = [vp]

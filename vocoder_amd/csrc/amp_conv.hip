@@ -36,7 +36,7 @@ struct AmpGeom {
     static constexpr int NCH = C / 8;
     static constexpr int WM = C / 32, WN = 4 / WM;                 // wave grid: one 32-row m-tile per wave row
     static constexpr int NT = W1 / 32 / WN;                        // n-tiles per wave
-    static constexpr int LDS_FLOATS = C * WA + RC * XS + 2 * RC * ES + 2 * C;
+    static constexpr int LDS_FLOATS = C * WA + RC * XS + 2 * RC * ES + 3 * C;
     static constexpr int NLD = (RC * WX + 255) / 256;              // raw elements per thread and chunk
 };
 
@@ -55,11 +55,13 @@ struct AmpParams {
     float out_scale;
 };
 
-__device__ __forceinline__ f32x2a amp_snake2(f32x2a u, float al_pi, float hb) {   // = snake2() of small_kernels.hip (hardware cosine)
-    const f32x2a ph = u * al_pi;
+__device__ __forceinline__ f32x2a amp_snake2(f32x2a u, float al_pi, float al_lo, float hb) {   // = snake2() of small_kernels.hip (hardware cosine,
+    const f32x2a ph = u * al_pi;                                                                  //   compensated phase): bit-identical to it
+    f32x2a r = __builtin_elementwise_fma(u, (f32x2a)(al_pi), -ph);
+    r = __builtin_elementwise_fma(u, (f32x2a)(al_lo), r);
     f32x2a c;
-    c.x = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ph.x));
-    c.y = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ph.y));
+    c.x = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ph.x) + r.x);
+    c.y = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ph.y) + r.y);
     return __builtin_elementwise_fma(c, (f32x2a)(-hb), u + hb);
 }
 
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void amp_conv_kernel(const AmpParams p) {
     float* Xc = As + C * G::WA;               // [RC][XS] raw chunk
     float* Ec = Xc + G::RC * G::XS;           // [RC][ES] even 2x-rate samples
     float* Oc = Ec + G::RC * G::ES;           // [RC][ES] odd
-    float* prm = Oc + G::RC * G::ES;          // [C] alpha / pi, [C] inv_beta / 2
+    float* prm = Oc + G::RC * G::ES;          // [C] alpha / pi, [C] inv_beta / 2, [C] low part of alpha / pi
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,8 +90,10 @@ __global__ __launch_bounds__(256, 2) void amp_conv_kernel(const AmpParams p) {
     const bool edge = ta - 6 < 0 || ta + G::WA_RAW + 6 > T;
 
     if (tid < C) {
-        prm[tid] = p.alpha[tid] * 0.318309886183790672f;
+        const float al = p.alpha[tid], al_pi = al * 0.318309886183790672f;
+        prm[tid] = al_pi;
         prm[C + tid] = 0.5f * p.inv_beta[tid];
+        prm[2 * C + tid] = fmaf(al, 0.318309886183790672f, -al_pi) + al * 1.2841276653e-8f;   // (snake_al_lo of small_kernels.hip)
     }
     f32x2a upp[6], dnp[6];   // taps as uniform register pairs (the up-sampler's gain of 2 folded in)
 #pragma unroll
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void amp_conv_kernel(const AmpParams p) {
                 const f32x2a xp = {xr[xi + 2 - q], xr[xi + 3 - q]};
                 u = __builtin_elementwise_fma(upp[q], xp, u);
             }
-            f32x2a a = amp_snake2(u, prm[c * G::RC + r], prm[C + c * G::RC + r]);
+            f32x2a a = amp_snake2(u, prm[c * G::RC + r], prm[2 * C + c * G::RC + r], prm[C + c * G::RC + r]);
             if (edge) {   // replicate padding of the low-pass input: n < 0 -> a[0], n > 2T - 1 -> a[2T - 1]
                 if (h < 0) a.y = a.x;
                 if (h > T - 1) a.x = a.y;

@@ -137,6 +137,8 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
     std::vector<float> packed;
     pack_conv_weights(wc, L.M, c_in, L.ks, L.m_pad, L.nchunk, packed);
     bias.resize(L.m_pad, 0.f);
+    bias.resize(2 * (size_t)L.m_pad);   // second half: -bias (pair_wino_impl.h)
+    for (int i = 0; i < L.m_pad; ++i) bias[L.m_pad + i] = -bias[i];
     L.wp_bytes = packed.size() * sizeof(float);
     FV_HIP_CHECK(hipMalloc((void**)&L.d_wp, L.wp_bytes));
     FV_HIP_CHECK(hipMalloc((void**)&L.d_bias, bias.size() * sizeof(float)));
@@ -259,6 +261,14 @@ void conv_layer_destroy(ConvLayer& L) {
 static long long* g_sk_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void fv_debug_set_splitk_timestamps(void* device_buffer) { g_sk_ts = (long long*)device_buffer; }
 #endif
+// fv_set_conv_algorithm of the running call, with the process-wide FV_WINO knob as the default behind FV_CONV_ALGO_AUTO
+static int effective_algo() {
+    const int a = cur_algo();
+    if (a != FV_CONV_ALGO_AUTO) return a;
+    const int w = knobs().wino;
+    return w == 0 ? FV_CONV_ALGO_DIRECT : w >= 2 ? FV_CONV_ALGO_WINOGRAD : FV_CONV_ALGO_AUTO;
+}
+
 static int choose_tile(int M, long long N, int batch) {
     int big, small;
     if (M <= 32) {
@@ -287,7 +297,7 @@ static int choose_tile(int M, long long N, int batch) {
         // still fewer workgroups than CUs: 32 x 64 tiles with K split across the four waves (latency variant)
         const long long blocks_small = tiles_small * m_blks * batch;
         static const long long sk_max = std::getenv("FV_SPLITK_MAX") ? std::atoll(std::getenv("FV_SPLITK_MAX")) : 200;   // experiments
-        if (blocks_small < sk_max) {
+        if (blocks_small < sk_max && !cur_invariant()) {   // (batch-invariant mode: the split-K kernels sum K in another order)
             // 32 x 64 tiles: 4x the workgroups of 128 x 64 / 2x those of 32 x 128.  Workgroups are dealt out one per CU and
             // round, and a workgroup's time is its MFMA chain (proportional to the tile width): the busiest CU decides, so
             // take 32 x 32 tiles when their rounds are shorter in total (344 tiles of 32 x 64 = 2 rounds of 2 units against
@@ -347,7 +357,7 @@ static int choose_gemm_pw(const ConvLayer& L, const ConvRun& r, long long tout) 
     }
     // a sixth of the SIMDs' time used or less (single clips): too few whole tiles — the conv kernel's split-K tiles do better
     // (measured crossover, tools/probe_pointwise.py: B = 32 x 86 frames, 512 -> 128 at 0.17 still wins by a third)
-    return best_score >= 0.15 ? best : -1;
+    return (best_score >= 0.15 || cur_invariant()) ? best : -1;   // (batch-invariant mode: by shape alone)
 }
 
 // Row groups of the XCD partition (gemm_pw.hip).  An XCD reads 1 / PX of the weights and PX / 8 of the activation columns:
@@ -532,7 +542,8 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     p.dbg_ts = g_sk_ts;
 #endif
     // Winograd F(2,3) tap groups for the dilated ResBlock / AMPBlock convs of launches that fill the chip (conv_wino_impl.h)
-    if (knobs().wino && L.d_wpw && !p.x2 && L.M >= knobs().wino_min_m) {
+    const int algo = effective_algo();
+    if (algo != FV_CONV_ALGO_DIRECT && L.d_wpw && !p.x2 && L.M >= knobs().wino_min_m) {
         static const int wdims[WINO_COUNT][2] = {{128, 32}, {64, 64}, {32, 128}, {128, 64}, {64, 128}};
         // 64 accumulator registers per wave (32 output pairs x 4 planes): three waves per SIMD; the 128 x 64-pair tile (two waves) measured
         // 8 % slower on the headline's C = 128 stage although it fetches each weight fragment half as often
@@ -549,7 +560,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         // launches of at least half a workgroup per CU: measured per batch size (tools/sweep_wino_batch.py) — HiFiGAN-V1 B = 2 ... 32 -12 ... -16 %
         // against the direct kernels with this gate, a single clip (86 workgroups at C = 128) +17 % without it
         const long long min_blocks = knobs().wino_min_blocks >= 0 ? knobs().wino_min_blocks : num_cus() / 2;
-        if (blocks >= min_blocks || knobs().wino >= 2) {   // (FV_WINO=2: tests force it on small launches)
+        if (blocks >= min_blocks || algo == FV_CONV_ALGO_WINOGRAD || cur_invariant()) {
             p.wp = L.d_wpw;
             p.m_blks = (L.M + mb - 1) / mb;
             p.n_tiles = (int)((np + pairs - 1) / pairs);
@@ -774,7 +785,9 @@ static fv_status conv_pair16_run_f16x3(const ConvLayer& c1, const ConvLayer& c2,
 }
 
 bool pair_wino_supported(int C, int ks, int dil) {
-    return (C == 16 || C == 32) && (ks == 3 || ks == 7 || ks == 11) && (dil == 1 || dil == 3 || dil == 5);
+    if (dil != 1 && dil != 3 && dil != 5) return false;
+    if (C == 16 || C == 32) return ks == 3 || ks == 7 || ks == 11;
+    return (C == 64 || C == 128) && ks == 3;   // (wider pairs fuse at k = 3 only: resblock_pair.hip)
 }
 
 fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x, float* y, int batch, int t, int out_mode,
@@ -792,16 +805,21 @@ fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x
         set_error("conv_pair_run: output must not alias the input (halo reads)");
         return FV_ERR_INVALID;
     }
-    if (knobs().pair_wino && c1.d_wpw16 && c2.d_wpw16 && pair_wino_supported(C, c1.k, c1.dil)) {
+    const bool wide = C >= 64;   // 32x32x2 kernels on the layers' d_wpw; C <= 32: 16x16x4 kernels on d_wpw16
+    if (knobs().pair_wino && effective_algo() != FV_CONV_ALGO_DIRECT && (wide ? (c1.d_wpw && c2.d_wpw) : (c1.d_wpw16 && c2.d_wpw16)) &&
+        pair_wino_supported(C, c1.k, c1.dil)) {
         // Winograd F(2,3) tap groups in both convs (pair_wino_impl.h)
         PairParams p;
         std::memset(&p, 0, sizeof(p));
         p.x = x;
         p.y = y;
-        p.w1 = c1.d_wpw16;
-        p.w2 = c2.d_wpw16;
+        p.w1 = wide ? c1.d_wpw : c1.d_wpw16;
+        p.w2 = wide ? c2.d_wpw : c2.d_wpw16;
+        p.n_frag = c1.nchunk * c1.nv;
         p.b1 = c1.d_bias;
         p.b2 = c2.d_bias;
+        p.b1n = c1.d_bias + c1.m_pad;
+        p.b2n = c2.d_bias + c2.m_pad;
         p.T = t;
         p.out_mode = out_mode;
         p.out_scale = out_scale;
@@ -817,7 +835,8 @@ fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x
         std::snprintf(name, sizeof(name), "pair_wino<k=%d d=%d C=%d>", c1.k, c1.dil, C);
         set_last_kernel(name);
         if (prof_idx >= 0) {
-            const int tt = 2 * (64 / c1.dil * c1.dil) - (c1.k - 1);   // PWGeom::TT
+            const int nbp = C == 128 ? 32 : 64;
+            const int tt = 2 * (nbp / c1.dil * c1.dil) - (c1.k - 1);   // PWGeom::TT / PW32Geom::TT
             char lbl[128];
             std::snprintf(lbl, sizeof(lbl), "%s grid=%d", name, batch * ((t + tt - 1) / tt));
             const double macs = 2.0 * C * C * c1.k * (double)t * batch;   // ALGORITHMIC (direct-sum) MACs of the two convs

@@ -89,6 +89,19 @@ static void reload_knobs() {
     g_knobs.store(load_knobs(), std::memory_order_release);
 }
 
+static thread_local int g_algo = FV_CONV_ALGO_AUTO;
+static thread_local bool g_invariant = false;
+AlgoScope::AlgoScope(int algo, bool invariant) : prev_algo(g_algo), prev_inv(g_invariant) {
+    g_algo = algo;
+    g_invariant = invariant;
+}
+AlgoScope::~AlgoScope() {
+    g_algo = prev_algo;
+    g_invariant = prev_inv;
+}
+int cur_algo() { return g_algo; }
+bool cur_invariant() { return g_invariant; }
+
 int num_cus() {
     static thread_local int cached_dev = -1, cached = 0;
     int dev = 0;
@@ -400,6 +413,9 @@ struct fv_engine {
     Profiler prof;
     bool profiling = false;
     int precision = FV_PRECISION_F32;   // fv_set_precision
+    int algo = FV_CONV_ALGO_AUTO;       // fv_set_conv_algorithm
+    bool invariant = false;             // fv_set_batch_invariant
+    void drop_graphs();
     bool fuse_pairs = true;   // FV_NO_PAIR_FUSION=1 in the environment disables the fused (c1, c2) kernels (A/B runs)
     bool post_mean_fused = true;   // FV_NO_POST_SUM3=1: mean_of_three_kernel before conv_post instead of the mean formed in its staging (A/B runs)
     int pair_max_c = 128;     // FV_PAIR_MAXC: widest stage whose (c1, c2) pairs fuse where a kernel exists (experiments)
@@ -882,7 +898,7 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
             // (C = 128 pairs: 126-column tiles, two workgroups per CU — only when the launch fills the chip; a single clip's 44 tiles
             //  are better served by the split-K latency kernels: p50 0.96 vs 1.04 ms)
             const bool fuse_narrow = ch <= pair_max_c && pair_supported(ch, br.k, br.dil[0]) && pair_supported(ch, br.k, br.dil[1]) &&
-                                     pair_supported(ch, br.k, br.dil[2]) && (ch < 128 || (long long)B * ((t + 125) / 126) >= 2LL * num_cus());
+                                     pair_supported(ch, br.k, br.dil[2]) && (ch < 128 || cur_invariant() || (long long)B * ((t + 125) / 126) >= 2LL * num_cus());
             // f16x3 precision mode: the wide stages (C = 128 / 64) fuse too (pair_f16x3_impl.h)
             const bool fuse_wide = pair_f16x3_supported(br.c1[0], br.c2[0]) && pair_f16x3_supported(br.c1[1], br.c2[1]) &&
                                    pair_f16x3_supported(br.c1[2], br.c2[2]);
@@ -1402,6 +1418,39 @@ FV_API fv_status fv_set_precision(fv_engine* e, int32_t precision) {
     return FV_OK;
 }
 
+void fv_engine::drop_graphs() {
+    for (auto& g : graphs) {
+        (void)hipGraphExecDestroy(g.exec);
+        (void)hipGraphDestroy(g.graph);
+    }
+    graphs.clear();
+    have_last = false;
+}
+
+FV_API fv_status fv_set_conv_algorithm(fv_engine* e, int32_t algo) {
+    if (!e) {
+        set_error("fv_set_conv_algorithm: null engine");
+        return FV_ERR_INVALID;
+    }
+    if (algo != FV_CONV_ALGO_AUTO && algo != FV_CONV_ALGO_DIRECT && algo != FV_CONV_ALGO_WINOGRAD) {
+        set_error("fv_set_conv_algorithm: unknown algorithm %d", algo);
+        return FV_ERR_INVALID;
+    }
+    if (e->algo != algo) e->drop_graphs();   // captured launch sequences hold the old choice
+    e->algo = algo;
+    return FV_OK;
+}
+
+FV_API fv_status fv_set_batch_invariant(fv_engine* e, int32_t enable) {
+    if (!e) {
+        set_error("fv_set_batch_invariant: null engine");
+        return FV_ERR_INVALID;
+    }
+    if (e->invariant != (enable != 0)) e->drop_graphs();
+    e->invariant = enable != 0;
+    return FV_OK;
+}
+
 FV_API fv_status fv_set_graph_replay(fv_engine* e, int32_t enable) {
     if (!e) {
         set_error("fv_set_graph_replay: null engine");
@@ -1596,6 +1645,7 @@ static fv_status forward_common(fv_engine* e, const float* d_in, const float* d_
     }
     e->cur_template = d_template;
     e->cur_noise = d_noise;
+    const AlgoScope algo_scope(e->algo, e->invariant);
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)d_workspace;
     struct ProfGuard {
@@ -2024,6 +2074,7 @@ FV_API fv_status fv_conv_forward(fv_conv* c, const float* d_x, float* d_y, const
     r.pre_act = c->desc.pre_act;
     r.post_act = c->desc.post_act;
     r.slope = c->desc.act_slope;
+    const AlgoScope algo_scope(c->L.algo, false);
     return conv_layer_run(c->L, r, (hipStream_t)stream);
 }
 
@@ -2038,6 +2089,7 @@ FV_API fv_status fv_conv_pair_forward(fv_conv* c1, fv_conv* c2, const float* d_x
         set_error("fv_conv_pair_forward: empty input");
         return FV_ERR_INVALID;
     }
+    const AlgoScope algo_scope(c1->L.algo, false);
     return conv_pair_run(c1->L, c2->L, d_x, d_y, batch, t, OUT_SET, 1.0f, (hipStream_t)stream);
 }
 
@@ -2047,6 +2099,15 @@ FV_API fv_status fv_conv_set_precision(fv_conv* c, int32_t precision) {
         return FV_ERR_INVALID;
     }
     c->L.precision = precision;
+    return FV_OK;
+}
+
+FV_API fv_status fv_conv_set_algorithm(fv_conv* c, int32_t algo) {
+    if (!c || (algo != FV_CONV_ALGO_AUTO && algo != FV_CONV_ALGO_DIRECT && algo != FV_CONV_ALGO_WINOGRAD)) {
+        set_error("fv_conv_set_algorithm: invalid argument");
+        return FV_ERR_INVALID;
+    }
+    c->L.algo = algo;
     return FV_OK;
 }
 

@@ -34,6 +34,17 @@ struct Knobs {
 };
 const Knobs& knobs();
 
+// Conv algorithm selection of the call being enqueued (fv_set_conv_algorithm / fv_set_batch_invariant): thread-local, set by the C-ABI entry
+// points for the duration of the call — conv_layer_run / conv_pair_run and the engine's fusion decisions read it
+struct AlgoScope {
+    AlgoScope(int algo, bool invariant);
+    ~AlgoScope();
+    int prev_algo;
+    bool prev_inv;
+};
+int cur_algo();          // fv_conv_algo
+bool cur_invariant();    // kernel choices from the layer shape alone
+
 // Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  Register-resident operand
 // rings need every index to be a constant expression in the source (an index that only becomes constant after loop unrolling
 // can leave the array in scratch memory: the optimiser promotes arrays to registers before it unrolls).
@@ -147,7 +158,8 @@ struct ConvLayer {
     float w_scale = 1.f;       // s_w: power of two folded into those planes
     int nch16 = 0;
     int precision = FV_PRECISION_F32;   // FV_PRECISION_F16X3: conv_layer_run uses the split-fp16 kernel (needs d_wph)
-    float* d_bias = nullptr;
+    int algo = FV_CONV_ALGO_AUTO;       // fv_conv_set_algorithm (single layers; an engine's layers follow the engine's setting)
+    float* d_bias = nullptr;   // m_pad values, followed by their negatives (m_pad more)
     size_t wp_bytes = 0;
 
     int64_t out_len(int t_in) const {
@@ -222,11 +234,14 @@ struct PairParams {
     const float* b1;
     const float4* w2;
     const float* b2;
+    const float* b1n;     // -b1 / -b2 (pair_wino_impl.h: the bias rides in two accumulator planes, one of them negated)
+    const float* b2n;
     float* y;             // (B, C, T); must NOT alias x (neighbouring workgroups read x's halo)
     int T, n_tiles;
     int out_mode;
     float out_scale;
     int batch;            // items in the launch (the kernels map workgroups to (item, tile) themselves)
+    int n_frag;           // pair_wino32_kernel: weight fragments per 32-row m-tile of w1 / w2 (nchunk * nv)
 };
 bool pair_supported(int C, int ks, int dil);
 

@@ -29,16 +29,16 @@ typedef float f32x2w __attribute__((ext_vector_type(2)));
 
 constexpr int pw_up(int v, int m, int r) { return v + ((r - v % m) % m + m) % m; }   // smallest x >= v with x % m == r
 
-#ifndef FV_X_PW_DA
-#define FV_X_PW_DA 4
-#endif
+// Weight ring: fragment f of a conv sits in slot f % RA, the load for fragment f + DA is issued while f is consumed.  RA = DA + U divides
+// the fragments of a chunk wherever the chunk loop is a real loop (C = 32), so every chunk starts at slot 0 and nothing is moved.
+constexpr int pw_da(int ks, int mt) { return mt == 2 ? (ks == 7 ? 4 : 3) : 4; }
 
 template <int KS, int DIL, int C, int CH>
 struct PWGeom {
     static_assert(C == 16 || C == 32, "16x16x4 kernel: one or two 16-row m-tiles");
     static_assert(CH == 8 || CH == 16, "chunk = 8 or 16 channels");
     static_assert(C % CH == 0 && CH * (C / 16) >= 16, "a chunk holds whole weight fragments");
-    static constexpr int KSZ = KS;
+    static constexpr int KSZ = KS, DILV = DIL;
     static constexpr int MT = C / 16;                    // 16-row m-tiles per wave (every wave owns all rows)
     static constexpr int U = MT == 2 ? 1 : 2;            // weight fragments (one float4 per lane = 4 MFMAs) per macro-step
     static constexpr int FCH = 16 / MT;                  // channels one weight fragment covers
@@ -62,6 +62,8 @@ struct PWGeom {
     static constexpr int NF4 = CH / FCH * NV;            // weight fragments per chunk
     static constexpr int NMS = NF4 / U;                  // macro-steps per chunk
     static_assert(NF4 % U == 0, "whole macro-steps");
+    static constexpr int DA = pw_da(KS, MT), RA = DA + U;   // weight prefetch distance / ring slots (fragments)
+    static_assert(C == CH || NF4 % RA == 0, "the ring returns to slot 0 at every chunk boundary");
 };
 
 // Virtual tap v of a conv with dilation DX on strides (PE, PD): which accumulator plane it feeds, and where its B operand sits
@@ -107,12 +109,85 @@ __device__ __forceinline__ void pw_transform(const float* __restrict__ eo, float
     }
 }
 
+// Phase 0 of both kernel families: silu(x) of the window [t0 - HP, ...) -> E / O planes of c1's lattice for all C channels (zero outside [0, T):
+// silu(0) == 0 is the conv's zero padding), and — XRES — the raw centre columns [t0, t0 + TT) -> Xr, the residual operand of the last epilogue.
+// Each wave stages C / 4 whole channel rows.  Positions are loaded in order (coalesced dwords through a per-row buffer descriptor whose bounds
+// check returns 0 outside the row) and scattered to their plane / pair column; the offsets are per lane slot, the same for every row, so a row
+// costs its loads, the SiLUs and the LDS writes — no per-element index arithmetic.  The last NP1 % 64 positions of the wave's rows are
+// flattened over (row, position) into whole lanes.
+template <class G, int C, bool XRES>
+__device__ __forceinline__ void pw_stage_window(const float* __restrict__ xb, int T, int t0, int wave, int lane, float* __restrict__ lds) {
+    float* EO = lds;
+    float* Xr = lds + G::EO_F + G::D_F;
+    constexpr int DIL = G::DILV;
+    constexpr int NFULL = G::NP1 / 64, TAILW = G::NP1 % 64, RPW = C / 4, NTAIL = (RPW * TAILW + 63) / 64;
+    const int ws = t0 - G::HP;
+    const int row0 = wave * RPW;
+    auto eo_of = [&](int pp) {   // position of the window -> offset inside a channel row's E / O planes
+        const int q = pp / (2 * DIL), rem = pp - 2 * DIL * q;
+        const int hi = rem >= DIL ? 1 : 0;
+        return hi * G::PE + q * DIL + rem - hi * DIL;
+    };
+    auto xr_of = [&](int pp) {
+        const int c = pp - G::HP;
+        return (c >= 0 && c < G::TT) ? c : G::TT;
+    };
+    float v[RPW][NFULL > 0 ? NFULL : 1];
+    float vt[NTAIL > 0 ? NTAIL : 1];
+    int eo_off[NFULL > 0 ? NFULL : 1], xr_off[NFULL > 0 ? NFULL : 1];
+    unsigned voff[NFULL > 0 ? NFULL : 1];
+#pragma unroll
+    for (int i = 0; i < NFULL; ++i) {
+        const int pp = lane + 64 * i;
+        eo_off[i] = row0 * G::SE + eo_of(pp);
+        xr_off[i] = row0 * G::XS + xr_of(pp);
+        voff[i] = (unsigned)(ws + pp) * 4u;   // negative positions wrap past the descriptor's size: the load returns 0
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (long long)(row0 + rr) * T), 0, (unsigned)T * 4u, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NFULL; ++i) v[rr][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff[i], 0, 0));
+    }
+    // the last TAILW positions of the wave's rows, flattened over (row, position): whole lanes instead of RPW part-filled slots
+    int eo_t[NTAIL > 0 ? NTAIL : 1], xr_t[NTAIL > 0 ? NTAIL : 1];
+    if constexpr (NTAIL > 0) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)(C * T) * 4u, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NTAIL; ++j) {
+            const int e = lane + 64 * j;
+            const bool ok = e < RPW * TAILW;
+            const int rr = e / TAILW, pp = NFULL * 64 + e - rr * TAILW;
+            const int tpos = ws + pp;
+            const bool in = ok && tpos >= 0 && tpos < T;
+            eo_t[j] = ok ? (row0 + rr) * G::SE + eo_of(pp) : G::TRASH;
+            const int xc = xr_of(pp);
+            xr_t[j] = ok ? (row0 + rr) * G::XS + xc : G::TRASH - G::EO_F - G::D_F;   // (Xr-relative)
+            vt[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, in ? (unsigned)((row0 + rr) * T + tpos) * 4u : 0xFFFFFFFFu, 0, 0));
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+        for (int i = 0; i < NFULL; ++i) {
+            EO[eo_off[i] + rr * G::SE] = pw_silu(v[rr][i]);   // silu(0) == 0: the conv's zero padding
+            if constexpr (XRES) Xr[xr_off[i] + rr * G::XS] = v[rr][i];
+        }
+    if constexpr (NTAIL > 0) {
+#pragma unroll
+        for (int j = 0; j < NTAIL; ++j) {
+            EO[eo_t[j]] = pw_silu(vt[j]);
+            if constexpr (XRES) Xr[xr_t[j]] = vt[j];
+        }
+    }
+}
+
 // MFMA loop over one chunk: NF4 weight fragments, four 16x16x4 MFMAs each.  dl / el: the lane's base into the d planes / the chunk's
 // E-O rows (k-quarter row and pair column folded in).  aq: weight ring, fragments [f, f + DA) of the conv on entry and on exit.
 template <class G, int DX>
 __device__ __forceinline__ void pw_gemm_chunk(f32x4w (&acc)[4][G::MT], const float* __restrict__ dl, const float* __restrict__ el,
-                                              const __amdgpu_buffer_rsrc_t wrs, int wvoff, int wsoff, float4 (&aq)[FV_X_PW_DA + G::U]) {
-    constexpr int DA = FV_X_PW_DA, U = G::U, KST = G::KST, MT = G::MT, NV = G::NV;
+                                              const __amdgpu_buffer_rsrc_t wrs, int wvoff, int wsoff, float4 (&aq)[G::RA]) {
+    constexpr int DA = G::DA, RA = G::RA, U = G::U, KST = G::KST, MT = G::MT, NV = G::NV;
     using TP = PWTap<G::KSZ, DX, G::PE, G::PD>;
     constexpr int NB = U * KST;       // B registers per macro-step
     constexpr int NM = 4 * U;         // MFMAs per macro-step
@@ -139,15 +214,15 @@ __device__ __forceinline__ void pw_gemm_chunk(f32x4w (&acc)[4][G::MT], const flo
             const int mt = MT == 2 ? m % 2 : 0;
             const int comp = MT == 2 ? m : m / 2;
             const int A = TP::acc_of((f0 + u) % NV);
-            const float4 a4 = u == 0 ? aq[0] : aq[U - 1];
+            const float4 a4 = u == 0 ? aq[f0 % RA] : aq[(f0 + U - 1) % RA];
             const float av = comp == 0 ? a4.x : comp == 1 ? a4.y : comp == 2 ? a4.z : a4.w;
             // The matrix instruction is a pure value to the instruction selector, which is free to float it past the (ordered) memory
             // operations and scheduling barriers around it — and did: every MFMA of c1 ended up behind all of the chunk's loads, 112
-            // operands live.  Two empty volatile asm statements (ordered like the loads) pin it: its B operand passes through one
+            // operands live.  Two empty volatile asm statements (ordered like the loads) pin it: its A operand passes through one
             // before it, its result through one after it.
-            float bv = b_cur[u * KST + s];
-            asm volatile("" : "+v"(bv));
-            acc[A][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[A][mt], 0, 0, 0);
+            float apin = av;   // (the A value is used by this MFMA alone: no copy; a B value feeds MT of them)
+            asm volatile("" : "+v"(apin));
+            acc[A][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(apin, b_cur[u * KST + s], acc[A][mt], 0, 0, 0);
             asm volatile("" : "+v"(acc[A][mt]));
 #pragma unroll
             for (int k = 0; k < NLDX; ++k) {
@@ -155,7 +230,7 @@ __device__ __forceinline__ void pw_gemm_chunk(f32x4w (&acc)[4][G::MT], const flo
                     if (k < U) {
                         const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff + (f0 + k) * 1024, 0);
                         const float4 wv = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
-                        if (k == 0) aq[DA] = wv; else aq[DA + U - 1] = wv;
+                        if (k == 0) aq[(f0 + DA) % RA] = wv; else aq[(f0 + DA + U - 1) % RA] = wv;
                     } else if (ms + 1 < G::NMS) {
                         b_nxt[k - U] = *b_addr(f0 + U + (k - U) / KST, (k - U) % KST);
                     }
@@ -164,8 +239,6 @@ __device__ __forceinline__ void pw_gemm_chunk(f32x4w (&acc)[4][G::MT], const flo
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int d = 0; d < DA; ++d) aq[d] = aq[d + U];
         if (ms + 1 < G::NMS) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) b_cur[i] = b_nxt[i];
@@ -176,7 +249,7 @@ __device__ __forceinline__ void pw_gemm_chunk(f32x4w (&acc)[4][G::MT], const flo
 template <int KS, int DIL, int C, int CH>
 __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p) {
     using G = PWGeom<KS, DIL, C, CH>;
-    constexpr int MT = G::MT, DA = FV_X_PW_DA, U = G::U, NCHK = C / CH;
+    constexpr int MT = G::MT, DA = G::DA, NCHK = C / CH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* EO = lds;
     float* Db = lds + G::EO_F;
@@ -196,7 +269,7 @@ __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p)
     const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 0x7fffffff, 0x00020000);
     const int wvoff = lane * 16;
-    float4 aq[DA + U];
+    float4 aq[G::RA];
     auto load_w = [&](const __amdgpu_buffer_rsrc_t rs, int f) __attribute__((always_inline)) {
         const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, wvoff, f * 1024, 0);
         return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
@@ -204,85 +277,22 @@ __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p)
 #pragma unroll
     for (int d = 0; d < DA; ++d) aq[d] = load_w(w1rs, d);
 
-    // ---- phase 0: silu(x) window -> E / O planes of c1's lattice; raw centre columns -> Xr ----
-    {
-        constexpr int NFULL = G::NP1 / 64, TAILW = G::NP1 % 64, RPW = C / 4, NTAIL = (RPW * TAILW + 63) / 64;
-        const int ws = t0 - G::HP;
-        const int row0 = wave * RPW;
-        auto eo_of = [&](int pp) {   // position of the window -> offset inside a channel row's E / O planes
-            const int q = pp / (2 * DIL), rem = pp - 2 * DIL * q;
-            const int hi = rem >= DIL ? 1 : 0;
-            return hi * G::PE + q * DIL + rem - hi * DIL;
-        };
-        auto xr_of = [&](int pp) {
-            const int c = pp - G::HP;
-            return (c >= 0 && c < G::TT) ? c : G::TT;
-        };
-        float v[RPW][NFULL > 0 ? NFULL : 1];
-        float vt[NTAIL > 0 ? NTAIL : 1];
-        int eo_off[NFULL > 0 ? NFULL : 1], xr_off[NFULL > 0 ? NFULL : 1];
-        unsigned voff[NFULL > 0 ? NFULL : 1];
-#pragma unroll
-        for (int i = 0; i < NFULL; ++i) {
-            const int pp = lane + 64 * i;
-            eo_off[i] = row0 * G::SE + eo_of(pp);
-            xr_off[i] = row0 * G::XS + xr_of(pp);
-            voff[i] = (unsigned)(ws + pp) * 4u;   // negative positions wrap past the descriptor's size: the load returns 0
-        }
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (long long)(row0 + rr) * T), 0, (unsigned)T * 4u, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < NFULL; ++i) v[rr][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff[i], 0, 0));
-        }
-        // the last TAILW positions of the wave's rows, flattened over (row, position): whole lanes instead of RPW part-filled slots
-        int eo_t[NTAIL > 0 ? NTAIL : 1], xr_t[NTAIL > 0 ? NTAIL : 1];
-        if constexpr (NTAIL > 0) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)(C * T) * 4u, 0x00020000);
-#pragma unroll
-            for (int j = 0; j < NTAIL; ++j) {
-                const int e = lane + 64 * j;
-                const bool ok = e < RPW * TAILW;
-                const int rr = e / TAILW, pp = NFULL * 64 + e - rr * TAILW;
-                const int tpos = ws + pp;
-                const bool in = ok && tpos >= 0 && tpos < T;
-                eo_t[j] = ok ? (row0 + rr) * G::SE + eo_of(pp) : G::TRASH;
-                const int xc = xr_of(pp);
-                xr_t[j] = ok ? (row0 + rr) * G::XS + xc : G::TRASH - G::EO_F - G::D_F;   // (Xr-relative)
-                vt[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, in ? (unsigned)((row0 + rr) * T + tpos) * 4u : 0xFFFFFFFFu, 0, 0));
-            }
-        }
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr)
-#pragma unroll
-            for (int i = 0; i < NFULL; ++i) {
-                EO[eo_off[i] + rr * G::SE] = pw_silu(v[rr][i]);   // silu(0) == 0: the conv's zero padding
-                Xr[xr_off[i] + rr * G::XS] = v[rr][i];
-            }
-        if constexpr (NTAIL > 0) {
-#pragma unroll
-            for (int j = 0; j < NTAIL; ++j) {
-                EO[eo_t[j]] = pw_silu(vt[j]);
-                Xr[xr_t[j]] = vt[j];
-            }
-        }
-    }
+    pw_stage_window<G, C, true>(xb, T, t0, wave, lane, lds);
 
     // accumulators: the bias rides in m0 (+b) and m3 (-b): y0 = m0 + m1 + m2, y1 = m1 - m2 - m3
     const int krow = lane >> 4;               // C / D layout of 16x16x4: row = 4 (lane >> 4) + reg, column = lane & 15
     const int ncol = 16 * wave + (lane & 15);
     f32x4w acc[4][MT];
-    auto init_acc = [&](const float* __restrict__ bias) __attribute__((always_inline)) {
+    auto init_acc = [&](const float* __restrict__ bias, const float* __restrict__ nbias) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const f32x4w bv = *(const f32x4w*)(bias + 16 * i + 4 * krow);
-            acc[0][i] = bv;
-            acc[3][i] = -bv;
+            acc[0][i] = *(const f32x4w*)(bias + 16 * i + 4 * krow);
+            acc[3][i] = *(const f32x4w*)(nbias + 16 * i + 4 * krow);   // (-b, negated on the host)
             acc[1][i] = f32x4w{0.f, 0.f, 0.f, 0.f};
             acc[2][i] = f32x4w{0.f, 0.f, 0.f, 0.f};
         }
     };
-    init_acc(p.b1);
+    init_acc(p.b1, p.b1n);
     const float* dl = Db + krow * G::SD + ncol;
     const float* el = EO + krow * G::SE + ncol;
     __syncthreads();
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p)
             }
         }
     }
-    init_acc(p.b2);
+    init_acc(p.b2, p.b2n);
     __syncthreads();
 
     // ---- c2 (dilation 1) ----
@@ -382,6 +392,268 @@ __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Wide stages (C = 64 / 128): v_mfma_f32_32x32x2_f32, waves stacked along M (each wave owns ONE 32-row m-tile — its own share of the
+// weights, in conv_wino_impl.h's fragment order: the layers' d_wpw — and NT n-tiles of 32 pair columns); WN = 4 / WM waves along N.
+// XRES: the raw tile for the residual stays in LDS (C = 64 at most: at C = 128 it does not fit next to the window); otherwise the last
+// epilogue reads x again, requested before c2's matrix loop starts.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+template <int KS, int DIL, int C, int CH, int NT, bool XRES_>
+struct PW32Geom {
+    static_assert(C == 64 || C == 128, "one 32-row m-tile per wave");
+    static_assert(CH % 8 == 0 && C % CH == 0, "chunks of whole 8-channel fragments");
+    static constexpr bool XRES = XRES_;
+    static constexpr int KSZ = KS, DILV = DIL;
+    static constexpr int WM = C / 32 > 4 ? 4 : C / 32, WN = 4 / WM;
+    static constexpr int NG = (KS + 1) / 4, NS = (KS - 3) / 4, NV = 4 * NG + 2 * NS;
+    static constexpr int NBP = WN * NT * 32;
+    static constexpr int NU = NBP / DIL * DIL;
+    static constexpr int W1 = 2 * NU, TT = W1 - (KS - 1);
+    static constexpr int H1 = (KS - 1) / 2 * DIL, H2 = (KS - 1) / 2, HP = H1 + H2;
+    static constexpr int WD1 = NBP + 2 * DIL * (NG - 1), WR1 = WD1 + DIL;
+    static constexpr int WD2 = NBP + 2 * (NG - 1), WR2 = WD2 + 1;
+    static constexpr int NQ1 = (WR1 + DIL - 1) / DIL;
+    static constexpr int NP1 = 2 * DIL * NQ1;
+    static constexpr int PE = pw_up(DIL * NQ1, 16, 8);   // (the transform's 16-lane row segments sit on disjoint banks; the 32-lane MFMA reads
+    static constexpr int PD = pw_up(WD1, 8, 4);          //  are conflict-free with any stride)
+    static constexpr int SE = 2 * PE, SD = 4 * PD;
+    static constexpr int XS = TT + 2;
+    static constexpr int EO_F = C * SE, D_F = CH * SD, XR_F = XRES ? C * XS + 16 : 0;
+    static constexpr int TRASH = EO_F + D_F + XR_F;
+    static constexpr int LDS_FLOATS = TRASH + 4;
+    static constexpr int NF4 = CH / 8 * NV;              // weight fragments (8 channels x one virtual tap = 4 MFMAs per n-tile) per chunk
+    static constexpr int DA = 3, RA = 4;                 // weight ring: RA divides the fragments of a chunk (NV * CH / 8)
+    static_assert(NF4 % RA == 0, "the ring returns to slot 0 at every chunk boundary");
+};
+
+template <class G, int DX>
+__device__ __forceinline__ void pw32_gemm_chunk(f32x16 (&acc)[4][1], const float* __restrict__ dl, const float* __restrict__ el,
+                                                const __amdgpu_buffer_rsrc_t wrs, int wvoff, int wsoff, float4 (&aq)[G::RA]) {
+    constexpr int DA = G::DA, RA = G::RA, NV = G::NV;
+    using TP = PWTap<G::KSZ, DX, G::PE, G::PD>;
+    float b_cur[4], b_nxt[4];
+    auto b_addr = [&](int f, int pp) __attribute__((always_inline)) -> const float* {   // fragment f of the chunk, channel pair pp
+        const int sb = f / NV, v = f % NV;
+        const int rowc = sb * 8 + 2 * pp;
+        return TP::from_eo(v) ? el + rowc * G::SE + TP::off_of(v) : dl + rowc * G::SD + TP::off_of(v);
+    };
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) b_cur[pp] = *b_addr(0, pp);
+    static_for<G::NF4>([&](auto f_c) __attribute__((always_inline)) {
+        constexpr int f = decltype(f_c)::value;
+        constexpr int A = TP::acc_of(f % NV);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float4 a4 = aq[f % RA];
+            float apin = m == 0 ? a4.x : m == 1 ? a4.y : m == 2 ? a4.z : a4.w;
+            asm volatile("" : "+v"(apin));   // (pins the MFMA between the memory operations around it: pw_gemm_chunk)
+            acc[A][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(apin, b_cur[m], acc[A][0], 0, 0, 0);
+            asm volatile("" : "+v"(acc[A][0]));
+            if (m == 0) {
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff + f * 1024, 0);
+                aq[(f + DA) % RA] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (f + 1 < G::NF4) {
+                b_nxt[m] = *b_addr(f + 1, m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (f + 1 < G::NF4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b_cur[i] = b_nxt[i];
+        }
+    });
+}
+
+template <int KS, int DIL, int C, int CH, bool XRES>
+__global__ __launch_bounds__(256, 2) void pair_wino32_kernel(const PairParams p) {
+    using G = PW32Geom<KS, DIL, C, CH, 1, XRES>;
+    constexpr int DA = G::DA, NCHK = C / CH, WN = G::WN;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* EO = lds;
+    float* Db = lds + G::EO_F;
+    float* Xr = lds + G::EO_F + G::D_F;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lid = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);   // a clip's tiles on one XCD
+    if (lid >= p.n_tiles * p.batch) return;
+    const int tile = lid % p.n_tiles, b = lid / p.n_tiles;
+    const int t0 = tile * G::TT;
+    const int T = p.T;
+    const float* __restrict__ xb = p.x + (long long)b * C * T;
+
+    // this wave's m-tile of the packed weights: fragments [wm * nfrag, (wm + 1) * nfrag), nfrag = p.n_frag (nchunk * NV)
+    const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 0x7fffffff, 0x00020000);
+    const int wvoff = lane * 16;
+    const int wbase = __builtin_amdgcn_readfirstlane(wm * p.n_frag * 1024);
+    float4 aq[G::RA];
+    auto load_w = [&](const __amdgpu_buffer_rsrc_t rs, int f) __attribute__((always_inline)) {
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, wvoff, wbase + f * 1024, 0);
+        return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    };
+#pragma unroll
+    for (int d = 0; d < DA; ++d) aq[d] = load_w(w1rs, d);
+
+    pw_stage_window<G, C, XRES>(xb, T, t0, wave, lane, lds);
+
+    // C / D layout of 32x32x2: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); the bias rides in m0 (+b) and m3 (-b)
+    const int khalf = lane >> 5;
+    const int ncol = 32 * wn + (lane & 31);
+    const int mrow0 = 32 * wm + 4 * khalf;
+    f32x16 acc[4][1];
+    auto init_acc = [&](const float* __restrict__ bias, const float* __restrict__ nbias) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x4w bv = *(const f32x4w*)(bias + mrow0 + 8 * rq);
+            const f32x4w nv = *(const f32x4w*)(nbias + mrow0 + 8 * rq);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                acc[0][0][4 * rq + rr] = bv[rr];
+                acc[3][0][4 * rq + rr] = nv[rr];
+                acc[1][0][4 * rq + rr] = 0.f;
+                acc[2][0][4 * rq + rr] = 0.f;
+            }
+        }
+    };
+    init_acc(p.b1, p.b1n);
+    const float* dl = Db + khalf * G::SD + ncol;
+    const float* el = EO + khalf * G::SE + ncol;
+    __syncthreads();
+
+    // ---- c1 ----
+    for (int c = 0; c < NCHK; ++c) {
+        pw_transform<G, DIL, G::WD1>(EO + c * CH * G::SE, Db, tid);
+        __syncthreads();
+        pw32_gemm_chunk<G, DIL>(acc, dl, el + c * CH * G::SE, w1rs, wvoff, __builtin_amdgcn_readfirstlane(wbase + (c * G::NF4 + DA) * 1024), aq);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 0; d < DA; ++d) aq[d] = load_w(w2rs, d);
+
+    // ---- c1 epilogue: silu(c1 + b1) -> E / O planes of c2's lattice ----
+    {
+        const int q = ncol / DIL, r = ncol - q * DIL;
+        const int u0 = 2 * DIL * q + r, u1 = u0 + DIL;
+        float* w0 = EO + mrow0 * G::SE + (u0 & 1) * G::PE + (u0 >> 1);
+        float* w1 = EO + mrow0 * G::SE + (u1 & 1) * G::PE + (u1 >> 1);
+        const int ts = t0 - G::H2;
+        const bool edge = ts < 0 || ts + 2 * G::NBP + DIL > T;
+        float k0 = 1.f, k1 = 1.f;
+        if (edge) {
+            k0 = (ts + u0 >= 0 && ts + u0 < T) ? 1.f : 0.f;
+            k1 = (ts + u1 >= 0 && ts + u1 < T) ? 1.f : 0.f;
+        }
+        const f32x16 y0 = (acc[0][0] + acc[1][0]) + acc[2][0];
+        const f32x16 y1 = (acc[1][0] - acc[2][0]) - acc[3][0];
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            float s0 = pw_silu(y0[rg]), s1 = pw_silu(y1[rg]);
+            if (edge) {
+                s0 *= k0;
+                s1 *= k1;
+            }
+            w0[((rg & 3) + 8 * (rg >> 2)) * G::SE] = s0;
+            w1[((rg & 3) + 8 * (rg >> 2)) * G::SE] = s1;
+        }
+    }
+    init_acc(p.b2, p.b2n);
+
+    // the last epilogue's operands that come from HBM (the residual when it is not in LDS, the accumulate operand) are requested now:
+    // their latency runs under c2's matrix loop
+    const int tl = 2 * ncol;
+    const int t = t0 + tl;
+    const unsigned va = (tl < G::TT && t < T) ? (unsigned)(mrow0 * T + t) * 4u : 0xFFFFFFFFu;
+    const unsigned vb = (tl + 1 < G::TT && t + 1 < T) ? (unsigned)(mrow0 * T + t + 1) * 4u : 0xFFFFFFFFu;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)b * C * T), 0, (unsigned)(C * T) * 4u, 0x00020000);
+    float ra[XRES ? 1 : 16], rb[XRES ? 1 : 16];
+    if constexpr (!XRES) {
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)(C * T) * 4u, 0x00020000);
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int so = __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4);
+            ra[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, va, so, 0));
+            rb[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, vb, so, 0));
+        }
+    }
+    __syncthreads();
+
+    // ---- c2 (dilation 1) ----
+    for (int c = 0; c < NCHK; ++c) {
+        pw_transform<G, 1, G::WD2>(EO + c * CH * G::SE, Db, tid);
+        __syncthreads();
+        pw32_gemm_chunk<G, 1>(acc, dl, el + c * CH * G::SE, w2rs, wvoff, __builtin_amdgcn_readfirstlane(wbase + (c * G::NF4 + DA) * 1024), aq);
+        if (c + 1 < NCHK) __syncthreads();
+    }
+
+    // ---- c2 epilogue: + raw x -> y ----
+    {
+        const f32x16 y0 = (acc[0][0] + acc[1][0]) + acc[2][0];
+        const f32x16 y1 = (acc[1][0] - acc[2][0]) - acc[3][0];
+        const float* xl = Xr + mrow0 * G::XS + (tl < G::TT ? tl : 0);
+        const bool accum = p.out_mode == OUT_ACCUM;
+        float o0[16], o1[16];
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            if constexpr (XRES) {
+                const f32x2w xr = *(const f32x2w*)(xl + ((rg & 3) + 8 * (rg >> 2)) * G::XS);
+                o0[rg] = y0[rg] + xr.x;
+                o1[rg] = y1[rg] + xr.y;
+            } else {
+                o0[rg] = y0[rg] + ra[rg];
+                o1[rg] = y1[rg] + rb[rg];
+            }
+        }
+        if (accum) {
+            float a0[16], a1[16];
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int so = __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4);
+                a0[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, va, so, 0));
+                a1[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, vb, so, 0));
+            }
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                o0[rg] = (a0[rg] + o0[rg]) * p.out_scale;
+                o1[rg] = (a1[rg] + o1[rg]) * p.out_scale;
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int so = __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0[rg]), yrs, va, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1[rg]), yrs, vb, so, 0);
+        }
+    }
+}
+
+#ifndef FV_X_PW_CH64
+#define FV_X_PW_CH64 16
+#endif
+#ifndef FV_X_PW_CH128
+#define FV_X_PW_CH128 16
+#endif
+#ifndef FV_X_PW_XRES64
+#define FV_X_PW_XRES64 0
+#endif
+
+template <int KS, int DIL, int C, int CH, bool XRES>
+inline bool launch_pair_wino32_one(const PairParams& p, int batch, hipStream_t s) {
+    using G = PW32Geom<KS, DIL, C, CH, 1, XRES>;
+    PairParams q = p;
+    q.n_tiles = (p.T + G::TT - 1) / G::TT;
+    q.batch = batch;
+    const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+    if (!FV_ENSURE_DYN_LDS((pair_wino32_kernel<KS, DIL, C, CH, XRES>), lds)) return false;
+    hipLaunchKernelGGL((pair_wino32_kernel<KS, DIL, C, CH, XRES>), dim3((batch * q.n_tiles + 7) / 8 * 8), dim3(256), lds, s, q);
+    return true;
+}
+
 template <int KS, int DIL, int C, int CH>
 inline bool launch_pair_wino16_one(const PairParams& p, int batch, hipStream_t s) {
     using G = PWGeom<KS, DIL, C, CH>;
@@ -404,6 +676,10 @@ inline bool launch_pair_wino16_k(const PairParams& p, int C, int dil, int batch,
     if (dil == D) {                                                                        \
         if (C == 16) return launch_pair_wino16_one<KS, D, 16, 16>(p, batch, s);            \
         if (C == 32) return launch_pair_wino16_one<KS, D, 32, FV_X_PW_CH32>(p, batch, s);  \
+        if constexpr (KS == 3) {                                                           \
+            if (C == 64) return launch_pair_wino32_one<KS, D, 64, FV_X_PW_CH64, FV_X_PW_XRES64 != 0>(p, batch, s);   \
+            if (C == 128) return launch_pair_wino32_one<KS, D, 128, FV_X_PW_CH128, false>(p, batch, s);              \
+        }                                                                                  \
     }
     FV_PW_CASE(1) FV_PW_CASE(3) FV_PW_CASE(5)
 #undef FV_PW_CASE

@@ -248,18 +248,31 @@ __device__ __forceinline__ f32x2 sin_squared2(f32x2 z) {
 // Seven instructions per pair instead of the polynomial's sixteen: what this kernel costs is its VALU INSTRUCTION COUNT — beside
 // the fp32 MFMAs of the conv kernels that share the SIMDs (other ResBlock branches) every VALU instruction, plain, packed or
 // transcendental, takes ~12 - 20 cycles out of the matrix stream (tools/ubench/mfma_mix.hip).  Accuracy against sin^2 in double
-// (same ubench): 3.8e-7 for |alpha u| <= 5, 3.1e-6 up to 40 (the fp32 rounding of the argument; the polynomial: 2.9e-7 / 3.2e-7);
-// FV_X_SNAKE_POLY builds the polynomial back in.
-__device__ __forceinline__ f32x2 snake2(f32x2 u, float al, float ib, float al_pi, float hb) {
+// (same ubench): 3.8e-7 for |alpha u| <= 5, 3.1e-6 up to 40 with the plain product u * al_pi (the polynomial: 2.9e-7 / 3.2e-7) — hence the
+// compensated phase below (four more instructions per pair; FV_X_SNAKE_FAST builds the plain product, FV_X_SNAKE_POLY the polynomial).
+// The phase u * alpha / pi is formed to better than fp32: ph = fl(u * al_pi) plus the product's exact residual (one FMA) plus u times the
+// low part of alpha / pi (one FMA) — without them the cosine's argument carries two fp32 roundings that grow with |alpha u| (3e-6 at
+// |alpha u| = 40, 1e-5 at the |alpha u| ~ 100 a trained log-scale alpha of e^3 reaches), times inv_beta / 2 in the output.
+__device__ __forceinline__ float snake_al_lo(float al, float al_pi) {   // alpha / pi - al_pi: product residual + alpha * (1/pi - fl(1/pi))
+    return fmaf(al, 0.318309886183790672f, -al_pi) + al * 1.2841276653e-8f;
+}
+__device__ __forceinline__ f32x2 snake2(f32x2 u, float al, float ib, float al_pi, float al_lo, float hb) {
 #ifdef FV_X_SNAKE_POLY
-    (void)al_pi; (void)hb;
+    (void)al_pi; (void)al_lo; (void)hb;
     return __builtin_elementwise_fma((f32x2)(ib), sin_squared2(u * al), u);
 #else
     (void)al; (void)ib;
     const f32x2 ph = u * al_pi;
+#ifndef FV_X_SNAKE_FAST
+    f32x2 r = __builtin_elementwise_fma(u, (f32x2)(al_pi), -ph);
+    r = __builtin_elementwise_fma(u, (f32x2)(al_lo), r);
+#else
+    (void)al_lo;
+    const f32x2 r = f32x2{0.f, 0.f};
+#endif
     f32x2 c;
-    c.x = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ph.x));
-    c.y = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ph.y));
+    c.x = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ph.x) + r.x);
+    c.y = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ph.y) + r.y);
     return __builtin_elementwise_fma(c, (f32x2)(-hb), u + hb);
 #endif
 }
@@ -274,7 +287,7 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
                                               const float* __restrict__ down_taps, float al, float ib, int t0, int T,
                                               const float* __restrict__ x2r = nullptr, const float* __restrict__ x3r = nullptr) {
     const int tid = threadIdx.x;
-    const float al_pi = al * 0.318309886183790672f, hb = 0.5f * ib;
+    const float al_pi = al * 0.318309886183790672f, al_lo = snake_al_lo(al, al_pi), hb = 0.5f * ib;
     auto load_x = [&](int e) {
         int t = t0 - 6 + e;
         if (EDGE) t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);   // replicate padding of the up-sampler input
@@ -304,7 +317,7 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
             const f32x2 xp = {xs[xi + 2 - q], xs[xi + 3 - q]};
             u = __builtin_elementwise_fma(upp[q], xp, u);
         }
-        f32x2 a = snake2(u, al, ib, al_pi, hb);
+        f32x2 a = snake2(u, al, ib, al_pi, al_lo, hb);
         if (EDGE) {   // replicate padding of the down-sampler input: n < 0 -> a[0] (even sample of h = 0), n > 2T-1 -> a[2T-1]
             if (h < 0) a.y = a.x;
             if (h > T - 1) a.x = a.y;
@@ -349,7 +362,7 @@ __device__ __forceinline__ void aa_snake4_tile(const float* __restrict__ xr, flo
                                                float* __restrict__ E, float* __restrict__ O, const float* __restrict__ up_taps,
                                                const float* __restrict__ down_taps, float al, float ib, int t0, int T) {
     const int tid = threadIdx.x;
-    const float al_pi = al * 0.318309886183790672f, hb = 0.5f * ib;
+    const float al_pi = al * 0.318309886183790672f, al_lo = snake_al_lo(al, al_pi), hb = 0.5f * ib;
     typedef float f4 __attribute__((ext_vector_type(4)));
     if constexpr (EDGE) {
         auto cl = [&](int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
@@ -388,7 +401,7 @@ __device__ __forceinline__ void aa_snake4_tile(const float* __restrict__ xr, flo
                 ue = fmaf(upe[q], w[k + 7 - q], ue);
                 uo = fmaf(upo[q], w[k + 8 - q], uo);
             }
-            const f32x2 a = snake2(f32x2{ue, uo}, al, ib, al_pi, hb);
+            const f32x2 a = snake2(f32x2{ue, uo}, al, ib, al_pi, al_lo, hb);
             ev[k] = a.x;
             od[k] = a.y;
         }

@@ -171,6 +171,15 @@ class Engine:
         """hipGraph replay of repeated identical calls (default on); off = every forward enqueues its kernels eagerly."""
         check(self._lib.fv_set_graph_replay(self._h, int(bool(enable))))
 
+    def set_conv_algorithm(self, algo: str) -> None:
+        """"auto" (per launch, fastest), "direct" (direct sums everywhere) or "winograd" (F(2,3) tap groups wherever a kernel exists):
+        include/fishvoc.h ``fv_conv_algo``.  Changes the last bits of the output, not its parity."""
+        check(self._lib.fv_set_conv_algorithm(self._h, _lib.CONV_ALGOS[algo]))
+
+    def set_batch_invariant(self, enable: bool) -> None:
+        """Kernel choices from the layer shape alone: a clip's output no longer depends on the batch it is part of (slower single clips)."""
+        check(self._lib.fv_set_batch_invariant(self._h, int(bool(enable))))
+
     def output_length(self, t_in: int) -> int:
         return int(self._lib.fv_output_length(self._h, int(t_in)))
 
@@ -295,6 +304,11 @@ class FusedConv:
     def set_precision(self, precision: str) -> "FusedConv":
         """"f32" (default) or "f16x3" (split-fp16 MFMA where the layer shape has such a kernel)."""
         check(self._lib.fv_conv_set_precision(self._h, _lib.PRECISIONS[precision]))
+        return self
+
+    def set_algorithm(self, algo: str) -> "FusedConv":
+        """"auto" | "direct" | "winograd" for the following calls on this layer (a pair follows c1's setting)."""
+        check(self._lib.fv_conv_set_algorithm(self._h, _lib.CONV_ALGOS[algo]))
         return self
 
     def __call__(self, x: torch.Tensor, residual: torch.Tensor | None = None, out: torch.Tensor | None = None):
