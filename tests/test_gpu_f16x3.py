@@ -255,7 +255,7 @@ def test_f16x3_pair16_needs_an_even_length_and_falls_back_to_fp32_otherwise():
     w = (rng.normal(size=(16, 16, 7)) / 10.0).astype(np.float32)
     c1 = FusedConv(w, None, dilation=3, padding=9).set_precision("f16x3")
     c2 = FusedConv(w, None, padding=3).set_precision("f16x3")
-    for T, want in ((300, "pair_f16x3"), (301, "resblock_pair")):
+    for T, want in ((300, "pair_f16x3"), (301, "pair_wino")):   # (the exact-fp32 pair kernel of this shape: pair_wino_impl.h)
         x = rng.normal(size=(2, 16, T)).astype(np.float32)
         y = c1.pair(c2, torch.from_numpy(x).to(_dev()))
         torch.cuda.synchronize()

@@ -510,6 +510,11 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     p.y_bstride = (long long)L.c_out * tout;
     p.acc_scale = 1.0f;
 
+    // stride-8 upsamplers, bias only, aligned: 16-byte output quads (conv_mfma_impl.h: conv_epilogue)
+    static const bool no_vec_store = std::getenv("FV_VEC_STORE") && std::atoi(std::getenv("FV_VEC_STORE")) == 0;   // experiments: FV_VEC_STORE=0
+    p.vec_store = (L.transposed && L.stride == 8 && !r.res && !r.gamma && r.out_mode == OUT_SET && r.post_act == FV_ACT_NONE &&
+                   tout % 4 == 0 && L.padding % 4 == 0 && ((uintptr_t)r.y & 15) == 0 && !no_vec_store) ? 1 : 0;
+
     if (f16) return conv_layer_run_f16x3(L, r, p, stream);
 
     // pointwise convs of the MFMA-bound kind (ConvNeXt's Linear layers): the LDS-free GEMM kernel (gemm_pw.hip)

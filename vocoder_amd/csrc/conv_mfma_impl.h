@@ -146,6 +146,37 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, f32x16 (
 
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][NT], int b, int mt0, int ncol0, int lane) {
+    if (p.vec_store) {
+        // Polyphase transposed conv with stride 8 (the first upsamplers, hifigan.py:175-187), bias only: GEMM row m = (c_out, phase m & 7),
+        // and the accumulator layout gives a lane the four rows 8 rq + 4 (lane >> 5) + {0..3} of GEMM column n — four CONSECUTIVE output
+        // samples t = 8 n - pad + 4 (lane >> 5) + {0..3} of one channel: one 16-byte store instead of four scattered dwords, and the two
+        // half-waves of an instruction fill whole 32-byte sectors (round 4: these launches have K = 512 ... 1024 only, their epilogue was
+        // a third of a workgroup's life).  The host sets vec_store only when every such quad is 16-byte aligned and entirely inside
+        // or outside [0, Tout) (Tout % 4 == 0, pad % 4 == 0, aligned tensors) and nothing but the bias is applied.
+        const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, (unsigned)(p.y_bstride * 4));
+        const int khalf = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int m0 = (mt0 + i) * 32 + 8 * rq + 4 * khalf;
+                const f32x4 bv = *(const f32x4*)(p.bias + m0);   // (bias is padded to whole 128-row blocks)
+                const int row_off = (m0 >> 3) * p.Tout - p.pad_t + 4 * khalf;
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    const int n = ncol0 + jn * 32;
+                    const int t = n * 8 - p.pad_t + 4 * khalf;
+                    const bool ok = m0 < p.M && n < p.N && t >= 0 && t < p.Tout;
+                    u32x4 v;
+                    v.x = __float_as_uint(fmaf(acc[i][jn][4 * rq + 0], p.acc_scale, bv.x));
+                    v.y = __float_as_uint(fmaf(acc[i][jn][4 * rq + 1], p.acc_scale, bv.y));
+                    v.z = __float_as_uint(fmaf(acc[i][jn][4 * rq + 2], p.acc_scale, bv.z));
+                    v.w = __float_as_uint(fmaf(acc[i][jn][4 * rq + 3], p.acc_scale, bv.w));
+                    __builtin_amdgcn_raw_buffer_store_b128(v, yrs, ok ? (unsigned)(row_off + n * 8) * 4u : 0xFFFFFFFFu, 0, 0);
+                }
+            }
+        return;
+    }
     // column part of the element offset (independent of the row) and its validity
     int coff[NT];
     bool cok[NT];

@@ -133,6 +133,7 @@ struct ConvParams {
     float acc_scale;     // accumulator scale applied before the bias (1 for the fp32 kernels, 1/s_w for f16x3)
     int xcd_rows;        // gemm_pw.hip: row groups the 8 XCDs split the m-tiles into (1, 2, 4 or 8)
     int wg_total;        // conv_wino_impl.h: workgroups of the launch (the grid is rounded up to a multiple of the 8 XCDs)
+    int vec_store;       // conv_epilogue: stride-8 polyphase transposed conv whose output quads can go out as 16-byte stores
 #if defined(FV_X_SPLITK_TS) || defined(FV_X_CONV_TS)
     long long* dbg_ts;   // experiment: per-workgroup phase time stamps (split-K kernel / tiled conv kernel)
 #endif

@@ -59,6 +59,7 @@ struct PWGeom {
     static constexpr int EO_F = C * SE, D_F = CH * SD, XR_F = C * XS + 16;
     static constexpr int TRASH = EO_F + D_F + XR_F;      // one float nobody reads
     static constexpr int LDS_FLOATS = TRASH + 4;
+    static constexpr int CHN = CH;
     static constexpr int NF4 = CH / FCH * NV;            // weight fragments per chunk
     static constexpr int NMS = NF4 / U;                  // macro-steps per chunk
     static_assert(NF4 % U == 0, "whole macro-steps");
@@ -85,7 +86,7 @@ __device__ __forceinline__ float pw_silu(float v) { return v * __builtin_amdgcn_
 // E / O planes (rows eo .. eo + CH - 1) -> d0..d3 planes of the chunk buffer.  TPR threads per channel row, consecutive columns.
 template <class G, int DX, int WD>
 __device__ __forceinline__ void pw_transform(const float* __restrict__ eo, float* __restrict__ d, int tid) {
-    constexpr int CHn = G::D_F / G::SD;
+    constexpr int CHn = G::CHN;
     constexpr int TPR = 256 / CHn, SLOTS = (WD + TPR - 1) / TPR;
     const int row = tid / TPR, c0 = tid % TPR;
     const float* e = eo + row * G::SE + c0;
@@ -399,8 +400,9 @@ __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p)
 // XRES: the raw tile for the residual stays in LDS (C = 64 at most: at C = 128 it does not fit next to the window); otherwise the last
 // epilogue reads x again, requested before c2's matrix loop starts.
 // ---------------------------------------------------------------------------------------------------------------------------------------
-template <int KS, int DIL, int C, int CH, int NT, bool XRES_>
+template <int KS, int DIL, int C, int CH, int NT, bool XRES_, bool DBUF_ = false>
 struct PW32Geom {
+    static constexpr bool DBUF = DBUF_;                  // two chunk buffers: one workgroup barrier per chunk instead of two
     static_assert(C == 64 || C == 128, "one 32-row m-tile per wave");
     static_assert(CH % 8 == 0 && C % CH == 0, "chunks of whole 8-channel fragments");
     static constexpr bool XRES = XRES_;
@@ -415,13 +417,15 @@ struct PW32Geom {
     static constexpr int WD2 = NBP + 2 * (NG - 1), WR2 = WD2 + 1;
     static constexpr int NQ1 = (WR1 + DIL - 1) / DIL;
     static constexpr int NP1 = 2 * DIL * NQ1;
-    static constexpr int PE = pw_up(DIL * NQ1, 16, 8);   // (the transform's 16-lane row segments sit on disjoint banks; the 32-lane MFMA reads
-    static constexpr int PD = pw_up(WD1, 8, 4);          //  are conflict-free with any stride)
+    static constexpr int PE = (DIL * NQ1 + 1) / 2 * 2;   // (a 32-lane group of the MFMA reads / the transform covers one row: any stride is conflict-free
+    static constexpr int PD = pw_up(WD1, 8, 4);          //  for CH = 8; the 16-lane row segments of CH = 16 want 4 PD == 16 (mod 32))
     static constexpr int SE = 2 * PE, SD = 4 * PD;
     static constexpr int XS = TT + 2;
-    static constexpr int EO_F = C * SE, D_F = CH * SD, XR_F = XRES ? C * XS + 16 : 0;
+    static constexpr int DB_F = CH * SD;                 // one chunk buffer
+    static constexpr int EO_F = C * SE, D_F = (DBUF ? 2 : 1) * DB_F, XR_F = XRES ? C * XS + 16 : 0;
     static constexpr int TRASH = EO_F + D_F + XR_F;
     static constexpr int LDS_FLOATS = TRASH + 4;
+    static constexpr int CHN = CH;
     static constexpr int NF4 = CH / 8 * NV;              // weight fragments (8 channels x one virtual tap = 4 MFMAs per n-tile) per chunk
     static constexpr int DA = 3, RA = 4;                 // weight ring: RA divides the fragments of a chunk (NV * CH / 8)
     static_assert(NF4 % RA == 0, "the ring returns to slot 0 at every chunk boundary");
@@ -468,9 +472,9 @@ __device__ __forceinline__ void pw32_gemm_chunk(f32x16 (&acc)[4][1], const float
     });
 }
 
-template <int KS, int DIL, int C, int CH, bool XRES>
+template <int KS, int DIL, int C, int CH, bool XRES, bool DBUF>
 __global__ __launch_bounds__(256, 2) void pair_wino32_kernel(const PairParams p) {
-    using G = PW32Geom<KS, DIL, C, CH, 1, XRES>;
+    using G = PW32Geom<KS, DIL, C, CH, 1, XRES, DBUF>;
     constexpr int DA = G::DA, NCHK = C / CH, WN = G::WN;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* EO = lds;
@@ -482,6 +486,13 @@ __global__ __launch_bounds__(256, 2) void pair_wino32_kernel(const PairParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int lid = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);   // a clip's tiles on one XCD
     if (lid >= p.n_tiles * p.batch) return;
+#ifdef FV_X_PW_STAGGER
+    // experiment: the first round's workgroups of a CU start a third of a workgroup life apart (are the co-resident workgroups in lock-step?)
+    if (blockIdx.x < 768) {
+        const int k = (int)(blockIdx.x >> 8);
+        for (int i = 0; i < k * FV_X_PW_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     const int tile = lid % p.n_tiles, b = lid / p.n_tiles;
     const int t0 = tile * G::TT;
     const int T = p.T;
@@ -527,11 +538,24 @@ __global__ __launch_bounds__(256, 2) void pair_wino32_kernel(const PairParams p)
     __syncthreads();
 
     // ---- c1 ----
-    for (int c = 0; c < NCHK; ++c) {
-        pw_transform<G, DIL, G::WD1>(EO + c * CH * G::SE, Db, tid);
+    if constexpr (DBUF) {
+        // chunk c + 1 is transformed into the other buffer BEFORE chunk c's matrix loop: one barrier per chunk, and the transform's LDS
+        // round trip runs under the matrix instructions that follow it
+        pw_transform<G, DIL, G::WD1>(EO, Db, tid);
         __syncthreads();
-        pw32_gemm_chunk<G, DIL>(acc, dl, el + c * CH * G::SE, w1rs, wvoff, __builtin_amdgcn_readfirstlane(wbase + (c * G::NF4 + DA) * 1024), aq);
-        __syncthreads();
+        for (int c = 0; c < NCHK; ++c) {
+            if (c + 1 < NCHK) pw_transform<G, DIL, G::WD1>(EO + (c + 1) * CH * G::SE, Db + ((c + 1) & 1) * G::DB_F, tid);
+            pw32_gemm_chunk<G, DIL>(acc, dl + (c & 1) * G::DB_F, el + c * CH * G::SE, w1rs, wvoff,
+                                    __builtin_amdgcn_readfirstlane(wbase + (c * G::NF4 + DA) * 1024), aq);
+            __syncthreads();
+        }
+    } else {
+        for (int c = 0; c < NCHK; ++c) {
+            pw_transform<G, DIL, G::WD1>(EO + c * CH * G::SE, Db, tid);
+            __syncthreads();
+            pw32_gemm_chunk<G, DIL>(acc, dl, el + c * CH * G::SE, w1rs, wvoff, __builtin_amdgcn_readfirstlane(wbase + (c * G::NF4 + DA) * 1024), aq);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int d = 0; d < DA; ++d) aq[d] = load_w(w2rs, d);
@@ -584,11 +608,22 @@ __global__ __launch_bounds__(256, 2) void pair_wino32_kernel(const PairParams p)
     __syncthreads();
 
     // ---- c2 (dilation 1) ----
-    for (int c = 0; c < NCHK; ++c) {
-        pw_transform<G, 1, G::WD2>(EO + c * CH * G::SE, Db, tid);
+    if constexpr (DBUF) {
+        pw_transform<G, 1, G::WD2>(EO, Db, tid);
         __syncthreads();
-        pw32_gemm_chunk<G, 1>(acc, dl, el + c * CH * G::SE, w2rs, wvoff, __builtin_amdgcn_readfirstlane(wbase + (c * G::NF4 + DA) * 1024), aq);
-        if (c + 1 < NCHK) __syncthreads();
+        for (int c = 0; c < NCHK; ++c) {
+            if (c + 1 < NCHK) pw_transform<G, 1, G::WD2>(EO + (c + 1) * CH * G::SE, Db + ((c + 1) & 1) * G::DB_F, tid);
+            pw32_gemm_chunk<G, 1>(acc, dl + (c & 1) * G::DB_F, el + c * CH * G::SE, w2rs, wvoff,
+                                  __builtin_amdgcn_readfirstlane(wbase + (c * G::NF4 + DA) * 1024), aq);
+            if (c + 1 < NCHK) __syncthreads();
+        }
+    } else {
+        for (int c = 0; c < NCHK; ++c) {
+            pw_transform<G, 1, G::WD2>(EO + c * CH * G::SE, Db, tid);
+            __syncthreads();
+            pw32_gemm_chunk<G, 1>(acc, dl, el + c * CH * G::SE, w2rs, wvoff, __builtin_amdgcn_readfirstlane(wbase + (c * G::NF4 + DA) * 1024), aq);
+            if (c + 1 < NCHK) __syncthreads();
+        }
     }
 
     // ---- c2 epilogue: + raw x -> y ----
@@ -633,24 +668,27 @@ __global__ __launch_bounds__(256, 2) void pair_wino32_kernel(const PairParams p)
 }
 
 #ifndef FV_X_PW_CH64
-#define FV_X_PW_CH64 16
+#define FV_X_PW_CH64 8
+#endif
+#ifndef FV_X_PW_DBUF
+#define FV_X_PW_DBUF 0
 #endif
 #ifndef FV_X_PW_CH128
-#define FV_X_PW_CH128 16
+#define FV_X_PW_CH128 8
 #endif
 #ifndef FV_X_PW_XRES64
-#define FV_X_PW_XRES64 0
+#define FV_X_PW_XRES64 1   // the raw tile stays in LDS at C = 64 (two workgroups per CU; measured equal to three without it, at 1.0 x the traffic)
 #endif
 
-template <int KS, int DIL, int C, int CH, bool XRES>
+template <int KS, int DIL, int C, int CH, bool XRES, bool DBUF>
 inline bool launch_pair_wino32_one(const PairParams& p, int batch, hipStream_t s) {
-    using G = PW32Geom<KS, DIL, C, CH, 1, XRES>;
+    using G = PW32Geom<KS, DIL, C, CH, 1, XRES, DBUF>;
     PairParams q = p;
     q.n_tiles = (p.T + G::TT - 1) / G::TT;
     q.batch = batch;
     const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
-    if (!FV_ENSURE_DYN_LDS((pair_wino32_kernel<KS, DIL, C, CH, XRES>), lds)) return false;
-    hipLaunchKernelGGL((pair_wino32_kernel<KS, DIL, C, CH, XRES>), dim3((batch * q.n_tiles + 7) / 8 * 8), dim3(256), lds, s, q);
+    if (!FV_ENSURE_DYN_LDS((pair_wino32_kernel<KS, DIL, C, CH, XRES, DBUF>), lds)) return false;
+    hipLaunchKernelGGL((pair_wino32_kernel<KS, DIL, C, CH, XRES, DBUF>), dim3((batch * q.n_tiles + 7) / 8 * 8), dim3(256), lds, s, q);
     return true;
 }
 
@@ -677,8 +715,8 @@ inline bool launch_pair_wino16_k(const PairParams& p, int C, int dil, int batch,
         if (C == 16) return launch_pair_wino16_one<KS, D, 16, 16>(p, batch, s);            \
         if (C == 32) return launch_pair_wino16_one<KS, D, 32, FV_X_PW_CH32>(p, batch, s);  \
         if constexpr (KS == 3) {                                                           \
-            if (C == 64) return launch_pair_wino32_one<KS, D, 64, FV_X_PW_CH64, FV_X_PW_XRES64 != 0>(p, batch, s);   \
-            if (C == 128) return launch_pair_wino32_one<KS, D, 128, FV_X_PW_CH128, false>(p, batch, s);              \
+            if (C == 64) return launch_pair_wino32_one<KS, D, 64, FV_X_PW_CH64, FV_X_PW_XRES64 != 0, FV_X_PW_DBUF != 0>(p, batch, s);   \
+            if (C == 128) return launch_pair_wino32_one<KS, D, 128, FV_X_PW_CH128, false, FV_X_PW_DBUF != 0>(p, batch, s);              \
         }                                                                                  \
     }
     FV_PW_CASE(1) FV_PW_CASE(3) FV_PW_CASE(5)
