@@ -333,6 +333,42 @@ def test_winograd_conv_matches_oracle(cfg, monkeypatch):
         _lib.reload_env()
 
 
+LAT_CASES = [
+    # (C, k, dil, B, T): single clips / small batches below the Winograd gate; ragged lengths; both tile widths (16 / 32 pairs)
+    (256, 11, 1, 1, 688), (256, 11, 5, 1, 97), (256, 7, 3, 1, 344), (256, 3, 1, 2, 200), (128, 11, 1, 1, 5504), (128, 11, 3, 1, 517),
+    (128, 7, 5, 1, 2048), (128, 3, 5, 1, 131), (64, 11, 5, 1, 11008), (64, 7, 1, 1, 129), (64, 3, 3, 1, 64), (192, 7, 5, 1, 1000),
+    (96, 11, 1, 1, 255), (32, 11, 5, 1, 900), (32, 7, 3, 1, 77), (32, 3, 1, 1, 2), (128, 11, 5, 1, 9), (128, 7, 3, 1, 1),
+]
+
+
+def test_winograd_latency_conv_matches_oracle():
+    """conv_wino_lat_impl.h — the Winograd conv of launches too small to fill the chip (the reference's single-utterance forward,
+    test.py:88-90): 16-row tiles on 16x16x4 MFMAs, K split over the four waves.  SiLU + bias + residual, the plain conv, and
+    c1's fused post-activation against the CPU oracle on ragged shapes; the direct split-K kernels on the same layer via fv_conv_set_algorithm."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import FusedConv
+    for (c, k, d, B, T) in LAT_CASES:
+        rng = np.random.default_rng(c * 1000 + k * 7 + d + T)
+        x = rng.normal(size=(B, c, T)).astype(np.float32)
+        w = (rng.normal(size=(c, c, k)) / np.sqrt(c * k)).astype(np.float32)
+        b = rng.normal(size=c).astype(np.float32)
+        pad = (k - 1) * d // 2
+        ref = orc.conv1d(orc.silu(x), w, b, dilation=d, padding=pad)
+        res = rng.normal(size=ref.shape).astype(np.float32)
+        y = _run(w, b, x, res, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
+        assert _lib.last_kernel().startswith("conv_wino_lat<"), (_lib.last_kernel(), c, k, d, B, T)
+        _check(y, ref + res)
+        y2 = _run(w, None, x, None, dilation=d, padding=pad)
+        _check(y2, orc.conv1d(x, w, None, dilation=d, padding=pad))
+        y3 = _run(w, b, x, None, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU, post_act=_lib.FV_ACT_SILU)
+        _check(y3, orc.silu(ref))
+        conv = FusedConv(w, b, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU).set_algorithm("direct")
+        yd = conv(torch.from_numpy(x).to(_dev()), torch.from_numpy(res).to(_dev()))
+        torch.cuda.synchronize()
+        assert _lib.last_kernel().startswith("conv_mfma<"), _lib.last_kernel()
+        assert np.abs(yd.cpu().numpy() - y).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
 def test_winograd_conv_offsets_beyond_2_gib(monkeypatch):
     """One batch item of 2.2 GB (C = 128, T = 4.3 M samples: byte offsets past 2^31, under the 4 GiB addressing span conv_layer_run
     enforces): the Winograd kernel (staging offsets, SGPR row offsets of its epilogue) against the direct-sum kernel on the same

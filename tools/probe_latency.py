@@ -18,5 +18,5 @@ print(prec, "p50 ms", np.percentile(lat, 50))
 tab = eng.profile(mel, repeats=3)
 tot = sum(r["total_ms"] for r in tab) / 3
 print("serialized kernel ms", tot, "launches", sum(r["launches"] for r in tab) // 3)
-for r in sorted(tab, key=lambda r: -r["total_ms"])[:24]:
+for r in sorted(tab, key=lambda r: -r["total_ms"])[:int(os.environ.get("TOP", "24"))]:
     print(f"{r['total_ms']/3:7.3f} ms x{r['launches']//3:2d} avg {r['avg_ms']*1e3:7.1f} us {r['flops_per_launch']/r['avg_ms']/1e9:6.1f} TF  {r['kernel']}")

@@ -173,6 +173,22 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
             FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw, pw.size() * sizeof(float)));
             FV_HIP_CHECK(hipMemcpy(L.d_wpw, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+        if (c_in >= 32 && c_in % 32 == 0) {
+            // conv_wino_lat_impl.h: fragment ((mt * nblk + blk) * nv / 2 + vp), one float4 per lane = A operands (row = lane & 15, k = lane >> 4) of
+            // four 16x16x4 MFMAs: .{x,y} = virtual tap 2 vp, channel quads 0 / 1 of 8-channel block blk; .{z,w} = virtual tap 2 vp + 1
+            const int nblk = c_in / 8, nf = nv / 2, mts = c_out / 16;
+            std::vector<float> pl(((size_t)mts * nblk * nf + 8) * 64 * 4, 0.f);
+            for (int mt = 0; mt < mts; ++mt)
+                for (int blk = 0; blk < nblk; ++blk)
+                    for (int vp = 0; vp < nf; ++vp)
+                        for (int l = 0; l < 64; ++l)
+                            for (int q = 0; q < 4; ++q) {
+                                const int co = 16 * mt + (l & 15), ci = 8 * blk + 4 * (q & 1) + (l >> 4), v = 2 * vp + (q >> 1);
+                                pl[((((size_t)mt * nblk + blk) * nf + vp) * 64 + l) * 4 + q] = ww[((size_t)co * c_in + ci) * nv + v];
+                            }
+            FV_HIP_CHECK(hipMalloc((void**)&L.d_wpwl, pl.size() * sizeof(float)));
+            FV_HIP_CHECK(hipMemcpy(L.d_wpwl, pl.data(), pl.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         if (c_in == 16 || c_in == 32) {
             // pair_wino_impl.h: A fragments of v_mfma_f32_16x16x4_f32 (row = lane & 15, k = lane >> 4), one float4 per lane = four MFMAs.
             //   C = 16: fragment v            .{x,y,z,w}[s]       = W'[lane & 15][4 s + (lane >> 4)][v]                      (16 channels)
@@ -248,6 +264,8 @@ void conv_layer_destroy(ConvLayer& L) {
     L.d_wpw = nullptr;
     if (L.d_wpw16) (void)hipFree(L.d_wpw16);
     L.d_wpw16 = nullptr;
+    if (L.d_wpwl) (void)hipFree(L.d_wpwl);
+    L.d_wpwl = nullptr;
     if (L.d_wph) (void)hipFree(L.d_wph);
     if (L.d_wph16) (void)hipFree(L.d_wph16);
     L.d_wph16 = nullptr;
@@ -594,6 +612,47 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
             }
         }
     }
+    // ... and for launches below that gate (single clips, small batches) the Winograd latency kernel: 16-row tiles, K split over the waves
+    // (conv_wino_lat_impl.h).  Not in batch-invariant mode (another order of the K sum than conv_wino_kernel).
+    if (algo != FV_CONV_ALGO_DIRECT && knobs().wino_lat && L.d_wpwl && !p.x2 && !r.gamma && !cur_invariant() &&
+        (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU) && L.M >= knobs().wino_min_m) {
+        const long long np = (long long)L.dil * ((tout + 2 * L.dil - 1) / (2 * L.dil));
+        const long long mts = L.M / 16, nts = (np + 15) / 16;
+        // the largest tile (32 rows x 32 pairs: every staged / transformed operand feeds twice the matrix instructions, every weight
+        // fragment twice the columns) that still leaves ~2 workgroups per CU; the smallest one otherwise
+        int tile = 0;
+        if (L.M % 32 == 0) {
+            if ((long long)r.batch * (mts / 2) * ((nts + 1) / 2) >= 2LL * num_cus()) tile = 2;
+            else if ((long long)r.batch * (mts / 2) * nts >= 2LL * num_cus()) tile = 1;
+        }
+        if (knobs().wino_lat >= 10) tile = knobs().wino_lat - 10;   // experiments: FV_WINO_LAT=10 / 11 / 12 force a tile
+        const int rows = tile == 0 ? 16 : 32, pairs = tile == 2 ? 32 : 16;
+        p.wp = L.d_wpwl;
+        p.m_blks = (int)(L.M / rows);
+        p.n_tiles = (int)((np + pairs - 1) / pairs);
+        const int prof_idx = prof_begin(stream);
+        const bool launched = L.ks == 3 ? launch_conv_wino_lat_k3(p, tile, r.batch, stream)
+                              : L.ks == 7 ? launch_conv_wino_lat_k7(p, tile, r.batch, stream) : launch_conv_wino_lat_k11(p, tile, r.batch, stream);
+        if (!launched) {
+            set_error("conv_layer_run: no Winograd latency kernel for (k=%d, dilation=%d)", L.ks, L.dil);
+            return FV_ERR_UNSUPPORTED;
+        }
+        static thread_local char name[96];
+        std::snprintf(name, sizeof(name), "conv_wino_lat<k=%d d=%d tile=%dx%dp>", L.ks, L.dil, rows, pairs);
+        set_last_kernel(name);
+        if (prof_idx >= 0) {
+            const double macs = (double)L.c_in * L.c_out * L.k * (double)tout * r.batch;   // ALGORITHMIC (direct-sum) MACs
+            double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
+            if (r.res) elems += (double)L.c_out * tout;
+            if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
+            char lbl[160];
+            std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d grid=%d", name, L.c_in, L.c_out, r.batch * p.m_blks * p.n_tiles);
+            prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
+        }
+        FV_HIP_CHECK(hipGetLastError());
+        return FV_OK;
+    }
+    p.wp = L.d_wp;
     int cfg = choose_tile(L.M, p.N, r.batch);
     // the stage-0 upsampler of a 1 s clip: 87 GEMM columns per item fill two thirds of a 128-column tile — 128 x 96 tiles (four waves
     // along M, three n-tiles each; instantiated for the two-tap polyphase convs only)

@@ -1,0 +1,5 @@
+// Latency variant of the Winograd conv (conv_wino_lat_impl.h), k = 3
+#include "conv_wino_lat_impl.h"
+namespace fv {
+bool launch_conv_wino_lat_k3(const ConvParams& p, int nt, int batch, hipStream_t s) { return launch_wino_lat_k<3>(p, nt, batch, s); }
+}  // namespace fv

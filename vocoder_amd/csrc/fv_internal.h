@@ -30,6 +30,7 @@ struct Knobs {
     int wino_min_m = 32;  // FV_WINO_MIN_M: narrowest layer (output rows) that takes it
     int wino_cfg = -1;    // FV_WINO_CFG: forced tile (WinoCfg 0 ... 2), -1 = by shape
     int wino_min_blocks = -1;   // FV_WINO_MIN_BLOCKS: fewest workgroups of a launch that takes it, -1 = default
+    int wino_lat = 1;     // FV_WINO_LAT: 0 = launches below the Winograd gate run the direct split-K kernels, 1 = the Winograd latency kernel
     int pair_wino = 1;    // FV_PAIR_WINO: 0 = the fused (c1, c2) pairs run direct sums (resblock_pair.hip), 1 = Winograd tap groups where a kernel exists
 };
 const Knobs& knobs();
@@ -153,6 +154,7 @@ struct ConvLayer {
     float4* d_wpw = nullptr;   // Winograd-transformed weights in the same fragment order, nv virtual taps (conv_wino_impl.h); optional
     int nv = 0;
     float4* d_wp16 = nullptr;  // 16x16x4-fragment layout, only for 16 -> 16 channel Conv1d (fused pair kernel)
+    float4* d_wpwl = nullptr;  // Winograd-transformed weights of the latency kernel: 16-row tiles, 8-channel blocks, tap pairs (conv_wino_lat_impl.h); optional
     float4* d_wpw16 = nullptr; // Winograd-transformed weights in 16x16x4 fragment order, C -> C with C in {16, 32} (pair_wino_impl.h); optional
     void* d_wph16 = nullptr;   // f16x3 mode, 16 -> 16 channel Conv1d: (wh, wl) planes of the two-samples-per-row layout (pair16_f16x3.hip)
     void* d_wph = nullptr;     // f16x3 mode: (wh, wl, wh * 2^-11) fp16 planes in 32x32x16 fragment order (optional)
@@ -273,6 +275,11 @@ enum WinoCfg : int { WINO_128x32 = 0, WINO_64x64 = 1, WINO_32x128 = 2, WINO_128x
 bool launch_conv_wino_k3(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_wino_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_wino_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
+// conv_wino_lat_impl.h: latency variant (16 rows x 16 nt pairs per workgroup, K split over the four waves); p.wp = the layer's d_wpwl,
+// p.m_blks = C / 16, p.n_tiles in units of 16 nt pair columns
+bool launch_conv_wino_lat_k3(const ConvParams& p, int nt, int batch, hipStream_t s);
+bool launch_conv_wino_lat_k7(const ConvParams& p, int nt, int batch, hipStream_t s);
+bool launch_conv_wino_lat_k11(const ConvParams& p, int nt, int batch, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Small fused kernels (elementwise / narrow-output / reduction)
