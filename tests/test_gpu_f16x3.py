@@ -58,7 +58,7 @@ def test_f16x3_conv_matches_oracle(cin, cout, k, d, B, T):
     assert err <= 1e-4 and err <= 2e-5 * scale, f"max|d|={err:.3e} scale={scale:.2f} ({kern})"
     # and it must be at least as close to the oracle as 4x the exact-fp32 kernel's own error (fp32-class accuracy)
     y32, kern32 = _conv(w, b, x, res, "f32", dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
-    assert kern32.startswith("conv_mfma"), kern32
+    assert kern32.startswith(("conv_mfma", "conv_wino")), kern32   # (direct sums, or Winograd tap groups where the shape has them)
     err32 = np.abs(y32 - ref).max()
     assert err <= max(4 * err32, 2e-6 * scale), f"f16x3 {err:.3e} vs f32 {err32:.3e}"
 
@@ -209,7 +209,8 @@ def test_f16x3_range_contract_is_loud():
     ref = orc.conv1d(x, w, None, padding=1)
     assert np.isfinite(y16[0][:, keep]).all() and np.abs(y16[0][:, keep] - ref[0][:, keep]).max() <= 1e-4
     y32, _ = _conv(w, None, x, None, "f32", padding=1)
-    assert np.isfinite(y32).all() and np.abs(y32 - ref).max() <= 1e-2   # 1e5-scale values: fp32 roundoff
+    # 1e5-scale values: fp32 roundoff relative to the largest output (the Winograd tap groups round the outlier's neighbours at its ulp)
+    assert np.isfinite(y32).all() and np.abs(y32 - ref).max() <= 3e-6 * np.abs(ref).max(), (np.abs(y32 - ref).max(), np.abs(ref).max())
 
 
 PAIR_CASES = [(256, 11, 5, 1, 688), (256, 3, 1, 2, 100), (256, 7, 3, 1, 87), (128, 11, 1, 2, 300), (128, 11, 5, 1, 517), (128, 7, 3, 2, 200), (128, 3, 1, 1, 1000), (128, 3, 5, 3, 97),

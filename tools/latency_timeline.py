@@ -13,7 +13,9 @@ for r in rows[1:]:
     else:
         cur.append(r)
 bursts.append(cur)
-b = [x for x in bursts if len(x) % n == 0 and len(x) <= 40 * n][-1][-n:]   # back-to-back forwards merge into one burst: take the last
+cands = [x for x in bursts if len(x) % n == 0] or bursts
+b = max(cands, key=len)[-n:]   # back-to-back replayed forwards merge into one long burst: its last forward (the profiled pass — single
+                                # stream, events around every launch — is a burst of its own, n kernels long)
 t0 = b[0][0]
 end = t0
 for s, e, q, name, grid in b:

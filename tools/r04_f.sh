@@ -1,5 +1,5 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r04f
+O=$R/gpurun_out/r04q
 mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; tail -8 $O/pytest_gpu.log

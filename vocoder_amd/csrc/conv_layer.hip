@@ -287,6 +287,8 @@ static int effective_algo() {
     return w == 0 ? FV_CONV_ALGO_DIRECT : w >= 2 ? FV_CONV_ALGO_WINOGRAD : FV_CONV_ALGO_AUTO;
 }
 
+static int wino_lat_tile(const ConvLayer& L, long long np, int batch, int layers);
+
 static int choose_tile(int M, long long N, int batch) {
     int big, small;
     if (M <= 32) {
@@ -617,15 +619,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     if (algo != FV_CONV_ALGO_DIRECT && knobs().wino_lat && L.d_wpwl && !p.x2 && !r.gamma && !cur_invariant() &&
         (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU) && L.M >= knobs().wino_min_m) {
         const long long np = (long long)L.dil * ((tout + 2 * L.dil - 1) / (2 * L.dil));
-        const long long mts = L.M / 16, nts = (np + 15) / 16;
-        // the largest tile (32 rows x 32 pairs: every staged / transformed operand feeds twice the matrix instructions, every weight
-        // fragment twice the columns) that still leaves ~2 workgroups per CU; the smallest one otherwise
-        int tile = 0;
-        if (L.M % 32 == 0) {
-            if ((long long)r.batch * (mts / 2) * ((nts + 1) / 2) >= 2LL * num_cus()) tile = 2;
-            else if ((long long)r.batch * (mts / 2) * nts >= 2LL * num_cus()) tile = 1;
-        }
-        if (knobs().wino_lat >= 10) tile = knobs().wino_lat - 10;   // experiments: FV_WINO_LAT=10 / 11 / 12 force a tile
+        const int tile = wino_lat_tile(L, np, r.batch, 1);
         const int rows = tile == 0 ? 16 : 32, pairs = tile == 2 ? 32 : 16;
         p.wp = L.d_wpwl;
         p.m_blks = (int)(L.M / rows);
@@ -737,6 +731,19 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     }
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
+}
+
+// Tile of the Winograd latency kernel for `layers` equal layers launched together: the largest one that still leaves ~2 workgroups per CU
+static int wino_lat_tile(const ConvLayer& L, long long np, int batch, int layers) {
+    const long long mts = L.M / 16, nts = (np + 15) / 16;
+    int tile = 0;
+    if (L.M % 32 == 0) {
+        if ((long long)layers * batch * (mts / 2) * ((nts + 1) / 2) >= 2LL * num_cus()) tile = 2;
+        else if ((long long)layers * batch * (mts / 2) * nts >= 2LL * num_cus()) tile = 1;
+    }
+    if (knobs().wino_lat >= 10) tile = knobs().wino_lat - 10;   // experiments: FV_WINO_LAT=10 / 11 / 12 force a tile
+    if (L.M % 32 != 0) tile = 0;
+    return tile;
 }
 
 // f16x3 precision mode: wide (C = 128 / 64) SiLU pairs on the fused split-fp16 kernel (pair_f16x3_impl.h)

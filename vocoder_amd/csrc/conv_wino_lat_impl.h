@@ -45,16 +45,17 @@ struct WLGeom {
     }
 };
 
+// The workgroup's work as a device function (tools/experiments/conv_wino_lat3.hip runs the same-depth convs of a stage's three ResBlock
+// branches through it in one launch).  lds: 4 * WLGeom::WAVE_F floats.  wg = workgroup index inside the layer's grid.
 template <int KS, int DIL, int NT, int MT>
-__global__ __launch_bounds__(256, 2) void conv_wino_lat_kernel(const ConvParams p) {
+__device__ __forceinline__ void wino_lat_body(const ConvParams& p, float* __restrict__ lds, int wg) {
     using G = WLGeom<KS, DIL, NT, MT>;
     constexpr int NF = G::NF, NSLOT = G::NSLOT, PW = G::PW, PLANE = G::PLANE, MU = G::MU, RA = G::RA;
-    __shared__ __attribute__((aligned(16))) float lds[4 * G::WAVE_F];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* __restrict__ W = lds + wave * G::WAVE_F;           // this wave's planes
-    int bid = blockIdx.x;
+    int bid = wg;
     const int n_tile = bid % p.n_tiles;
     bid /= p.n_tiles;
     const int mt = (bid % p.m_blks) * MT;                     // first of the workgroup's MT 16-row tiles
@@ -271,6 +272,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_lat_kernel(const ConvParams 
     __builtin_amdgcn_s_waitcnt(0);
 #endif
     FV_CV_STAMP(14);
+}
+
+template <int KS, int DIL, int NT, int MT>
+__global__ __launch_bounds__(256, 2) void conv_wino_lat_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * WLGeom<KS, DIL, NT, MT>::WAVE_F];
+    wino_lat_body<KS, DIL, NT, MT>(p, lds, (int)blockIdx.x);
 }
 
 // tile: 0 = 16 rows x 16 pairs, 1 = 32 x 16, 2 = 32 x 32 (p.m_blks / p.n_tiles count these tiles)

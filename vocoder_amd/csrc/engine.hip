@@ -896,10 +896,10 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
             float* const y_last = tree ? XB(bj) : Y;   // tree: the branch keeps its own output, summed after the join
             // HiFiGAN narrow stages: the whole (c1, c2) pair in one kernel, intermediate kept in LDS.  Not in place
             // (workgroups read their neighbours' halo), so the branch ping-pongs S -> XB -> XT -> Y.
-            // (C = 128 pairs: 126-column tiles, two workgroups per CU — only when the launch fills the chip; a single clip's 44 tiles
-            //  are better served by the split-K latency kernels: p50 0.96 vs 1.04 ms)
+            // (C = 64 / 128 pairs — k = 3 only — fuse when the launch fills the chip; a single clip's 44 - 88 tiles are better served by the
+            //  per-layer latency kernels: conv_wino_lat_impl.h)
             const bool fuse_narrow = ch <= pair_max_c && pair_supported(ch, br.k, br.dil[0]) && pair_supported(ch, br.k, br.dil[1]) &&
-                                     pair_supported(ch, br.k, br.dil[2]) && (ch < 128 || cur_invariant() || (long long)B * ((t + 125) / 126) >= 2LL * num_cus());
+                                     pair_supported(ch, br.k, br.dil[2]) && (ch < 64 || cur_invariant() || (long long)B * ((t + 125) / 126) >= 2LL * num_cus());
             // f16x3 precision mode: the wide stages (C = 128 / 64) fuse too (pair_f16x3_impl.h)
             const bool fuse_wide = pair_f16x3_supported(br.c1[0], br.c2[0]) && pair_f16x3_supported(br.c1[1], br.c2[1]) &&
                                    pair_f16x3_supported(br.c1[2], br.c2[2]);

@@ -87,9 +87,10 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const float* __restric
 // bounds check supplies the zero padding.
 // SUM3: the input is ((x + x2) + x3) / 3 — the stack-mean of the last stage's three ResBlock branches, formed while staging instead
 // of by a mean_of_three_kernel pass over four tensors (the same additions in the same order: bit-identical).
-constexpr int POST_TT = 1024;
-template <int K, bool SUM3>
-__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+// POST_TT = 1024 columns per 256-thread workgroup; 256 columns per single-wave workgroup (round 4) for launches that would otherwise leave
+// most CUs idle — a single clip's conv_post ran 23 us on the generic kernel above, plus a mean_of_three launch in front of it.
+template <int K, bool SUM3, int POST_TT = 1024>
+__global__ __launch_bounds__(POST_TT / 4) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ x2,
                                                         const float* __restrict__ x3, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int Cin, int T,
                                                         int pre_act, int post_act, float slope, int n_tiles) {
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     constexpr int LEAD = (PAD + 3) / 4 * 4;            // staged columns before the tile, whole float4s
     constexpr int NV = (LEAD - PAD + 4 + K - 1 + 3) / 4;   // float4s covering a thread's window
     constexpr int PITCH = POST_TT + LEAD + 8;          // row pitch in floats (multiple of 4)
+    constexpr int NTHR = POST_TT / 4;                  // four consecutive outputs per thread
     __shared__ __attribute__((aligned(16))) float xs[NARROW_CH][PITCH];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
@@ -111,8 +113,8 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
         for (int r = 0; r < NARROW_CH; ++r) {
             const int ci = c0 + r;
 #pragma unroll
-            for (int i = 0; i < (PITCH + 255) / 256; ++i) {
-                const int col = tid + i * 256;
+            for (int i = 0; i < (PITCH + NTHR - 1) / NTHR; ++i) {
+                const int col = tid + i * NTHR;
                 const int t = t0 - LEAD + col;
                 const bool ok = ci < Cin && t >= 0 && t < T;
                 const unsigned off = ok ? (unsigned)(ci * T + t) * 4u : 0xFFFFFFFFu;
@@ -160,10 +162,10 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     }
 }
 
-// does launch_conv_narrow form a three-operand input mean itself for this call (the 1024-column conv_post kernel)?
+// does launch_conv_narrow form a three-operand input mean itself for this call (the conv_post kernels)?
 bool conv_narrow_sum3_ok(int B, int Cin, int T, int Cout, int k, int pad) {
-    const bool small = (long long)B * ((T + 1023) / 1024) < 2 * num_cus();
-    return !small && Cout == 1 && (k == 7 || k == 13) && 2 * pad == k - 1 && (long long)Cin * T < (1LL << 30);
+    (void)B;
+    return Cout == 1 && (k == 7 || k == 13) && 2 * pad == k - 1 && (long long)Cin * T < (1LL << 30);
 }
 
 fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int T,
@@ -177,18 +179,24 @@ fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, 
         set_error("conv_narrow: needs c_out <= %d and 'same' padding (c_out=%d k=%d pad=%d)", NARROW_MAXCO, Cout, k, pad);
         return FV_ERR_UNSUPPORTED;
     }
-    // 1024-column tiles unless they leave most CUs idle (single-clip latency): then 256-column tiles
+    // 1024-column tiles unless they leave most CUs idle (single-clip latency): then 256-column tiles, one wave each
     const bool small = (long long)B * ((T + 1023) / 1024) < 2 * num_cus();
-    if (!small && Cout == 1 && (k == 7 || k == 13) && (long long)Cin * T < (1LL << 30)) {
-        const int nt = (T + POST_TT - 1) / POST_TT;
-        if (k == 7 && x2)
-            hipLaunchKernelGGL((conv_post_kernel<7, true>), dim3(B * nt), dim3(256), 0, s, x, x2, x3, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
-        else if (k == 7)
-            hipLaunchKernelGGL((conv_post_kernel<7, false>), dim3(B * nt), dim3(256), 0, s, x, x, x, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
-        else if (x2)
-            hipLaunchKernelGGL((conv_post_kernel<13, true>), dim3(B * nt), dim3(256), 0, s, x, x2, x3, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
-        else
-            hipLaunchKernelGGL((conv_post_kernel<13, false>), dim3(B * nt), dim3(256), 0, s, x, x, x, w, bias, y, Cin, T, pre_act, post_act, slope, nt);
+    if (Cout == 1 && (k == 7 || k == 13) && (long long)Cin * T < (1LL << 30)) {
+#define FV_POST_LAUNCH(K, S3, TT)                                                                                                   \
+    hipLaunchKernelGGL((conv_post_kernel<K, S3, TT>), dim3(B * ((T + TT - 1) / TT)), dim3(TT / 4), 0, s, x, S3 ? x2 : x, S3 ? x3 : x, w, bias, \
+                       y, Cin, T, pre_act, post_act, slope, (T + TT - 1) / TT)
+        if (small) {
+            if (k == 7 && x2) FV_POST_LAUNCH(7, true, 256);
+            else if (k == 7) FV_POST_LAUNCH(7, false, 256);
+            else if (x2) FV_POST_LAUNCH(13, true, 256);
+            else FV_POST_LAUNCH(13, false, 256);
+        } else {
+            if (k == 7 && x2) FV_POST_LAUNCH(7, true, 1024);
+            else if (k == 7) FV_POST_LAUNCH(7, false, 1024);
+            else if (x2) FV_POST_LAUNCH(13, true, 1024);
+            else FV_POST_LAUNCH(13, false, 1024);
+        }
+#undef FV_POST_LAUNCH
         FV_HIP_CHECK(hipGetLastError());
         return FV_OK;
     }
