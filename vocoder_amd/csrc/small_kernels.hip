@@ -87,8 +87,6 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const float* __restric
 // bounds check supplies the zero padding.
 // SUM3: the input is ((x + x2) + x3) / 3 — the stack-mean of the last stage's three ResBlock branches, formed while staging instead
 // of by a mean_of_three_kernel pass over four tensors (the same additions in the same order: bit-identical).
-// POST_TT = 1024 columns per 256-thread workgroup; 256 columns per single-wave workgroup (round 4) for launches that would otherwise leave
-// most CUs idle — a single clip's conv_post ran 23 us on the generic kernel above, plus a mean_of_three launch in front of it.
 template <int K, bool SUM3, int POST_TT = 1024>
 __global__ __launch_bounds__(POST_TT / 4) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ x2,
                                                         const float* __restrict__ x3, const float* __restrict__ w,
@@ -162,6 +160,72 @@ __global__ __launch_bounds__(POST_TT / 4) void conv_post_kernel(const float* __r
     }
 }
 
+// Small launches (a single clip's conv_post: 44 032 outputs — 43 workgroups of conv_post_kernel, 23 us on the generic kernel): 128 outputs
+// per 256-thread workgroup, the whole 16-channel slab of the window requested at once (one memory round trip per slab), two threads
+// per output (8 channels each, partial sums added through LDS).  The per-output sum runs in another order than conv_post_kernel's, and
+// this kernel is chosen by launch size: batch-invariant mode (fv_set_batch_invariant) keeps conv_post_kernel.
+template <int K, bool SUM3>
+__global__ __launch_bounds__(256) void conv_post_small_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                              const float* __restrict__ x3, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y, int Cin, int T,
+                                                              int pre_act, int post_act, float slope, int n_tiles) {
+    constexpr int TT = 128, PAD = (K - 1) / 2, WIN = TT + K - 1, SLAB = 16;
+    constexpr int NE = (SLAB * WIN + 255) / 256;
+    __shared__ float xs[SLAB][WIN + 1];
+    __shared__ float part[TT];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
+    const int t0 = tile * TT;
+    const unsigned span = (unsigned)((long long)Cin * T * 4);
+    const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(x + (long long)b * Cin * T, span);
+    const __amdgpu_buffer_rsrc_t xrs2 = uniform_rsrc((SUM3 ? x2 : x) + (long long)b * Cin * T, span);
+    const __amdgpu_buffer_rsrc_t xrs3 = uniform_rsrc((SUM3 ? x3 : x) + (long long)b * Cin * T, span);
+    const int o = tid & (TT - 1), half = tid >> 7;
+    float acc = 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += SLAB) {
+        float v[NE], v2[SUM3 ? NE : 1], v3[SUM3 ? NE : 1];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + 256 * i;
+            const int r = e / WIN, col = e - r * WIN;
+            const int ci = c0 + r, t = t0 - PAD + col;
+            const unsigned off = (e < SLAB * WIN && ci < Cin && t >= 0 && t < T) ? (unsigned)(ci * T + t) * 4u : 0xFFFFFFFFu;
+            v[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
+            if constexpr (SUM3) {
+                v2[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs2, off, 0, 0));
+                v3[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs3, off, 0, 0));
+            }
+        }
+        __syncthreads();   // (the previous slab's readers are done)
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + 256 * i;
+            const int r = e / WIN, col = e - r * WIN;
+            float u = v[i];
+            if constexpr (SUM3) u = ((u + v2[i]) + v3[i]) * (1.0f / 3.0f);
+            u = pre_act == FV_ACT_SILU ? u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)) : act_apply(u, pre_act, slope);
+            if (e < SLAB * WIN) xs[r][col] = u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+            const int r = 8 * half + r8;
+            if (c0 + r < Cin) {
+                const float* wr = w + (long long)(c0 + r) * K;
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc = fmaf(wr[j], xs[r][o + j], acc);
+            }
+        }
+    }
+    if (half == 1) part[o] = acc;
+    __syncthreads();
+    if (half == 0) {
+        const int t = t0 + o;
+        const float r = act_apply(acc + part[o] + (bias ? bias[0] : 0.f), post_act, slope);
+        if (t < T) y[(long long)b * T + t] = r;
+    }
+}
+
 // does launch_conv_narrow form a three-operand input mean itself for this call (the conv_post kernels)?
 bool conv_narrow_sum3_ok(int B, int Cin, int T, int Cout, int k, int pad) {
     (void)B;
@@ -185,11 +249,15 @@ fv_status launch_conv_narrow(const float* x, const float* w, const float* bias, 
 #define FV_POST_LAUNCH(K, S3, TT)                                                                                                   \
     hipLaunchKernelGGL((conv_post_kernel<K, S3, TT>), dim3(B * ((T + TT - 1) / TT)), dim3(TT / 4), 0, s, x, S3 ? x2 : x, S3 ? x3 : x, w, bias, \
                        y, Cin, T, pre_act, post_act, slope, (T + TT - 1) / TT)
-        if (small) {
-            if (k == 7 && x2) FV_POST_LAUNCH(7, true, 256);
-            else if (k == 7) FV_POST_LAUNCH(7, false, 256);
-            else if (x2) FV_POST_LAUNCH(13, true, 256);
-            else FV_POST_LAUNCH(13, false, 256);
+        if (small && !cur_invariant()) {
+#define FV_POST_SMALL(K, S3)                                                                                                        \
+    hipLaunchKernelGGL((conv_post_small_kernel<K, S3>), dim3(B * ((T + 127) / 128)), dim3(256), 0, s, x, S3 ? x2 : x, S3 ? x3 : x, w, bias, y, \
+                       Cin, T, pre_act, post_act, slope, (T + 127) / 128)
+            if (k == 7 && x2) FV_POST_SMALL(7, true);
+            else if (k == 7) FV_POST_SMALL(7, false);
+            else if (x2) FV_POST_SMALL(13, true);
+            else FV_POST_SMALL(13, false);
+#undef FV_POST_SMALL
         } else {
             if (k == 7 && x2) FV_POST_LAUNCH(7, true, 1024);
             else if (k == 7) FV_POST_LAUNCH(7, false, 1024);
