@@ -31,6 +31,12 @@ def key_of(kernel_name: str, grid_threads: int):
     m = re.search(r"pair16_f16x3_kernel<(\d+), (\d+)>", kernel_name)
     if m:
         return f"pair_f16x3 k={m.group(1)} d={m.group(2)} C=16 grid={blocks}"
+    m = re.search(r"pair_wino(?:16|32)_kernel<(\d+), (\d+), (\d+),", kernel_name)   # (KS, DIL, C, chunk, ...)
+    if m:
+        return f"pair_wino k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={blocks}"
+    m = re.search(r"conv_wino_lat_kernel<(\d+), (\d+), (\d+), (\d+)>", kernel_name)      # (KS, DIL, NT, MT)
+    if m:
+        return f"conv_wino_lat k={m.group(1)} d={m.group(2)} tile={16 * int(m.group(4))}x{16 * int(m.group(3))}p grid={blocks}"
     m = re.search(r"resblock_pair16_kernel<(\d+), (\d+)>", kernel_name)
     if m:
         return f"resblock_pair k={m.group(1)} d={m.group(2)} C=16 grid={blocks}"
@@ -57,6 +63,12 @@ def bench_key(label: str):
     m = re.search(r"resblock_pair<k=(\d+) d=(\d+) C=(\d+)> grid=(\d+)", label)
     if m:
         return f"resblock_pair k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={m.group(4)}"
+    m = re.search(r"pair_wino<k=(\d+) d=(\d+) C=(\d+)> grid=(\d+)", label)
+    if m:   # (the launch's grid is rounded up to a multiple of the 8 XCDs: key_of sees the rounded count)
+        return f"pair_wino k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={(int(m.group(4)) + 7) // 8 * 8}"
+    m = re.search(r"conv_wino_lat<k=(\d+) d=(\d+) tile=(\w+)>.*grid=(\d+)", label)
+    if m:
+        return f"conv_wino_lat k={m.group(1)} d={m.group(2)} tile={m.group(3)} grid={m.group(4)}"
     return None
 
 

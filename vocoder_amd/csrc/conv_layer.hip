@@ -383,7 +383,7 @@ static int choose_gemm_pw(const ConvLayer& L, const ConvRun& r, long long tout) 
 // Row groups of the XCD partition (gemm_pw.hip).  An XCD reads 1 / PX of the weights and PX / 8 of the activation columns:
 // four row groups when the weights are the operand that does not fit (activations under ten times their size: the C -> 4C
 // layers, +2 ... 3 %), one (every XCD owns a column range and streams all weights) when the activations dominate (4C -> C:
-// four row groups measured -5 %).  tools/px_probe.sh.
+// four row groups measured -5 %).  tools/archive/px_probe.sh.
 static int choose_gemm_pw_xcd_rows(const ConvLayer& L, const ConvRun& r, long long tout, int cfg) {
     const int mt = cfg == GEMM_PW_32x64_W3 ? 1 : 2;
     const int mtiles = (L.M + 32 * mt - 1) / (32 * mt);
