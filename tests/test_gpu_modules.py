@@ -221,3 +221,29 @@ def test_linear_spectrogram_standalone_vs_reference_golden_and_oracle():
     y = m(torch.from_numpy(wave).cuda()[:, None, :]).cpu().numpy()
     ref = orc.linear_spectrogram(wave, 3072, 3072, 2048)
     assert y.shape == ref.shape == (2, 1537, 5) and np.abs(y - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_module_level_batch_invariance_switch():
+    """`gen.batch_invariant = True` / `gen.conv_algorithm` on a drop-in module (include/fishvoc.h fv_set_batch_invariant, fv_set_conv_algorithm):
+    a clip forwarded alone equals the same clip inside a batch bit for bit; the default stays within 2e-5."""
+    from vocoder_amd.modules.generators.hifigan import HiFiGANGenerator
+    cfg = dict(hop_length=64, upsample_rates=[4, 4, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4], resblock_kernel_sizes=[3, 7, 11],
+               resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=80, upsample_initial_channel=256, use_template=False,
+               pre_conv_kernel_size=7, post_conv_kernel_size=7)
+    sd = syn.hifigan_state_dict(cfg, seed=4)
+    gen = HiFiGANGenerator(**cfg)
+    gen.load_state_dict(_t(sd), strict=True)
+    gen = gen.eval().cuda()
+    mel = torch.from_numpy(syn.synthetic_mel(24, 80, 60, seed=6)).cuda()
+    y = gen(mel).clone()
+    y1 = gen(mel[7:8]).clone()
+    assert float((y1 - y[7:8]).abs().max()) <= 2e-5
+    with pytest.raises(ValueError):
+        gen.conv_algorithm = "fft"
+    for algo in ("auto", "direct", "winograd"):
+        gen.conv_algorithm = algo
+        gen.batch_invariant = True
+        yi = gen(mel).clone()
+        assert torch.equal(gen(mel[7:8]), yi[7:8]) and torch.equal(gen(mel[20:24]), yi[20:24]), algo
+        assert float((yi - y).abs().max()) <= 2e-5
+        gen.batch_invariant = False

@@ -17,6 +17,8 @@ class EngineModule(nn.Module):
         super().__init__()
         object.__setattr__(self, "_engine", None)
         object.__setattr__(self, "_precision", "f32")
+        object.__setattr__(self, "_conv_algorithm", "auto")
+        object.__setattr__(self, "_batch_invariant", False)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_engine())
 
     # -- subclasses implement -------------------------------------------------------------
@@ -37,6 +39,33 @@ class EngineModule(nn.Module):
             self.invalidate_engine()
         object.__setattr__(self, "_precision", value)
 
+    # -- which fp32 sums the conv layers form (include/fishvoc.h fv_conv_algo): "auto" (per launch, fastest; default), "direct", "winograd";
+    #    batch_invariant = True: kernel choices from the layer shape alone, a clip's output no longer depends on the batch it is part of ----
+    @property
+    def conv_algorithm(self) -> str:
+        return self.__dict__.get("_conv_algorithm", "auto")
+
+    @conv_algorithm.setter
+    def conv_algorithm(self, value: str) -> None:
+        from .. import _lib
+        if value not in _lib.CONV_ALGOS:
+            raise ValueError(f"conv_algorithm must be one of {sorted(_lib.CONV_ALGOS)}, got {value!r}")
+        object.__setattr__(self, "_conv_algorithm", value)
+        eng = self.__dict__.get("_engine")
+        if eng is not None:
+            eng.set_conv_algorithm(value)
+
+    @property
+    def batch_invariant(self) -> bool:
+        return bool(self.__dict__.get("_batch_invariant", False))
+
+    @batch_invariant.setter
+    def batch_invariant(self, value: bool) -> None:
+        object.__setattr__(self, "_batch_invariant", bool(value))
+        eng = self.__dict__.get("_engine")
+        if eng is not None:
+            eng.set_batch_invariant(bool(value))
+
     # -- engine cache ----------------------------------------------------------------------
     def invalidate_engine(self) -> None:
         eng = self.__dict__.get("_engine")
@@ -54,6 +83,10 @@ class EngineModule(nn.Module):
             self.invalidate_engine()
             with torch.cuda.device(device):
                 eng = self._make_engine({k: v for k, v in self.state_dict().items()})
+            if self.conv_algorithm != "auto":
+                eng.set_conv_algorithm(self.conv_algorithm)
+            if self.batch_invariant:
+                eng.set_batch_invariant(True)
             object.__setattr__(self, "_engine", eng)
         return eng
 
