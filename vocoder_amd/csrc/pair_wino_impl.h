@@ -486,13 +486,6 @@ __global__ __launch_bounds__(256, 2) void pair_wino32_kernel(const PairParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int lid = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);   // a clip's tiles on one XCD
     if (lid >= p.n_tiles * p.batch) return;
-#ifdef FV_X_PW_STAGGER
-    // experiment: the first round's workgroups of a CU start a third of a workgroup life apart (are the co-resident workgroups in lock-step?)
-    if (blockIdx.x < 768) {
-        const int k = (int)(blockIdx.x >> 8);
-        for (int i = 0; i < k * FV_X_PW_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
     const int tile = lid % p.n_tiles, b = lid / p.n_tiles;
     const int t0 = tile * G::TT;
     const int T = p.T;
