@@ -268,12 +268,16 @@ def cpu_baseline(cfg, sd, clips: int, frames: int) -> dict:
 # roofline
 # ------------------------------------------------------------------------------------------------------------------
 _WINO_PRODUCTS = {3: 4 / 6, 7: 10 / 14, 11: 16 / 22}   # matrix products per output pair: Winograd F(2,3) tap groups / direct sum
+_WINO4_PRODUCTS = {3: 6 / 12, 7: 16 / 28, 11: 26 / 44}  # ... per four outputs: F(4,3) tap groups (conv_wino4_impl.h) / direct sum
 
 
 def executed_flops(rec: dict) -> float:
     """MFMA flops a launch really issues: the algorithmic (direct-sum) count, except for the Winograd kernels (conv_wino_impl.h,
-    pair_wino_impl.h), which compute the same outputs with 4 / 10 / 16 products per output pair instead of 6 / 14 / 22."""
+    pair_wino_impl.h), which compute the same outputs with 4 / 10 / 16 products per output pair instead of 6 / 14 / 22, and the F(4,3) ones
+    (conv_wino4_impl.h): 6 / 16 / 26 per four outputs instead of 12 / 28 / 44."""
     k = rec["kernel"]
+    if k.startswith("conv_wino4<k="):
+        return rec["flops_per_launch"] * _WINO4_PRODUCTS[int(k[len("conv_wino4<k="):].split()[0])]
     for pre in ("conv_wino<k=", "pair_wino<k="):
         if k.startswith(pre):
             return rec["flops_per_launch"] * _WINO_PRODUCTS[int(k[len(pre):].split()[0])]

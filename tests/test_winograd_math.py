@@ -1,7 +1,7 @@
-"""CPU: the arithmetic conv_wino_impl.h implements, restated in numpy (float64) against the oracle's direct conv — Winograd F(2,3) tap
-groups {0,1,2}, {4,5,6}, {8,9,10} on the dilated pair lattice plus the single taps 3, 7 folded into accumulators m0 / m3, with the
-virtual-tap order, plane offsets and weight transform of the kernel / conv_layer_create.  Exact in real arithmetic: float64 agrees
-to ~1e-12, so an indexing or sign error in the scheme cannot hide behind a tolerance."""
+"""CPU: the arithmetic conv_wino_impl.h and conv_wino4_impl.h implement, restated in numpy (float64) against the oracle's direct conv — Winograd
+F(2,3) tap groups {0,1,2}, {4,5,6}, {8,9,10} on the dilated pair lattice plus the single taps 3, 7 folded into accumulators m0 / m3, and F(4,3)
+groups on the quad lattice split over two plane halves, each with the virtual-tap order, plane offsets and weight transform of the kernel /
+conv_layer_create.  Exact in real arithmetic: float64 agrees to ~1e-11, so an indexing or sign error in the scheme cannot hide behind a tolerance."""
 import numpy as np
 import pytest
 
@@ -71,3 +71,85 @@ def test_pair_lattice_winograd_equals_the_direct_conv(k, d, T):
 
 def test_products_per_output_pair():
     assert [len(virtual_taps(k)) for k in (3, 7, 11)] == [4, 10, 16]       # against 6 / 14 / 22 for the direct sum
+
+
+# ---- conv_wino4_impl.h: F(4,3) tap groups on the dilated quad lattice, two plane halves per 32-row tile ----
+def virtual_taps4(k, h):
+    """(plane name, shift in units of D, accumulator 0..3 of half h, weight source) per virtual tap in the kernel's order (Wino4Geom::off_of / acc_of).
+    Half 0 accumulates m0 m1 m2 S1, half 1 m5 m4 m3 S2."""
+    ng, ns = (k + 1) // 4, (k - 3) // 4
+    taps = [(("V", i if h == 0 else 5 - i), g, i, ("g", g, i if h == 0 else 5 - i)) for g in range(ng) for i in range(3)]
+    for s in range(ns):
+        if h == 0:
+            taps += [(("X", 3), s, 0, ("s", s)), (("X", 0), s + 1, 3, ("s", s))]
+        else:
+            taps += [(("X", 2), s + 1, 0, ("s", s)), (("X", 1), s + 1, 3, ("s", s))]
+    return taps
+
+
+def transformed_weights4(w, k, h):
+    out = []
+    for (_, _, _, src) in virtual_taps4(k, h):
+        if src[0] == "g":
+            g0, g1, g2 = (w[..., 4 * src[1] + i] for i in range(3))
+            out.append([g0 / 4, -(g0 + g1 + g2) / 6, -(g0 - g1 + g2) / 6, g0 / 24 + g1 / 12 + g2 / 6, g0 / 24 - g1 / 12 + g2 / 6, g2][src[2]])
+        else:
+            out.append(w[..., 4 * src[1] + 3])
+    return np.stack(out, axis=-1)
+
+
+def wino4_conv1d(x, w, d):
+    B, C, T = x.shape
+    k = w.shape[-1]
+    pad = (k - 1) * d // 2
+    nq = -(-T // (4 * d))                      # blocks of 4 D samples
+    NP = nq * d                                # quad columns
+    halo = d * ((k + 1) // 4 - 1) + d          # largest shift + the transform's neighbour
+    xp = np.zeros((B, C, 4 * d * (nq + 1) + 4 * halo + pad))
+    xp[..., pad:pad + T] = x                   # x'[tau] = x[tau - pad]
+    n = np.arange(NP + halo)
+    t0 = 4 * d * (n // d) + n % d
+    X = [xp[..., t0 + j * d] for j in range(4)]
+    x0, x1, x2, x3 = X
+    x4, x5 = np.roll(x0, -d, axis=-1), np.roll(x1, -d, axis=-1)
+    V = [4 * x0 - 5 * x2 + x4, (x4 - 4 * x2) + (x3 - 4 * x1), (x4 - 4 * x2) - (x3 - 4 * x1), (x4 - x2) + 2 * (x3 - x1), (x4 - x2) - 2 * (x3 - x1),
+         4 * x1 - 5 * x3 + x5]
+    planes = {("V", p): V[p] for p in range(6)} | {("X", j): X[j] for j in range(4)}
+    acc = []
+    for h in (0, 1):
+        ww = transformed_weights4(w, k, h)
+        m = [np.zeros((B, w.shape[0], NP)) for _ in range(4)]
+        for v, (pl, sh, a, _) in enumerate(virtual_taps4(k, h)):
+            m[a] += np.einsum("oc,bcn->bon", ww[..., v], planes[pl][..., sh * d:sh * d + NP])
+        acc.append(m)
+    # the kernel's output transform: what each half keeps (A in acc 0, B in acc 3) and what it passes to its partner (slots 0 / 1)
+    (m0, m1, m2, s1), (m5, m4, m3, s2) = acc
+    slot = [[m1 + m2, m1 - m2], [m3 + m4, 2 * (m3 - m4)]]
+    A0, B0 = m0 + (m1 + m2), s1 + (m1 - m2)
+    A1, B1 = m5 + 8 * (m3 - m4), s2 + 4 * (m3 + m4)
+    y = np.zeros((B, w.shape[0], 4 * d * nq))
+    tt = 4 * d * (np.arange(NP) // d) + np.arange(NP) % d
+    y[..., tt] = A0 + slot[1][0]
+    y[..., tt + d] = B0 + slot[1][1]
+    y[..., tt + 3 * d] = A1 + slot[0][1]
+    y[..., tt + 2 * d] = B1 + slot[0][0]
+    return y[..., :T]
+
+
+@pytest.mark.parametrize("k,d,T", [(3, 1, 17), (3, 5, 40), (7, 1, 64), (7, 3, 1), (7, 5, 333), (11, 1, 129), (11, 3, 50), (11, 5, 9), (11, 5, 700), (11, 1, 3)])
+def test_quad_lattice_winograd_equals_the_direct_conv(k, d, T):
+    rng = np.random.default_rng(k * 100 + d * 10 + T)
+    x = rng.normal(size=(2, 6, T)).astype(np.float32).astype(np.float64)
+    w = rng.normal(size=(5, 6, k)).astype(np.float32).astype(np.float64)
+    ref = orc.conv1d(x.astype(np.float32), w.astype(np.float32), None, dilation=d, padding=(k - 1) * d // 2)
+    y = wino4_conv1d(x, w, d)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())       # the float32 oracle's own rounding
+    xp = np.pad(x, ((0, 0), (0, 0), ((k - 1) * d // 2,) * 2))
+    direct = sum(np.einsum("oc,bct->bot", w[..., j], xp[..., j * d:j * d + T]) for j in range(k))
+    assert np.abs(y - direct).max() <= 1e-10   # (exact in real arithmetic; the transform constants reach 8)
+
+
+def test_products_per_output_quad():
+    assert [len(virtual_taps4(k, 0)) + len(virtual_taps4(k, 1)) for k in (3, 7, 11)] == [6, 16, 26]   # against 12 / 28 / 44 for the direct sum
+    assert all(len(virtual_taps4(k, 0)) == len(virtual_taps4(k, 1)) for k in (3, 7, 11))             # the two halves stay in step

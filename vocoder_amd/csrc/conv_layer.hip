@@ -173,6 +173,30 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
             FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw, pw.size() * sizeof(float)));
             FV_HIP_CHECK(hipMemcpy(L.d_wpw, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+        if (c_in >= 64 && c_out % 64 == 0) {
+            // Winograd F(4,3) tap groups (conv_wino4_impl.h): per (32-row tile, plane half h) nv4 = 3 ng + 2 ns virtual taps = Wino4Geom::off_of / acc_of:
+            // group g, i = 0..2 -> transformed weight U_p of taps 4g..4g+2 with p = i (h = 0: m0 m1 m2) or 5 - i (h = 1: m5 m4 m3); then per single tap
+            // 4s + 3 two plain copies (h = 0: into m0 and S1, h = 1: into m5 and S2).  Packed as 2 M rows: row (2 mt + h) * 32 + r = (row 32 mt + r, half h)
+            const int nv4 = 3 * ng + 2 * ns;
+            std::vector<float> w4((size_t)2 * c_out * c_in * nv4);
+            for (int co = 0; co < c_out; ++co)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int ci = 0; ci < c_in; ++ci) {
+                        const float* w = &wc[((size_t)co * c_in + ci) * k];
+                        float* o = &w4[((size_t)((co / 32 * 2 + hh) * 32 + co % 32) * c_in + ci) * nv4];
+                        for (int g = 0; g < ng; ++g) {
+                            const double g0 = w[4 * g], g1 = w[4 * g + 1], g2 = w[4 * g + 2];
+                            const double U[6] = {g0 / 4, -(g0 + g1 + g2) / 6, -(g0 - g1 + g2) / 6, g0 / 24 + g1 / 12 + g2 / 6, g0 / 24 - g1 / 12 + g2 / 6, g2};
+                            for (int i = 0; i < 3; ++i) o[3 * g + i] = (float)U[hh == 0 ? i : 5 - i];
+                        }
+                        for (int s2 = 0; s2 < ns; ++s2) o[3 * ng + 2 * s2] = o[3 * ng + 2 * s2 + 1] = w[4 * s2 + 3];
+                    }
+            L.nv4 = nv4;
+            std::vector<float> pw;
+            pack_conv_weights(w4, 2 * L.M, c_in, nv4, 2 * L.m_pad, L.nchunk, pw);
+            FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw4, pw.size() * sizeof(float)));
+            FV_HIP_CHECK(hipMemcpy(L.d_wpw4, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         if (c_in >= 32 && c_in % 32 == 0) {
             // conv_wino_lat_impl.h: fragment ((mt * nblk + blk) * nv / 2 + vp), one float4 per lane = A operands (row = lane & 15, k = lane >> 4) of
             // four 16x16x4 MFMAs: .{x,y} = virtual tap 2 vp, channel quads 0 / 1 of 8-channel block blk; .{z,w} = virtual tap 2 vp + 1
@@ -264,6 +288,8 @@ void conv_layer_destroy(ConvLayer& L) {
     L.d_wpw = nullptr;
     if (L.d_wpw16) (void)hipFree(L.d_wpw16);
     L.d_wpw16 = nullptr;
+    if (L.d_wpw4) (void)hipFree(L.d_wpw4);
+    L.d_wpw4 = nullptr;
     if (L.d_wpwl) (void)hipFree(L.d_wpwl);
     L.d_wpwl = nullptr;
     if (L.d_wph) (void)hipFree(L.d_wph);
@@ -586,6 +612,37 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         // against the direct kernels with this gate, a single clip (86 workgroups at C = 128) +17 % without it
         const long long min_blocks = knobs().wino_min_blocks >= 0 ? knobs().wino_min_blocks : num_cus() / 2;
         if (blocks >= min_blocks || algo == FV_CONV_ALGO_WINOGRAD || cur_invariant()) {
+            // F(4,3) tap groups where the layer has whole 64-row tiles (conv_wino4_impl.h): the same gate, so one algorithm per layer whatever
+            // the batch in batch-invariant mode
+            if (knobs().wino4 && L.d_wpw4 && (L.ks >= 7 || knobs().wino4 >= 2)) {   // (k = 3: 6 products per quad against 8, and F(2,3) measured faster)
+                const long long nq = (long long)L.dil * ((tout + 4 * L.dil - 1) / (4 * L.dil));   // quad columns: whole blocks of 4 D samples
+                // 64-row workgroups (four waves); the 128-row form (eight waves, half the staging per product) measured 10 - 25 % slower: LOG R4.14
+                const int rows = (knobs().wino4_rows == 128 && L.M % 128 == 0) ? 128 : 64;
+                p.wp = L.d_wpw4;
+                p.m_blks = L.M / rows;
+                p.n_tiles = (int)((nq + 31) / 32);
+                const int prof_idx = prof_begin(stream);
+                const bool launched = L.ks == 3 ? launch_conv_wino4_k3(p, rows, r.batch, stream)
+                                      : L.ks == 7 ? launch_conv_wino4_k7(p, rows, r.batch, stream) : launch_conv_wino4_k11(p, rows, r.batch, stream);
+                if (!launched) {
+                    set_error("conv_layer_run: no F(4,3) Winograd kernel for (k=%d, dilation=%d)", L.ks, L.dil);
+                    return FV_ERR_UNSUPPORTED;
+                }
+                static thread_local char name[96];
+                std::snprintf(name, sizeof(name), "conv_wino4<k=%d d=%d tile=%dx32q>", L.ks, L.dil, rows);
+                set_last_kernel(name);
+                if (prof_idx >= 0) {
+                    const double macs = (double)L.c_in * L.c_out * L.k * (double)tout * r.batch;   // ALGORITHMIC (direct-sum) MACs
+                    double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
+                    if (r.res) elems += (double)L.c_out * tout;
+                    if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
+                    char lbl[160];
+                    std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d grid=%lld", name, L.c_in, L.c_out, (long long)r.batch * p.m_blks * p.n_tiles);
+                    prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
+                }
+                FV_HIP_CHECK(hipGetLastError());
+                return FV_OK;
+            }
             p.wp = L.d_wpw;
             p.m_blks = (L.M + mb - 1) / mb;
             p.n_tiles = (int)((np + pairs - 1) / pairs);
