@@ -319,7 +319,7 @@ def roofline_from_profile(table: list[dict], repeats: int) -> dict:
         out = {"bound": "mfma", "achieved": ex_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ex_tf / peak_tf,
                "issued_flops_per_launch": ex, "algorithmic_tflops": tf, "algorithmic_speedup": top["flops_per_launch"] / ex}
         if ex != top["flops_per_launch"]:
-            out["note"] = ("achieved / frac count the matrix products the kernel issues (Winograd F(2,3) tap groups: issued_flops_per_launch); "
+            out["note"] = ("achieved / frac count the matrix products the kernel issues (Winograd F(2,3) / F(4,3) tap groups: issued_flops_per_launch); "
                            "algorithmic_tflops counts the layer's direct sum 2 C_in C_out k T B (flops_per_launch) over the same time and "
                            "may exceed the peak")
         if peak_tf != PEAK_MFMA_F32_TFLOPS:

@@ -139,10 +139,12 @@ def test_linearity_at_full_size():
     y1 = _run(w, None, x1, dilation=d, padding=pad)
     y2 = _run(w, None, x2, dilation=d, padding=pad)
     y12 = _run(w, None, (0.5 * x1 + x2).astype(np.float32), dilation=d, padding=pad)
-    assert np.abs(y12 - (0.5 * y1 + y2)).max() < 2e-5
+    # three rounded results meet in the difference; the launch takes the F(4,3) Winograd kernel (conv_wino4_impl.h: ~1.5 x a direct sum's round-off)
+    assert np.abs(y12 - (0.5 * y1 + y2)).max() <= 8e-6 * max(1.0, np.abs(y12).max())
     # spot-check a slab against the oracle
     ref = orc.conv1d(x1[:1, :, :700], w, None, dilation=d, padding=pad)
-    assert np.abs(y1[:1, :, :600] - ref[:, :, :600]).max() < 1e-5
+    _check(y1[:1, :, :600], ref[:, :, :600])
+    assert np.abs(y1[:1, :, :600] - ref[:, :, :600]).max() <= 4e-6 * np.abs(ref).max()
 
 
 def test_errors_are_reported():
