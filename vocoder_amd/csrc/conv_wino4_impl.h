@@ -62,7 +62,10 @@ struct Wino4Geom {
 };
 
 template <int KS, int DIL, int WM>
-__global__ __launch_bounds__(128 * WM, (WM == 2 ? 3 : 4)) void conv_wino4_kernel(const ConvParams p) {
+#ifndef FV_X_WINO4_OCC
+#define FV_X_WINO4_OCC 3
+#endif
+__global__ __launch_bounds__(128 * WM, (WM == 2 ? FV_X_WINO4_OCC : 4)) void conv_wino4_kernel(const ConvParams p) {
     using G = Wino4Geom<KS, DIL, WM>;
     constexpr int NV = G::NV, NBQ = G::NBQ, WR = G::WR, ROW = G::ROW, SUBS = G::SUBS, CH = G::CH, RPW = G::RPW, NE = G::NE;
     __shared__ float xs[G::XS_F];
@@ -176,7 +179,13 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 3 : 4)) void conv_wino4_kernel
     for (int d = 0; d < DA; ++d) aq[d] = load_a(d * 1024);
     for (int c = 0; c < nch; ++c) {
         float* xsb = xs + (c & 1) * (CH * ROW);
+#ifdef FV_X_WINO4_PRIO
+        __builtin_amdgcn_s_setprio(FV_X_WINO4_PRIO);
+#endif
         store_chunk(xsb);
+#ifdef FV_X_WINO4_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
         if (c < 12) FV_CV_STAMP(1 + c);
         if (c + 1 < nch) load_chunk(c + 1);
