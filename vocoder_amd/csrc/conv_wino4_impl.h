@@ -61,7 +61,9 @@ struct Wino4Geom {
     }
 };
 
-template <int KS, int DIL, int WM>
+// C64: the 64-channel layers (the narrowest that take this kernel: eight 8-channel blocks, M = 64 = one workgroup row) are their own instances — a constant trip
+// count for the chunk loop, and their own rows in rocprofv3's per-kernel statistics (the C = 128 stage's launches have the same grid at B = 32)
+template <int KS, int DIL, int WM, bool C64>
 #ifndef FV_X_WINO4_OCC
 #define FV_X_WINO4_OCC 3
 #endif
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? FV_X_WINO4_OCC : 4)) void conv
     constexpr int DA = FV_X_WINO4_DA;   // weight prefetch distance in virtual taps (4 MFMAs each)
     float4 aq[DA + 1];
     float b_cur[4], b_nxt[4];
-    const int nch = (p.nchunk_real + SUBS - 1) / SUBS;
+    const int nch = C64 ? 8 / SUBS : (p.nchunk_real + SUBS - 1) / SUBS;
     load_chunk(0);
 #pragma unroll
     for (int d = 0; d < DA; ++d) aq[d] = load_a(d * 1024);
@@ -318,22 +320,23 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? FV_X_WINO4_OCC : 4)) void conv
     FV_CV_STAMP(14);
 }
 
-template <int KS, int WM>
+template <int KS, int WM, bool C64>
 inline bool launch_wino4_kw(const ConvParams& p0, int batch, hipStream_t s) {
     ConvParams p = p0;
     p.wg_total = batch * p.m_blks * p.n_tiles;
     const int grid = (p.wg_total + 7) / 8 * 8;
     switch (p.dil) {
-        case 1: hipLaunchKernelGGL((conv_wino4_kernel<KS, 1, WM>), dim3(grid), dim3(128 * WM), 0, s, p); return true;
-        case 3: hipLaunchKernelGGL((conv_wino4_kernel<KS, 3, WM>), dim3(grid), dim3(128 * WM), 0, s, p); return true;
-        case 5: hipLaunchKernelGGL((conv_wino4_kernel<KS, 5, WM>), dim3(grid), dim3(128 * WM), 0, s, p); return true;
+        case 1: hipLaunchKernelGGL((conv_wino4_kernel<KS, 1, WM, C64>), dim3(grid), dim3(128 * WM), 0, s, p); return true;
+        case 3: hipLaunchKernelGGL((conv_wino4_kernel<KS, 3, WM, C64>), dim3(grid), dim3(128 * WM), 0, s, p); return true;
+        case 5: hipLaunchKernelGGL((conv_wino4_kernel<KS, 5, WM, C64>), dim3(grid), dim3(128 * WM), 0, s, p); return true;
         default: return false;
     }
 }
 
 template <int KS>
 inline bool launch_wino4_k(const ConvParams& p, int rows, int batch, hipStream_t s) {
-    return rows == 128 ? launch_wino4_kw<KS, 4>(p, batch, s) : launch_wino4_kw<KS, 2>(p, batch, s);
+    if (rows == 128) return launch_wino4_kw<KS, 4, false>(p, batch, s);
+    return (p.Cin == 64 && p.M == 64) ? launch_wino4_kw<KS, 2, true>(p, batch, s) : launch_wino4_kw<KS, 2, false>(p, batch, s);
 }
 
 }  // namespace fv
