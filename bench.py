@@ -269,13 +269,16 @@ def cpu_baseline(cfg, sd, clips: int, frames: int) -> dict:
 # ------------------------------------------------------------------------------------------------------------------
 _WINO_PRODUCTS = {3: 4 / 6, 7: 10 / 14, 11: 16 / 22}   # matrix products per output pair: Winograd F(2,3) tap groups / direct sum
 _WINO4_PRODUCTS = {3: 6 / 12, 7: 16 / 28, 11: 26 / 44}  # ... per four outputs: F(4,3) tap groups (conv_wino4_impl.h) / direct sum
+_WINO44_PRODUCTS = {7: 13 / 28, 11: 20 / 44}            # ... F(4,4) tap groups (conv_wino44_impl.h)
 
 
 def executed_flops(rec: dict) -> float:
     """MFMA flops a launch really issues: the algorithmic (direct-sum) count, except for the Winograd kernels (conv_wino_impl.h,
     pair_wino_impl.h), which compute the same outputs with 4 / 10 / 16 products per output pair instead of 6 / 14 / 22, and the F(4,3) ones
-    (conv_wino4_impl.h): 6 / 16 / 26 per four outputs instead of 12 / 28 / 44."""
+    (conv_wino4_impl.h): 6 / 16 / 26 per four outputs instead of 12 / 28 / 44; F(4,4) (conv_wino44_impl.h): 13 / 20 instead of 28 / 44."""
     k = rec["kernel"]
+    if k.startswith("conv_wino44<k="):
+        return rec["flops_per_launch"] * _WINO44_PRODUCTS[int(k[len("conv_wino44<k="):].split()[0])]
     if k.startswith("conv_wino4<k="):
         return rec["flops_per_launch"] * _WINO4_PRODUCTS[int(k[len("conv_wino4<k="):].split()[0])]
     for pre in ("conv_wino<k=", "pair_wino<k="):
@@ -319,7 +322,7 @@ def roofline_from_profile(table: list[dict], repeats: int) -> dict:
         out = {"bound": "mfma", "achieved": ex_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ex_tf / peak_tf,
                "issued_flops_per_launch": ex, "algorithmic_tflops": tf, "algorithmic_speedup": top["flops_per_launch"] / ex}
         if ex != top["flops_per_launch"]:
-            out["note"] = ("achieved / frac count the matrix products the kernel issues (Winograd F(2,3) / F(4,3) tap groups: issued_flops_per_launch); "
+            out["note"] = ("achieved / frac count the matrix products the kernel issues (Winograd F(2,3) / F(4,3) / F(4,4) tap groups: issued_flops_per_launch); "
                            "algorithmic_tflops counts the layer's direct sum 2 C_in C_out k T B (flops_per_launch) over the same time and "
                            "may exceed the peak")
         if peak_tf != PEAK_MFMA_F32_TFLOPS:

@@ -139,7 +139,7 @@ def test_linearity_at_full_size():
     y1 = _run(w, None, x1, dilation=d, padding=pad)
     y2 = _run(w, None, x2, dilation=d, padding=pad)
     y12 = _run(w, None, (0.5 * x1 + x2).astype(np.float32), dilation=d, padding=pad)
-    # three rounded results meet in the difference; the launch takes the F(4,3) Winograd kernel (conv_wino4_impl.h: ~1.5 x a direct sum's round-off)
+    # three rounded results meet in the difference; the launch takes the F(4,4) Winograd kernel (conv_wino44_impl.h: ~1.5 x a direct sum's round-off)
     assert np.abs(y12 - (0.5 * y1 + y2)).max() <= 8e-6 * max(1.0, np.abs(y12).max())
     # spot-check a slab against the oracle
     ref = orc.conv1d(x1[:1, :, :700], w, None, dilation=d, padding=pad)
@@ -355,6 +355,7 @@ def test_winograd_f43_conv_matches_oracle(rows, monkeypatch):
     from vocoder_amd import _lib
     monkeypatch.setenv("FV_WINO", "2")
     monkeypatch.setenv("FV_WINO4", "2")
+    monkeypatch.setenv("FV_WINO44", "0")
     monkeypatch.setenv("FV_WINO4_ROWS", str(rows))
     _lib.reload_env()
     try:
@@ -380,7 +381,47 @@ def test_winograd_f43_conv_matches_oracle(rows, monkeypatch):
     finally:
         monkeypatch.delenv("FV_WINO")
         monkeypatch.delenv("FV_WINO4")
+        monkeypatch.delenv("FV_WINO44")
         monkeypatch.delenv("FV_WINO4_ROWS")
+        _lib.reload_env()
+
+
+WINO44_CASES = [
+    # (C, k, dil, B, T): whole 64-row tiles, k = 7 / 11; ragged lengths (odd, below one block of 4 D samples, one sample), one to four row blocks, both chunk sizes
+    (128, 11, 1, 1, 517), (128, 7, 3, 2, 300), (256, 11, 5, 1, 97), (192, 7, 5, 1, 1000), (64, 11, 3, 2, 700), (64, 7, 1, 1, 129), (128, 11, 5, 1, 9),
+    (128, 7, 3, 1, 1), (64, 11, 1, 3, 4099), (64, 7, 5, 1, 19), (128, 11, 3, 1, 12), (128, 7, 1, 2, 127), (256, 7, 1, 1, 33), (320, 11, 1, 1, 70),
+]
+
+
+def test_winograd_f44_conv_matches_oracle(monkeypatch):
+    """conv_wino44_impl.h — Winograd F(4,4) tap groups on the dilated quad lattice (20 / 13 matrix products per four outputs; seven planes over two waves,
+    the ∞ plane shared by channel pairs) — through fv_conv_* with the kernel forced (FV_WINO=2): SiLU + bias + residual, the plain conv and a
+    leaky-ReLU conv with a SiLU behind it against the CPU oracle."""
+    from vocoder_amd import _lib
+    monkeypatch.setenv("FV_WINO", "2")
+    _lib.reload_env()
+    try:
+        for (c, k, d, B, T) in WINO44_CASES:
+            rng = np.random.default_rng(c * 1000 + k * 7 + d + T)
+            x = rng.normal(size=(B, c, T)).astype(np.float32)
+            w = (rng.normal(size=(c, c, k)) / np.sqrt(c * k)).astype(np.float32)
+            b = rng.normal(size=c).astype(np.float32)
+            pad = (k - 1) * d // 2
+            ref = orc.conv1d(orc.silu(x), w, b, dilation=d, padding=pad)
+            res = rng.normal(size=ref.shape).astype(np.float32)
+            y = _run(w, b, x, res, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
+            want = f"conv_wino44<k={k} d={d} tile=64x32q>"
+            assert _lib.last_kernel() == want, (_lib.last_kernel(), want)
+            _check(y, ref + res)
+            y2 = _run(w, None, x, None, dilation=d, padding=pad)
+            assert _lib.last_kernel() == want
+            _check(y2, orc.conv1d(x, w, None, dilation=d, padding=pad))
+            if T in (517, 300, 700, 19):
+                y3 = _run(w, b, x, None, dilation=d, padding=pad, pre_act=_lib.FV_ACT_LEAKY_RELU, post_act=_lib.FV_ACT_SILU, act_slope=0.1)
+                assert _lib.last_kernel() == want
+                _check(y3, orc.silu(orc.conv1d(np.where(x >= 0, x, np.float32(0.1) * x), w, b, dilation=d, padding=pad)))
+    finally:
+        monkeypatch.delenv("FV_WINO")
         _lib.reload_env()
 
 
@@ -434,7 +475,7 @@ def test_winograd_conv_offsets_beyond_2_gib(monkeypatch):
     conv = FusedConv(w, torch.zeros(C), dilation=d, padding=(k - 1) * d // 2, pre_act=_lib.FV_ACT_SILU)
     try:
         y1 = conv(x, res)
-        assert _lib.last_kernel().startswith("conv_wino4<"), _lib.last_kernel()
+        assert _lib.last_kernel().startswith("conv_wino44<"), _lib.last_kernel()
         monkeypatch.setenv("FV_WINO", "0")
         _lib.reload_env()
         y0 = conv(x, res)

@@ -963,7 +963,7 @@ def test_winograd_convs_against_the_direct_sums_and_the_oracle(model, monkeypatc
         y = eng(x).clone()
         torch.cuda.synchronize()
         prof = eng.profile(x, repeats=1)
-        wino = [r["kernel"] for r in prof if r["kernel"].startswith(("conv_wino<", "conv_wino4<"))]
+        wino = [r["kernel"] for r in prof if r["kernel"].startswith(("conv_wino<", "conv_wino4<", "conv_wino44<"))]
         assert any("k=11" in k for k in wino) and any("k=7" in k for k in wino), [r["kernel"] for r in prof][:20]
         assert torch.equal(eng(x), y)
         monkeypatch.setenv("FV_WINO", "0")
@@ -971,7 +971,7 @@ def test_winograd_convs_against_the_direct_sums_and_the_oracle(model, monkeypatc
         direct = mk()   # (a fresh engine: the first one replays its captured launch sequence for this input)
         y0 = direct(x).clone()
         torch.cuda.synchronize()
-        assert not any(r["kernel"].startswith(("conv_wino<", "conv_wino4<")) for r in direct.profile(x, repeats=1))
+        assert not any(r["kernel"].startswith(("conv_wino<", "conv_wino4<", "conv_wino44<")) for r in direct.profile(x, repeats=1))
         direct.close()
         d = float((y - y0).abs().max())
         assert 0 < d <= 2e-5, d
@@ -982,7 +982,7 @@ def test_winograd_convs_against_the_direct_sums_and_the_oracle(model, monkeypatc
             ref = ref_fn(sd, cfg, mel)
             err = np.abs(_fwd(eng, mel) - ref).max()
             assert err <= TOL, (b, t, err)
-        assert any(r["kernel"].startswith(("conv_wino<", "conv_wino4<")) for r in eng.profile(torch.from_numpy(syn.synthetic_mel(1, 80, 9, seed=1)).to(_dev()), repeats=1))
+        assert any(r["kernel"].startswith(("conv_wino<", "conv_wino4<", "conv_wino44<")) for r in eng.profile(torch.from_numpy(syn.synthetic_mel(1, 80, 9, seed=1)).to(_dev()), repeats=1))
         eng.close()
     finally:
         monkeypatch.delenv("FV_WINO", raising=False)
@@ -1027,6 +1027,6 @@ def test_ragged_shards_against_the_global_batch_and_the_batch_invariant_switch()
         assert torch.equal(y1, yi[17:18]), algo
         prof = [r["kernel"] for r in eng.profile(x[:4], repeats=1)]
         assert not any("splitK" in k for k in prof), prof[:10]
-        assert any(k.startswith(("conv_wino<", "conv_wino4<")) for k in prof) == (algo == "auto"), prof[:10]
+        assert any(k.startswith(("conv_wino<", "conv_wino4<", "conv_wino44<")) for k in prof) == (algo == "auto"), prof[:10]
         eng.set_batch_invariant(False)
     eng.close()

@@ -153,3 +153,74 @@ def test_quad_lattice_winograd_equals_the_direct_conv(k, d, T):
 def test_products_per_output_quad():
     assert [len(virtual_taps4(k, 0)) + len(virtual_taps4(k, 1)) for k in (3, 7, 11)] == [6, 16, 26]   # against 12 / 28 / 44 for the direct sum
     assert all(len(virtual_taps4(k, 0)) == len(virtual_taps4(k, 1)) for k in (3, 7, 11))             # the two halves stay in step
+
+
+# ---- conv_wino44_impl.h: F(4,4) tap groups (points ±1/2, ±1, ±2, ∞) on the quad lattice; seven planes over two halves, the ∞ plane shared by channel pairs ----
+G44 = np.array([[16 / 45, 8 / 45, 4 / 45, 2 / 45], [-16 / 45, 8 / 45, -4 / 45, 2 / 45], [-2 / 9, -2 / 9, -2 / 9, -2 / 9], [2 / 9, -2 / 9, 2 / 9, -2 / 9],
+                [1 / 45, 2 / 45, 4 / 45, 8 / 45], [-1 / 45, 2 / 45, -4 / 45, 8 / 45]])
+
+
+def wino44_conv1d(x, w, d):
+    B, C, T = x.shape
+    k = w.shape[-1]
+    assert C % 8 == 0
+    pad = (k - 1) * d // 2
+    ng = (k + 3) // 4
+    wz = np.zeros(w.shape[:2] + (4 * ng,))
+    wz[..., :k] = w                              # the taps past k are zero
+    nq = -(-T // (4 * d))
+    NP = nq * d
+    halo = d * (ng - 1) + d
+    xp = np.zeros((B, C, 4 * d * (nq + 1) + 4 * halo + pad))
+    xp[..., pad:pad + T] = x
+    n = np.arange(NP + halo)
+    t0 = 4 * d * (n // d) + n % d
+    x0, x1, x2, x3 = (xp[..., t0 + j * d] for j in range(4))
+    x4, x5, x6 = (np.roll(v, -d, axis=-1) for v in (x0, x1, x2))
+    V = []
+    for a, (c0, c1) in ((0.5, (4.0, -5.0)), (1.0, (1.0, -4.25)), (2.0, (0.25, -1.25))):
+        E, O = x4 + c1 * x2 + c0 * x0, x5 + c1 * x3 + c0 * x1
+        V += [O + a * E, O - a * E]
+    Vinf = (x6 - x0) + 5.25 * (x2 - x4)
+    pair_of_channel = (np.arange(C) % 8) // 2     # channel pair inside its 8-channel block: half h takes the ∞ plane's products of pairs 2 h, 2 h + 1
+    acc = []
+    for h in (0, 1):
+        m = [np.zeros((B, w.shape[0], NP)) for _ in range(4)]
+        for g in range(ng):
+            for i in range(3):
+                U = np.einsum("t,oct->oc", G44[3 * h + i], wz[..., 4 * g:4 * g + 4])
+                m[i] += np.einsum("oc,bcn->bon", U, V[3 * h + i][..., g * d:g * d + NP])
+            if g < ng - 1:                       # U(∞) = the group's fourth tap: absent (zero) in the last group of k = 7 / 11
+                mine = (pair_of_channel // 2) == h
+                m[3] += np.einsum("oc,bcn->bon", wz[..., 4 * g + 3][:, mine], Vinf[:, mine, g * d:g * d + NP])
+        acc.append(m)
+    (mh, mmh, m1, ia), (mm1, m2, mm2, ib) = acc
+    s, df = mh + mmh, mh - mmh                   # half 0 keeps y0, y1 and sends its parts of y2, y3
+    keepA, sendA = [s + m1, 0.5 * df + m1], [0.25 * s + m1, 0.125 * df + m1 + ia]
+    s, df = m2 + mm2, m2 - mm2                   # half 1 sends its parts of y0, y1 and keeps y2, y3
+    sendB, keepB = [s + mm1, 2 * df - mm1], [4 * s + mm1, 8 * df - mm1 + ib]
+    y = np.zeros((B, w.shape[0], 4 * d * nq))
+    tt = 4 * d * (np.arange(NP) // d) + np.arange(NP) % d
+    for j in range(2):
+        y[..., tt + j * d] = keepA[j] + sendB[j]
+        y[..., tt + (2 + j) * d] = keepB[j] + sendA[j]
+    return y[..., :T]
+
+
+@pytest.mark.parametrize("k,d,T", [(7, 1, 64), (7, 3, 1), (7, 5, 333), (11, 1, 129), (11, 3, 50), (11, 5, 9), (11, 5, 700), (11, 1, 3)])
+def test_quad_lattice_f44_winograd_equals_the_direct_conv(k, d, T):
+    rng = np.random.default_rng(k * 100 + d * 10 + T)
+    x = rng.normal(size=(2, 8, T)).astype(np.float32).astype(np.float64)
+    w = rng.normal(size=(5, 8, k)).astype(np.float32).astype(np.float64)
+    y = wino44_conv1d(x, w, d)
+    xp = np.pad(x, ((0, 0), (0, 0), ((k - 1) * d // 2,) * 2))
+    direct = sum(np.einsum("oc,bct->bot", w[..., j], xp[..., j * d:j * d + T]) for j in range(k))
+    assert y.shape == direct.shape
+    assert np.abs(y - direct).max() <= 1e-10   # exact in real arithmetic
+    ref = orc.conv1d(x.astype(np.float32), w.astype(np.float32), None, dilation=d, padding=(k - 1) * d // 2)
+    assert np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_products_per_output_quad_f44():
+    # per half and two channels: 3 planes x ng groups + the ∞ plane's (ng - 1) products on half of the channel pairs
+    assert [2 * (3 * ng + (ng - 1) / 2) for ng in (2, 3)] == [13, 20]     # k = 7, 11: against 16 / 26 for F(4,3) and 28 / 44 for the direct sum

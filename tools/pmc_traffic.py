@@ -17,6 +17,9 @@ def key_of(kernel_name: str, grid_threads: int):
     if m:
         ks, dil, wm, wn, nt = map(int, m.groups())
         return f"conv_wino k={ks} d={dil} tile={wm * 32}x{wn * nt * 32}p grid={blocks}"
+    m = re.search(r"conv_wino44_kernel<(\d+), (\d+), (true|false)>", kernel_name)   # (KS, DIL, C64): 64 rows x 32 quad columns, 256 threads
+    if m:
+        return f"conv_wino44 k={m.group(1)} d={m.group(2)} tile=64x32q{' c64' if m.group(3) == 'true' else ''} grid={blocks}"
     m = re.search(r"conv_wino4_kernel<(\d+), (\d+), (\d+), (true|false)>", kernel_name)   # (KS, DIL, WM, C64): tile = rows x QUAD columns, 128 WM threads
     if m:
         return f"conv_wino4 k={m.group(1)} d={m.group(2)} tile={32 * int(m.group(3))}x32q{' c64' if m.group(4) == 'true' else ''} grid={grid_threads // (128 * int(m.group(3)))}"
@@ -69,6 +72,10 @@ def bench_key(label: str):
     m = re.search(r"pair_wino<k=(\d+) d=(\d+) C=(\d+)> grid=(\d+)", label)
     if m:   # (the launch's grid is rounded up to a multiple of the 8 XCDs: key_of sees the rounded count)
         return f"pair_wino k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={(int(m.group(4)) + 7) // 8 * 8}"
+    m = re.search(r"conv_wino44<k=(\d+) d=(\d+) tile=(\w+)> cin=(\d+) cout=(\d+) grid=(\d+)", label)
+    if m:
+        c64 = " c64" if (m.group(4), m.group(5)) == ("64", "64") else ""
+        return f"conv_wino44 k={m.group(1)} d={m.group(2)} tile={m.group(3)}{c64} grid={(int(m.group(6)) + 7) // 8 * 8}"
     m = re.search(r"conv_wino4<k=(\d+) d=(\d+) tile=(\w+)> cin=(\d+) cout=(\d+) grid=(\d+)", label)
     if m:
         c64 = " c64" if (m.group(4), m.group(5)) == ("64", "64") else ""

@@ -173,6 +173,37 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
             FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw, pw.size() * sizeof(float)));
             FV_HIP_CHECK(hipMemcpy(L.d_wpw, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+        if (c_in >= 64 && c_in % 8 == 0 && c_out % 64 == 0 && k >= 7) {
+            // Winograd F(4,4) tap groups (conv_wino44_impl.h): groups of FOUR taps at 0, 4, 8 (taps past k are zero), points ±1/2, ±1, ±2, ∞.  Per (32-row tile,
+            // plane half h) and 8-channel block: 3 ng full fragments — group g, own plane i (h = 0: +1/2, -1/2, +1; h = 1: -1, +2, -2), the four channel pairs
+            // in .xyzw — then ONE fragment of the shared ∞ plane (U = the group's fourth tap): component j = group j / 2, channel pair 2 h + j % 2
+            static const double G44[6][4] = {{16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45}, {-16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45}, {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                             {2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},   {1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},    {-1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45}};
+            const int ng4 = (k + 3) / 4, nv44 = 3 * ng4 + 1, mts = c_out / 32;
+            auto tap = [&](int co, int ci, int j) -> double { return (j < k && ci < c_in) ? (double)wc[((size_t)co * c_in + ci) * k + j] : 0.0; };
+            std::vector<float> p44(((size_t)mts * 2 * L.nchunk * nv44 + 8) * 64 * 4, 0.f);
+            for (int mt = 0; mt < mts; ++mt)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int c = 0; c < L.nchunk; ++c)
+                        for (int v = 0; v < nv44; ++v)
+                            for (int l = 0; l < 64; ++l) {
+                                const int co = 32 * mt + (l & 31);
+                                float* dst = &p44[(((((size_t)mt * 2 + hh) * L.nchunk + c) * nv44 + v) * 64 + l) * 4];
+                                for (int j = 0; j < 4; ++j) {
+                                    if (v < 3 * ng4) {
+                                        const int g = v / 3, pl = 3 * hh + v % 3, ci = 8 * c + 2 * j + (l >> 5);
+                                        double u = 0.0;
+                                        for (int t = 0; t < 4; ++t) u += G44[pl][t] * tap(co, ci, 4 * g + t);
+                                        dst[j] = (float)u;
+                                    } else {
+                                        const int g = j / 2, ci = 8 * c + 2 * (2 * hh + j % 2) + (l >> 5);
+                                        dst[j] = g < ng4 - 1 ? (float)tap(co, ci, 4 * g + 3) : 0.f;
+                                    }
+                                }
+                            }
+            FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw44, p44.size() * sizeof(float)));
+            FV_HIP_CHECK(hipMemcpy(L.d_wpw44, p44.data(), p44.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         if (c_in >= 64 && c_out % 64 == 0) {
             // Winograd F(4,3) tap groups (conv_wino4_impl.h): per (32-row tile, plane half h) nv4 = 3 ng + 2 ns virtual taps = Wino4Geom::off_of / acc_of:
             // group g, i = 0..2 -> transformed weight U_p of taps 4g..4g+2 with p = i (h = 0: m0 m1 m2) or 5 - i (h = 1: m5 m4 m3); then per single tap
@@ -288,6 +319,8 @@ void conv_layer_destroy(ConvLayer& L) {
     L.d_wpw = nullptr;
     if (L.d_wpw16) (void)hipFree(L.d_wpw16);
     L.d_wpw16 = nullptr;
+    if (L.d_wpw44) (void)hipFree(L.d_wpw44);
+    L.d_wpw44 = nullptr;
     if (L.d_wpw4) (void)hipFree(L.d_wpw4);
     L.d_wpw4 = nullptr;
     if (L.d_wpwl) (void)hipFree(L.d_wpwl);
@@ -614,6 +647,33 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
         if (blocks >= min_blocks || algo == FV_CONV_ALGO_WINOGRAD || cur_invariant()) {
             // F(4,3) tap groups where the layer has whole 64-row tiles (conv_wino4_impl.h): the same gate, so one algorithm per layer whatever
             // the batch in batch-invariant mode
+            // F(4,4) tap groups for k = 7 / 11 on layers of whole 64-row tiles (conv_wino44_impl.h: 20 / 13 products per four outputs) — the same gate as below
+            if (knobs().wino4 && knobs().wino44 && L.d_wpw44 && knobs().wino4_rows != 128) {
+                const long long nq = (long long)L.dil * ((tout + 4 * L.dil - 1) / (4 * L.dil));   // quad columns: whole blocks of 4 D samples
+                p.wp = L.d_wpw44;
+                p.m_blks = L.M / 64;
+                p.n_tiles = (int)((nq + 31) / 32);
+                const int prof_idx = prof_begin(stream);
+                const bool launched = L.ks == 7 ? launch_conv_wino44_k7(p, r.batch, stream) : launch_conv_wino44_k11(p, r.batch, stream);
+                if (!launched) {
+                    set_error("conv_layer_run: no F(4,4) Winograd kernel for (k=%d, dilation=%d)", L.ks, L.dil);
+                    return FV_ERR_UNSUPPORTED;
+                }
+                static thread_local char name[96];
+                std::snprintf(name, sizeof(name), "conv_wino44<k=%d d=%d tile=64x32q>", L.ks, L.dil);
+                set_last_kernel(name);
+                if (prof_idx >= 0) {
+                    const double macs = (double)L.c_in * L.c_out * L.k * (double)tout * r.batch;   // ALGORITHMIC (direct-sum) MACs
+                    double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
+                    if (r.res) elems += (double)L.c_out * tout;
+                    if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
+                    char lbl[160];
+                    std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d grid=%lld", name, L.c_in, L.c_out, (long long)r.batch * p.m_blks * p.n_tiles);
+                    prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
+                }
+                FV_HIP_CHECK(hipGetLastError());
+                return FV_OK;
+            }
             if (knobs().wino4 && L.d_wpw4 && (L.ks >= 7 || knobs().wino4 >= 2)) {   // (k = 3: 6 products per quad against 8, and F(2,3) measured faster)
                 const long long nq = (long long)L.dil * ((tout + 4 * L.dil - 1) / (4 * L.dil));   // quad columns: whole blocks of 4 D samples
                 // 64-row workgroups (four waves); the 128-row form (eight waves, half the staging per product) measured 10 - 25 % slower: LOG R4.14

@@ -1,0 +1,332 @@
+// Dilated "same" Conv1d (k = 7 / 11: the ResBlock / AMPBlock convs, fish_vocoder/modules/generators/hifigan.py:101-108, bigvgan.py:235-245) as an
+// implicit GEMM over Winograd F(4,4) tap groups on the fp32 matrix cores: 20 / 13 matrix products per FOUR outputs and (c_out, c_in) against
+// F(4,3)'s 26 / 16 (conv_wino4_impl.h), F(2,3)'s 32 / 20 (conv_wino_impl.h) and the direct sum's 44 / 28.
+//
+// Quad lattice as in conv_wino4_impl.h: column n = q D + r <-> t0(n) = 4 D q + r, X_j[n] = x'[t0(n) + j D]; a shift by four taps = D columns.
+// Tap groups {0..3}, {4..7}, {8..11} (the taps past k are zero): FOUR taps per group, seven products per quad and group, no taps left between groups.
+// Interpolation points ±1/2, ±1, ±2, ∞ — symmetric, so the input transform splits into even / odd parts (x4 x5 x6 = X0 X1 X2[n + D]):
+//   E_a = x4 + c1 x2 + c0 x0,  O_a = x5 + c1 x3 + c0 x1,   V(±a) = O_a ± a E_a     (c0, c1) = (4, -5), (1, -17/4), (1/4, -5/4) for a = 1/2, 1, 2
+//   V(∞) = (x6 - x0) + 21/4 (x2 - x4)                                                          21 FMA-class instructions per lattice element
+// transformed weights (host, double): U(±a) = f_a (g0 ± a g1 + a² g2 ± a³ g3), f = 32/45, -2/9, 1/45 (the -a rows: -f for a = 1/2, 1 ... see
+// conv_layer.hip), U(∞) = g3; outputs y_j = sum_a a^j m(+a) + (-a)^j m(-a)  (+ m(∞) for j = 3).
+// U(∞) = g3 is ZERO for the last group of both kernel sizes (taps 11 / 7 do not exist): the ∞ plane costs NG - 1 products, 20 / 13 per quad in all.
+// Accuracy (tools/experiments/winograd_f44_precision.py): per layer 1.3 - 1.8e-6 of full scale against 1.3 - 1.5e-6 for F(4,3) — symmetric points
+// with |a| <= 2 keep the transform constants <= 8; the set 0, ±1, ±2, 3 would cost 5 x that.
+//
+// Work split: seven accumulator planes over two waves — half 0: m(1/2) m(-1/2) m(1), half 1: m(-1) m(2) m(-2), and m(∞) SHARED: each half
+// accumulates it over two of every four channel pairs (its MFMAs for that plane use k-pairs 2h, 2h + 1 of an 8-channel block); 64 accumulator
+// registers and 10 / 6.5 products per two channels for each half.  LDS row of a channel: V(1/2) V(-1/2) V(1) | V(-1) V(2) V(-2) | V(∞) | X0 X1 X2
+// (the raw phases are only the transform's scratch).  Output transform: half 0 keeps y[t0], y[t0 + D], half 1 y[t0 + 2D], y[t0 + 3D]; each passes
+// its partial sums of the partner's two outputs through the free chunk buffers.
+#pragma once
+#include "conv_mfma_impl.h"
+
+namespace fv {
+
+template <int KS, int DIL>
+struct Wino44Geom {
+    static constexpr int NG = (KS + 3) / 4;            // F(4,4) groups at taps 0, 4, 8
+    static constexpr int NSH = NG - 1;                 // groups whose fourth tap exists: products of the shared ∞ plane
+    static constexpr int NV = 3 * NG + 1;              // weight fragments per 8-channel sub-chunk and half: 3 NG full virtual taps + one shared-plane fragment
+    static constexpr int NBQ = 32;                     // quad columns per workgroup
+    static constexpr int WD = NBQ + DIL * (NG - 1);    // columns of a transformed plane
+    static constexpr int WR = WD + DIL;                // columns of X0..X2 (the transform reads column n + D)
+    static constexpr int ROW = 10 * WR;                // floats per channel row
+    static constexpr int V_INF = 6 * WR, X_OFF = 7 * WR;
+    static constexpr int HALF_G = 3 * WR;              // half 1's own planes
+#ifndef FV_X_WINO44_LDS
+#define FV_X_WINO44_LDS (52 * 1024)   // three workgroups per CU: 53.8 KB (k = 7, D = 5 with 16-channel chunks) measured as two
+#endif
+    static constexpr int subs_fit(int s) { return (s > 1 && 2 * kChunk * s * ROW * 4 + 64 > FV_X_WINO44_LDS) ? subs_fit(s / 2) : s; }
+    static constexpr int SUBS = subs_fit(2);
+    static constexpr int CH = kChunk * SUBS;
+    static constexpr int RPW = CH / 4;                 // channel rows staged by one wave
+    static constexpr int NE = (RPW * WR + 63) / 64;    // lattice elements (four samples each) per lane and chunk
+    static constexpr int XS_F = 2 * CH * ROW + 8 > 8192 ? 2 * CH * ROW + 8 : 8192;   // (the epilogue's exchange: 4 waves x 2 x 16 x 64 floats)
+    // step v of a sub-chunk: v < 3 NG: group v / 3, own plane v % 3, four MFMAs (channel pairs 0..3) into accumulator v % 3;
+    // v == 3 NG: the shared plane: MFMA j -> group j / 2, channel pair 2 h + j % 2, accumulator 3 (2 NSH MFMAs)
+    static constexpr bool shared_of(int v) { return v == 3 * NG; }
+    static constexpr int n_mfma(int v) { return shared_of(v) ? 2 * NSH : 4; }
+    static constexpr int acc_of(int v) { return shared_of(v) ? 3 : v % 3; }
+    static constexpr int off_of(int v, int j) {        // LDS float offset of MFMA j's operand relative to the sub-chunk and the lane base
+        if (!shared_of(v)) return 2 * j * ROW + (v % 3) * WR + DIL * (v / 3);
+        return 2 * (j % 2) * ROW + V_INF + DIL * (j / 2);
+    }
+};
+
+template <int KS, int DIL, bool C64>
+__global__ __launch_bounds__(256, 3) void conv_wino44_kernel(const ConvParams p) {
+    using G = Wino44Geom<KS, DIL>;
+    constexpr int NV = G::NV, NBQ = G::NBQ, WR = G::WR, ROW = G::ROW, SUBS = G::SUBS, CH = G::CH, RPW = G::RPW, NE = G::NE;
+    __shared__ float xs[G::XS_F];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, h = wave & 1;
+    // workgroup b runs on XCD b % 8: neighbouring tiles of a clip behind one L2 (conv_wino_impl.h)
+    int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (bid >= p.wg_total) return;
+    const int n_tile = bid % p.n_tiles;
+    bid /= p.n_tiles;
+    const int m_blk = bid % p.m_blks;
+    const int b = bid / p.m_blks;
+    const int n0 = n_tile * NBQ;
+    const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
+
+    FV_CV_STAMP(0);
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    // ---- staging plan (conv_wino4_impl.h): this wave owns channel rows wave * RPW .. + RPW - 1 of every chunk; lane element i = quad column
+    // (lane + 64 i) % WR of row (lane + 64 i) / WR; byte offsets relative to the chunk's first row, 0xFFFFFFFF outside [0, Tin) ----
+    unsigned vo[NE][4];
+    int lo[NE];               // LDS float offset of (row, column) inside the chunk buffer
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        int e = lane + 64 * i;
+        e = e < RPW * WR ? e : RPW * WR - 1;
+        const int rr = e / WR, c = e - rr * WR;
+        const int n = n0 + c;
+        const int q = n / DIL;
+        const int t0 = 4 * DIL * q + (n - q * DIL) - p.pad_l;
+        const int row = wave * RPW + rr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + j * DIL;
+            vo[i][j] = (t >= 0 && t < p.Tin) ? (unsigned)(row * p.Tin + t) * 4u : 0xFFFFFFFFu;
+        }
+        lo[i] = row * ROW + c;
+    }
+    float sx[4 * NE];   // [j * NE + i]
+    auto load_chunk = [&](int c) {
+        const int cbase = c * CH;
+        const long long span = p.x_bstride - (long long)cbase * p.Tin;
+        const long long rows = (long long)(p.Cin - cbase) * p.Tin;
+        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)((rows < span ? rows : span) * 4));
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sx[j * NE + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, vo[i][j], 0, 0));
+    };
+    auto store_chunk = [&](float* dst) {
+        act_apply_all(sx, p.pre_act, p.slope);   // act(0) == 0 keeps the zero padding
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dst[lo[i] + G::X_OFF + j * WR] = sx[j * NE + i];
+        // the neighbours (column + D of the same row) were written by this wave: its LDS operations execute in order, the fence
+        // only keeps the compiler from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float x4[NE], x5[NE], x6[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            x4[i] = dst[lo[i] + G::X_OFF + DIL];
+            x5[i] = dst[lo[i] + G::X_OFF + WR + DIL];
+            x6[i] = dst[lo[i] + G::X_OFF + 2 * WR + DIL];
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const float x0 = sx[i], x1 = sx[NE + i], x2 = sx[2 * NE + i], x3 = sx[3 * NE + i];
+            const float eh = fmaf(4.0f, x0, fmaf(-5.0f, x2, x4[i])), oh = fmaf(4.0f, x1, fmaf(-5.0f, x3, x5[i]));          // a = 1/2
+            const float e1 = fmaf(-4.25f, x2, x4[i]) + x0, o1 = fmaf(-4.25f, x3, x5[i]) + x1;                                // a = 1
+            const float e2 = fmaf(0.25f, x0, fmaf(-1.25f, x2, x4[i])), o2 = fmaf(0.25f, x1, fmaf(-1.25f, x3, x5[i]));        // a = 2
+            dst[lo[i]] = fmaf(0.5f, eh, oh);
+            dst[lo[i] + WR] = fmaf(-0.5f, eh, oh);
+            dst[lo[i] + 2 * WR] = o1 + e1;
+            dst[lo[i] + 3 * WR] = o1 - e1;
+            dst[lo[i] + 4 * WR] = fmaf(2.0f, e2, o2);
+            dst[lo[i] + 5 * WR] = fmaf(-2.0f, e2, o2);
+            dst[lo[i] + G::V_INF] = fmaf(5.25f, x2 - x4[i], x6[i] - x0);
+        }
+    };
+
+    const int mt0 = m_blk * 2 + wm;   // 32-row tile
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+    const int wvoff = lane * 16;
+    const int wbase = __builtin_amdgcn_readfirstlane((mt0 * 2 + h) * (p.nchunk * NV * 1024));   // bytes per (m-tile, half): nchunk * NV fragments of 1 KiB
+    auto load_a = [&](int goff_b) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wbase + goff_b, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    const int b_lane_g = (lane >> 5) * ROW + (lane & 31) + h * G::HALF_G;       // own planes
+    const int b_lane_s = (lane >> 5) * ROW + (lane & 31) + h * (4 * ROW);       // shared plane: this half's channel pairs 2 h, 2 h + 1
+
+    constexpr int STEPS = SUBS * NV;
+#ifndef FV_X_WINO44_DA
+#define FV_X_WINO44_DA 3
+#endif
+    constexpr int DA = FV_X_WINO44_DA;   // weight prefetch distance in fragments
+    float4 aq[DA + 1];
+    float b_cur[4], b_nxt[4];
+    const int nch = C64 ? 8 / SUBS : (p.nchunk_real + SUBS - 1) / SUBS;
+    load_chunk(0);
+#pragma unroll
+    for (int d = 0; d < DA; ++d) aq[d] = load_a(d * 1024);
+    for (int c = 0; c < nch; ++c) {
+        float* xsb = xs + (c & 1) * (CH * ROW);
+        store_chunk(xsb);
+        __syncthreads();
+        if (c < 12) FV_CV_STAMP(1 + c);
+        if (c + 1 < nch) load_chunk(c + 1);
+        const int gchunk_b = __builtin_amdgcn_readfirstlane((c * STEPS + DA) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_cur[j] = xsb[b_lane_g + G::off_of(0, j)];
+        static_for<STEPS>([&](auto st_c) __attribute__((always_inline)) {
+            constexpr int st = decltype(st_c)::value;
+            constexpr int v = st % NV;
+            constexpr int A = G::acc_of(v), NM = G::n_mfma(v);
+            constexpr int sub_n = (st + 1) / NV, v_n = (st + 1) % NV;
+            constexpr int NM_n = st + 1 < STEPS ? G::n_mfma(v_n) : 0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (m < NM) {
+                    const float av = m == 0 ? aq[0].x : m == 1 ? aq[0].y : m == 2 ? aq[0].z : aq[0].w;
+                    acc[A] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[m], acc[A], 0, 0, 0);
+                }
+                // one weight fragment (DA fragments ahead) and the next step's operands, spread over this step's MFMAs
+                if (m == 0) aq[DA] = load_a(gchunk_b + st * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < NM_n && (j * NM) / 4 == m && m < NM)
+                        b_nxt[j] = xsb[(G::shared_of(v_n) ? b_lane_s : b_lane_g) + sub_n * kChunk * ROW + G::off_of(v_n, j)];
+                if (m < NM) __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < DA; ++d) aq[d] = aq[d + 1];
+            if constexpr (st + 1 < STEPS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];
+            }
+        });
+    }
+
+    FV_CV_STAMP(13);
+    // ---- output transform.  y_j = sum over points a^j m(a) (+ m(∞) for j = 3); each half forms the partial sums of its planes for all four
+    // outputs, keeps two of them in place (A in acc 0, B in acc 1) and passes the other two to its partner:
+    //   half 0 (m(1/2) m(-1/2) m(1), its part of m(∞)):  s = m(1/2) + m(-1/2), d = m(1/2) - m(-1/2)
+    //       keeps  y0: s + m1,  y1: d/2 + m1        sends  y2: s/4 + m1,  y3: d/8 + m1 + m(∞)
+    //   half 1 (m(-1) m(2) m(-2), its part of m(∞)):      s = m(2) + m(-2),     d = m(2) - m(-2)
+    //       sends  y0: s + m(-1),  y1: 2 d - m(-1)  keeps  y2: 4 s + m(-1),  y3: 8 d - m(-1) + m(∞) ----
+    __syncthreads();   // every wave is past its last operand read: the chunk buffers become the exchange area
+    {
+        float* ex = xs + wave * 2048 + lane;
+        if (h == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sm = acc[0][r] + acc[1][r], df = acc[0][r] - acc[1][r], m1 = acc[2][r];
+                ex[r * 64] = fmaf(0.25f, sm, m1);
+                ex[1024 + r * 64] = fmaf(0.125f, df, m1) + acc[3][r];
+                acc[0][r] = sm + m1;
+                acc[1][r] = fmaf(0.5f, df, m1);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sm = acc[1][r] + acc[2][r], df = acc[1][r] - acc[2][r], mm = acc[0][r];
+                ex[r * 64] = sm + mm;
+                ex[1024 + r * 64] = fmaf(2.0f, df, -mm);
+                acc[0][r] = fmaf(4.0f, sm, mm);
+                acc[1][r] = fmaf(8.0f, df, -mm) + acc[3][r];
+            }
+        }
+    }
+    __syncthreads();
+    const float* pa = xs + (wave ^ 1) * 2048 + lane;          // partner's partial sum of this half's first output
+    const float* pb = xs + (wave ^ 1) * 2048 + 1024 + lane;   // ... and second
+    if (mt0 * 32 >= p.M) return;
+    const int n = n0 + (lane & 31);
+    const int q = n / DIL;
+    const int ta = 4 * DIL * q + (n - q * DIL) + 2 * h * DIL, tb = ta + DIL;   // half 0: t0, t0 + D; half 1: t0 + 2D, t0 + 3D
+    // The common case — whole 32-row tiles, bias [+ residual] [+ post-activation], plain store — without per-element offset registers
+    // (conv_wino_impl.h): all bias and residual operands are requested before the partner's planes are read back.
+    if (p.M % 32 == 0 && p.gamma == nullptr && p.out_mode == OUT_SET && p.acc_scale == 1.0f) {
+        const unsigned span = (unsigned)(p.y_bstride * 4);
+        const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
+        const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
+        const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(p.bias, (unsigned)(p.M * 4));
+        const int mrow = 4 * (lane >> 5);                                   // lane part of the row; + mt0 * 32 + (r & 3) + 8 * (r >> 2) in SGPRs
+        const unsigned va = ta < p.N ? (unsigned)(mrow * p.N + ta) * 4u : 0xFFFFFFFFu;
+        const unsigned vb = tb < p.N ? (unsigned)(mrow * p.N + tb) * 4u : 0xFFFFFFFFu;
+        float bias[16], ra[16], rb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            bias[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, mrow * 4, (mt0 * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+        if (p.res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);   // (< 4 GiB per item: conv_layer_run)
+                ra[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, va, so, 0));
+                rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, vb, so, 0));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ra[r] = rb[r] = 0.f;
+        }
+        const bool has_res = p.res != nullptr;
+        float oa[16], ob[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float y0 = acc[0][r] + pa[r * 64];
+            const float y1 = acc[1][r] + pb[r * 64];
+            oa[r] = fmaf(y0, 1.0f, bias[r]);
+            ob[r] = fmaf(y1, 1.0f, bias[r]);
+            if (has_res) {
+                oa[r] += ra[r];
+                ob[r] += rb[r];
+            }
+        }
+        act_apply_all(oa, p.post_act, p.slope);   // (c1 of a ResBlock pair carries the SiLU in front of c2: hifigan.py:104-106)
+        act_apply_all(ob, p.post_act, p.slope);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int so = (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oa[r]), yrs, va, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ob[r]), yrs, vb, so, 0);
+        }
+#ifdef FV_X_CONV_TS
+        __builtin_amdgcn_s_waitcnt(0);
+#endif
+        FV_CV_STAMP(14);
+        return;
+    }
+    f32x16 out[1][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        out[0][0][r] = acc[0][r] + pa[r * 64];
+        out[0][1][r] = acc[1][r] + pb[r * 64];
+    }
+    const int coff[2] = {ta, tb};
+    const bool cok[2] = {ta < p.N, tb < p.N};
+    conv_epilogue_cols<1, 2>(p, out, b, mt0, coff, cok, lane);
+#ifdef FV_X_CONV_TS
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    FV_CV_STAMP(14);
+}
+
+template <int KS, bool C64>
+inline bool launch_wino44_kc(const ConvParams& p0, int batch, hipStream_t s) {
+    ConvParams p = p0;
+    p.wg_total = batch * p.m_blks * p.n_tiles;
+    const int grid = (p.wg_total + 7) / 8 * 8;
+    switch (p.dil) {
+        case 1: hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, C64>), dim3(grid), dim3(256), 0, s, p); return true;
+        case 3: hipLaunchKernelGGL((conv_wino44_kernel<KS, 3, C64>), dim3(grid), dim3(256), 0, s, p); return true;
+        case 5: hipLaunchKernelGGL((conv_wino44_kernel<KS, 5, C64>), dim3(grid), dim3(256), 0, s, p); return true;
+        default: return false;
+    }
+}
+
+template <int KS>
+inline bool launch_wino44_k(const ConvParams& p, int batch, hipStream_t s) {
+    return (p.Cin == 64 && p.M == 64) ? launch_wino44_kc<KS, true>(p, batch, s) : launch_wino44_kc<KS, false>(p, batch, s);
+}
+
+}  // namespace fv

@@ -30,6 +30,7 @@ struct Knobs {
     int wino_min_m = 32;  // FV_WINO_MIN_M: narrowest layer (output rows) that takes it
     int wino_cfg = -1;    // FV_WINO_CFG: forced tile (WinoCfg 0 ... 2), -1 = by shape
     int wino_min_blocks = -1;   // FV_WINO_MIN_BLOCKS: fewest workgroups of a launch that takes it, -1 = default
+    int wino44 = 1;       // FV_WINO44: 1 = F(4,4) tap groups (conv_wino44_impl.h) for k = 7 / 11 where FV_WINO4 would take F(4,3), 0 = F(4,3) there
     int wino4_rows = 0;   // FV_WINO4_ROWS: 128 = the eight-wave F(4,3) workgroups (experiments), otherwise 64 rows
     int wino4 = 1;        // FV_WINO4: 1 = F(4,3) tap groups (conv_wino4_impl.h) for k = 7 / 11 where the Winograd path is taken and the layer has whole 64-row tiles, 2 = for k = 3 too, 0 = F(2,3) everywhere
     int wino_lat = 1;     // FV_WINO_LAT: 0 = launches below the Winograd gate run the direct split-K kernels, 1 = the Winograd latency kernel
@@ -156,6 +157,7 @@ struct ConvLayer {
     float4* d_wpw = nullptr;   // Winograd-transformed weights in the same fragment order, nv virtual taps (conv_wino_impl.h); optional
     int nv = 0;
     float4* d_wp16 = nullptr;  // 16x16x4-fragment layout, only for 16 -> 16 channel Conv1d (fused pair kernel)
+    float4* d_wpw44 = nullptr; // Winograd F(4,4)-transformed weights (conv_wino44_impl.h): (32-row tile, plane half) x chunk x (3 ng + 1) fragments; optional
     float4* d_wpw4 = nullptr;  // Winograd F(4,3)-transformed weights (conv_wino4_impl.h): (32-row tile, plane half) x chunk x nv4 fragments; optional
     int nv4 = 0;
     float4* d_wpwl = nullptr;  // Winograd-transformed weights of the latency kernel: 16-row tiles, 8-channel blocks, tap pairs (conv_wino_lat_impl.h); optional
@@ -283,6 +285,9 @@ bool launch_conv_wino_k11(const ConvParams& p, int cfg, int batch, hipStream_t s
 bool launch_conv_wino4_k3(const ConvParams& p, int rows, int batch, hipStream_t s);
 bool launch_conv_wino4_k7(const ConvParams& p, int rows, int batch, hipStream_t s);
 bool launch_conv_wino4_k11(const ConvParams& p, int rows, int batch, hipStream_t s);
+// conv_wino44_impl.h: F(4,4) tap groups, 64 rows x 32 quad columns per workgroup; p.wp = the layer's d_wpw44, p.m_blks = M / 64, p.n_tiles over quad columns
+bool launch_conv_wino44_k7(const ConvParams& p, int batch, hipStream_t s);
+bool launch_conv_wino44_k11(const ConvParams& p, int batch, hipStream_t s);
 // conv_wino_lat_impl.h: latency variant (16 rows x 16 nt pairs per workgroup, K split over the four waves); p.wp = the layer's d_wpwl,
 // p.m_blks = C / 16, p.n_tiles in units of 16 nt pair columns
 bool launch_conv_wino_lat_k3(const ConvParams& p, int nt, int batch, hipStream_t s);
