@@ -45,7 +45,7 @@ bash tools/pmc_clock.sh 32 > $O/clock_per_kernel.txt 2>&1
 bash tools/power_trace.sh 6 $O/power_trace.txt > /dev/null 2>&1; rm -f $O/power_trace.txt.idle $O/power_trace.txt.samples
 # matrix-pipe / VALU / LDS counters: the dominant conv, the fused pairs (direct-sum and Winograd forms), BigVGAN's anti-aliased snake
 bash tools/pmc_conv.sh 128 5504 11 1 > $O/conv_pmc.txt 2>&1
-{ echo "== F(2,3) form of the same layer (FV_WINO4=0)"; FV_WINO4=0 bash tools/pmc_conv.sh 128 5504 11 1; } >> $O/conv_pmc.txt 2>&1
+{ echo "== F(4,3) form of the same layer (FV_WINO44=0)"; FV_WINO44=0 bash tools/pmc_conv.sh 128 5504 11 1; echo "== F(2,3) form of the same layer (FV_WINO4=0)"; FV_WINO4=0 bash tools/pmc_conv.sh 128 5504 11 1; } >> $O/conv_pmc.txt 2>&1
 timeout 600 python tools/probe_wino4.py 20 > $O/wino4_vs_wino.txt 2>&1
 for s in "16 44032 3 1" "16 44032 11 1" "32 22016 3 1" "32 22016 11 1" "64 11008 3 1" "128 5504 3 1"; do
   echo "== C T k d = $s (Winograd pair)" >> $O/pair_pmc.txt; bash tools/pmc_pair.sh $s >> $O/pair_pmc.txt 2>&1
