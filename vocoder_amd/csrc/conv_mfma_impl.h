@@ -89,7 +89,8 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, f32x16 (
     // two is small (-0.2 %): tools/probe_conv_timeline.py shows a 128 x 128 workgroup ~20 us in this function (12 us without a
     // residual), but that is bandwidth, not latency — every CU's workgroups start together, so the whole chip reads its
     // residual tiles and stores its outputs (2 x 49 MB at B = 32) in the same few microseconds, twice per launch.
-    // (conv_wino_impl.h passes RG = 4: its accumulator planes are dead by then, the whole m-tile's operands fit)
+    // (the Winograd kernels — conv_wino_impl.h, conv_wino4_impl.h, conv_wino44_impl.h — come here with the default RG = 2 for their general epilogue; their common case
+    //  is a leaner path of their own that requests the whole m-tile's operands at once: their accumulator planes are dead by then)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll

@@ -38,7 +38,10 @@ struct Wino44Geom {
 #define FV_X_WINO44_LDS (52 * 1024)   // three workgroups per CU: 53.8 KB (k = 7, D = 5 with 16-channel chunks) measured as two
 #endif
     static constexpr int subs_fit(int s) { return (s > 1 && 2 * kChunk * s * ROW * 4 + 64 > FV_X_WINO44_LDS) ? subs_fit(s / 2) : s; }
-    static constexpr int SUBS = subs_fit(2);
+#ifndef FV_X_WINO44_SUBS_MAX
+#define FV_X_WINO44_SUBS_MAX 2
+#endif
+    static constexpr int SUBS = subs_fit(FV_X_WINO44_SUBS_MAX);
     static constexpr int CH = kChunk * SUBS;
     static constexpr int RPW = CH / 4;                 // channel rows staged by one wave
     static constexpr int NE = (RPW * WR + 63) / 64;    // lattice elements (four samples each) per lane and chunk
@@ -54,8 +57,11 @@ struct Wino44Geom {
     }
 };
 
+#ifndef FV_X_WINO44_OCC
+#define FV_X_WINO44_OCC 3
+#endif
 template <int KS, int DIL, bool C64>
-__global__ __launch_bounds__(256, 3) void conv_wino44_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, FV_X_WINO44_OCC) void conv_wino44_kernel(const ConvParams p) {
     using G = Wino44Geom<KS, DIL>;
     constexpr int NV = G::NV, NBQ = G::NBQ, WR = G::WR, ROW = G::ROW, SUBS = G::SUBS, CH = G::CH, RPW = G::RPW, NE = G::NE;
     __shared__ float xs[G::XS_F];

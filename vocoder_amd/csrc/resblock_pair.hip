@@ -173,7 +173,7 @@ template <int KS, int DIL>
 __global__ __launch_bounds__(256, kPairMinWaves) void resblock_pair16_kernel(const PairParams p) {
     constexpr int C = 16;
     using G = PairGeom<KS, DIL, C>;
-    constexpr int NT = G::W1 / 16 / 4;   // 8 n-tiles of 16 columns per wave
+    constexpr int NT = G::W1 / 16 / 4;   // n-tiles of 16 columns per wave: 2 (W1 = 128 columns over four waves)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;
     float* Bs = lds;   // overlays As once every wave has finished c1
