@@ -60,9 +60,13 @@ struct Wino44Geom {
 #ifndef FV_X_WINO44_OCC
 #define FV_X_WINO44_OCC 3
 #endif
-template <int KS, int DIL, bool C64>
+// VAR: 0 = any layer of whole 64-row blocks; 1 = the 64-channel layers (eight 8-channel blocks, one row block: a constant trip count, and their own rows in rocprofv3's
+// per-kernel statistics — the C = 128 stage's launches have the same grid at B = 32).  (Layers with an odd number of 32-row tiles — BigVGAN's C = 96 — stay on
+// conv_wino_kernel: an instance whose last workgroup idles two waves measured no faster there, and the test for it in the common instance cost 3 %: LOG R4.15)
+template <int KS, int DIL, int VAR>
 __global__ __launch_bounds__(256, FV_X_WINO44_OCC) void conv_wino44_kernel(const ConvParams p) {
     using G = Wino44Geom<KS, DIL>;
+    constexpr bool C64 = VAR == 1;
     constexpr int NV = G::NV, NBQ = G::NBQ, WR = G::WR, ROW = G::ROW, SUBS = G::SUBS, CH = G::CH, RPW = G::RPW, NE = G::NE;
     __shared__ float xs[G::XS_F];
 
@@ -317,22 +321,22 @@ __global__ __launch_bounds__(256, FV_X_WINO44_OCC) void conv_wino44_kernel(const
     FV_CV_STAMP(14);
 }
 
-template <int KS, bool C64>
+template <int KS, int VAR>
 inline bool launch_wino44_kc(const ConvParams& p0, int batch, hipStream_t s) {
     ConvParams p = p0;
     p.wg_total = batch * p.m_blks * p.n_tiles;
     const int grid = (p.wg_total + 7) / 8 * 8;
     switch (p.dil) {
-        case 1: hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, C64>), dim3(grid), dim3(256), 0, s, p); return true;
-        case 3: hipLaunchKernelGGL((conv_wino44_kernel<KS, 3, C64>), dim3(grid), dim3(256), 0, s, p); return true;
-        case 5: hipLaunchKernelGGL((conv_wino44_kernel<KS, 5, C64>), dim3(grid), dim3(256), 0, s, p); return true;
+        case 1: hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, VAR>), dim3(grid), dim3(256), 0, s, p); return true;
+        case 3: hipLaunchKernelGGL((conv_wino44_kernel<KS, 3, VAR>), dim3(grid), dim3(256), 0, s, p); return true;
+        case 5: hipLaunchKernelGGL((conv_wino44_kernel<KS, 5, VAR>), dim3(grid), dim3(256), 0, s, p); return true;
         default: return false;
     }
 }
 
 template <int KS>
 inline bool launch_wino44_k(const ConvParams& p, int batch, hipStream_t s) {
-    return (p.Cin == 64 && p.M == 64) ? launch_wino44_kc<KS, true>(p, batch, s) : launch_wino44_kc<KS, false>(p, batch, s);
+    return (p.Cin == 64 && p.M == 64) ? launch_wino44_kc<KS, 1>(p, batch, s) : launch_wino44_kc<KS, 0>(p, batch, s);
 }
 
 }  // namespace fv
