@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, FV_X_WINO44_OCC) void conv_wino44_kernel(const
     constexpr int DA = FV_X_WINO44_DA;   // weight prefetch distance in fragments
     float4 aq[DA + 1];
     float b_cur[4], b_nxt[4];
-    const int nch = C64 ? 8 / SUBS : (p.nchunk_real + SUBS - 1) / SUBS;
+    const int nch = C64 ? 8 / SUBS : (p.nchunk_real + SUBS - 1) / SUBS;   // (compile-time counts for C = 128 / 256 too: no difference in the step)
     load_chunk(0);
 #pragma unroll
     for (int d = 0; d < DA; ++d) aq[d] = load_a(d * 1024);
