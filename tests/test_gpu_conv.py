@@ -393,12 +393,14 @@ WINO44_CASES = [
 ]
 
 
-def test_winograd_f44_conv_matches_oracle(monkeypatch):
+@pytest.mark.parametrize("rows", [64, 128])
+def test_winograd_f44_conv_matches_oracle(rows, monkeypatch):
     """conv_wino44_impl.h — Winograd F(4,4) tap groups on the dilated quad lattice (20 / 13 matrix products per four outputs; seven planes over two waves,
-    the ∞ plane shared by channel pairs) — through fv_conv_* with the kernel forced (FV_WINO=2): SiLU + bias + residual, the plain conv and a
-    leaky-ReLU conv with a SiLU behind it against the CPU oracle."""
+    the ∞ plane shared by channel pairs) — through fv_conv_* with the kernel forced (FV_WINO=2; FV_WINO44_ROWS: one or two 32-row tiles per wave): SiLU +
+    bias + residual, the plain conv and a leaky-ReLU conv with a SiLU behind it against the CPU oracle."""
     from vocoder_amd import _lib
     monkeypatch.setenv("FV_WINO", "2")
+    monkeypatch.setenv("FV_WINO44_ROWS", str(rows))   # (128 is the default where the layer has whole 128-row blocks)
     _lib.reload_env()
     try:
         for (c, k, d, B, T) in WINO44_CASES:
@@ -410,7 +412,7 @@ def test_winograd_f44_conv_matches_oracle(monkeypatch):
             ref = orc.conv1d(orc.silu(x), w, b, dilation=d, padding=pad)
             res = rng.normal(size=ref.shape).astype(np.float32)
             y = _run(w, b, x, res, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
-            want = f"conv_wino44<k={k} d={d} tile=64x32q>"
+            want = f"conv_wino44<k={k} d={d} tile={rows if c % 128 == 0 else 64}x32q>"
             assert _lib.last_kernel() == want, (_lib.last_kernel(), want)
             _check(y, ref + res)
             y2 = _run(w, None, x, None, dilation=d, padding=pad)
@@ -422,6 +424,7 @@ def test_winograd_f44_conv_matches_oracle(monkeypatch):
                 _check(y3, orc.silu(orc.conv1d(np.where(x >= 0, x, np.float32(0.1) * x), w, b, dilation=d, padding=pad)))
     finally:
         monkeypatch.delenv("FV_WINO")
+        monkeypatch.delenv("FV_WINO44_ROWS")
         _lib.reload_env()
 
 

@@ -17,9 +17,9 @@ def key_of(kernel_name: str, grid_threads: int):
     if m:
         ks, dil, wm, wn, nt = map(int, m.groups())
         return f"conv_wino k={ks} d={dil} tile={wm * 32}x{wn * nt * 32}p grid={blocks}"
-    m = re.search(r"conv_wino44_kernel<(\d+), (\d+), (\d+)>", kernel_name)   # (KS, DIL, VAR: 1 = the 64-channel layers): 64 rows x 32 quad columns, 256 threads
+    m = re.search(r"conv_wino44_kernel<(\d+), (\d+), (\d+), (\d+)>", kernel_name)   # (KS, DIL, VAR: 1 = the 64-channel layers, MT): 64 MT rows x 32 quad columns, 256 threads
     if m:
-        return f"conv_wino44 k={m.group(1)} d={m.group(2)} tile=64x32q{' c64' if m.group(3) == '1' else ''} grid={blocks}"
+        return f"conv_wino44 k={m.group(1)} d={m.group(2)} tile={64 * int(m.group(4))}x32q{' c64' if m.group(3) == '1' else ''} grid={blocks}"
     m = re.search(r"conv_wino4_kernel<(\d+), (\d+), (\d+), (true|false)>", kernel_name)   # (KS, DIL, WM, C64): tile = rows x QUAD columns, 128 WM threads
     if m:
         return f"conv_wino4 k={m.group(1)} d={m.group(2)} tile={32 * int(m.group(3))}x32q{' c64' if m.group(4) == 'true' else ''} grid={grid_threads // (128 * int(m.group(3)))}"

@@ -650,17 +650,21 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
             // F(4,4) tap groups for k = 7 / 11 on layers of whole 64-row tiles (conv_wino44_impl.h: 20 / 13 products per four outputs) — the same gate as below
             if (knobs().wino4 && knobs().wino44 && L.d_wpw44 && knobs().wino4_rows != 128) {
                 const long long nq = (long long)L.dil * ((tout + 4 * L.dil - 1) / (4 * L.dil));   // quad columns: whole blocks of 4 D samples
+                // two 32-row tiles per wave (128-row workgroups, two waves per SIMD) wherever the layer has whole 128-row blocks: the staging of a window then feeds
+                // twice the products.  Back to back the C = 256 launches are slower that way (384 workgroups on 256 CUs), inside the three-stream step they are not:
+                // 10.95 (64 rows) / 10.77 (128 rows for launches of >= 4 workgroups per CU only) / 10.65 ms (always) interleaved on one box (LOG R4.16)
+                const int rows44 = (L.M % 128 == 0 && knobs().wino44_rows != 64) ? 128 : 64;
                 p.wp = L.d_wpw44;
-                p.m_blks = L.M / 64;
+                p.m_blks = L.M / rows44;
                 p.n_tiles = (int)((nq + 31) / 32);
                 const int prof_idx = prof_begin(stream);
-                const bool launched = L.ks == 7 ? launch_conv_wino44_k7(p, r.batch, stream) : launch_conv_wino44_k11(p, r.batch, stream);
+                const bool launched = L.ks == 7 ? launch_conv_wino44_k7(p, rows44, r.batch, stream) : launch_conv_wino44_k11(p, rows44, r.batch, stream);
                 if (!launched) {
                     set_error("conv_layer_run: no F(4,4) Winograd kernel for (k=%d, dilation=%d)", L.ks, L.dil);
                     return FV_ERR_UNSUPPORTED;
                 }
                 static thread_local char name[96];
-                std::snprintf(name, sizeof(name), "conv_wino44<k=%d d=%d tile=64x32q>", L.ks, L.dil);
+                std::snprintf(name, sizeof(name), "conv_wino44<k=%d d=%d tile=%dx32q>", L.ks, L.dil, rows44);
                 set_last_kernel(name);
                 if (prof_idx >= 0) {
                     const double macs = (double)L.c_in * L.c_out * L.k * (double)tout * r.batch;   // ALGORITHMIC (direct-sum) MACs

@@ -63,8 +63,10 @@ struct Wino44Geom {
 // VAR: 0 = any layer of whole 64-row blocks; 1 = the 64-channel layers (eight 8-channel blocks, one row block: a constant trip count, and their own rows in rocprofv3's
 // per-kernel statistics — the C = 128 stage's launches have the same grid at B = 32).  (Layers with an odd number of 32-row tiles — BigVGAN's C = 96 — stay on
 // conv_wino_kernel: an instance whose last workgroup idles two waves measured no faster there, and the test for it in the common instance cost 3 %: LOG R4.15)
-template <int KS, int DIL, int VAR>
-__global__ __launch_bounds__(256, FV_X_WINO44_OCC) void conv_wino44_kernel(const ConvParams p) {
+// MT: 32-row tiles per wave.  1: workgroup = 64 rows, three waves per SIMD.  2: workgroup = 128 rows — the same staging feeds twice the products, each operand read from LDS
+// serves two MFMAs — with 128 accumulator registers per wave, two waves per SIMD.
+template <int KS, int DIL, int VAR, int MT>
+__global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_wino44_kernel(const ConvParams p) {
     using G = Wino44Geom<KS, DIL>;
     constexpr bool C64 = VAR == 1;
     constexpr int NV = G::NV, NBQ = G::NBQ, WR = G::WR, ROW = G::ROW, SUBS = G::SUBS, CH = G::CH, RPW = G::RPW, NE = G::NE;
@@ -85,11 +87,13 @@ __global__ __launch_bounds__(256, FV_X_WINO44_OCC) void conv_wino44_kernel(const
     const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
 
     FV_CV_STAMP(0);
-    f32x16 acc[4];
+    f32x16 acc[MT][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][a][r] = 0.f;
 
     // ---- staging plan (conv_wino4_impl.h): this wave owns channel rows wave * RPW .. + RPW - 1 of every chunk; lane element i = quad column
     // (lane + 64 i) % WR of row (lane + 64 i) / WR; byte offsets relative to the chunk's first row, 0xFFFFFFFF outside [0, Tin) ----
@@ -156,12 +160,13 @@ __global__ __launch_bounds__(256, FV_X_WINO44_OCC) void conv_wino44_kernel(const
         }
     };
 
-    const int mt0 = m_blk * 2 + wm;   // 32-row tile
+    const int mt0 = (m_blk * 2 + wm) * MT;   // first 32-row tile of this wave
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
     const int wvoff = lane * 16;
     const int wbase = __builtin_amdgcn_readfirstlane((mt0 * 2 + h) * (p.nchunk * NV * 1024));   // bytes per (m-tile, half): nchunk * NV fragments of 1 KiB
-    auto load_a = [&](int goff_b) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wbase + goff_b, 0);
+    const int wtile = __builtin_amdgcn_readfirstlane(2 * p.nchunk * NV * 1024);   // bytes from one 32-row tile's fragments to the next one's (same half)
+    auto load_a = [&](int i, int goff_b) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wbase + i * wtile + goff_b, 0);
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
     const int b_lane_g = (lane >> 5) * ROW + (lane & 31) + h * G::HALF_G;       // own planes
@@ -172,12 +177,14 @@ __global__ __launch_bounds__(256, FV_X_WINO44_OCC) void conv_wino44_kernel(const
 #define FV_X_WINO44_DA 3
 #endif
     constexpr int DA = FV_X_WINO44_DA;   // weight prefetch distance in fragments
-    float4 aq[DA + 1];
+    float4 aq[MT][DA + 1];
     float b_cur[4], b_nxt[4];
     const int nch = C64 ? 8 / SUBS : (p.nchunk_real + SUBS - 1) / SUBS;   // (compile-time counts for C = 128 / 256 too: no difference in the step)
     load_chunk(0);
 #pragma unroll
-    for (int d = 0; d < DA; ++d) aq[d] = load_a(d * 1024);
+    for (int d = 0; d < DA; ++d)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) aq[i][d] = load_a(i, d * 1024);
     for (int c = 0; c < nch; ++c) {
         float* xsb = xs + (c & 1) * (CH * ROW);
         store_chunk(xsb);
@@ -196,11 +203,14 @@ __global__ __launch_bounds__(256, FV_X_WINO44_OCC) void conv_wino44_kernel(const
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 if (m < NM) {
-                    const float av = m == 0 ? aq[0].x : m == 1 ? aq[0].y : m == 2 ? aq[0].z : aq[0].w;
-                    acc[A] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[m], acc[A], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const float av = m == 0 ? aq[i][0].x : m == 1 ? aq[i][0].y : m == 2 ? aq[i][0].z : aq[i][0].w;
+                        acc[i][A] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[m], acc[i][A], 0, 0, 0);
+                    }
                 }
-                // one weight fragment (DA fragments ahead) and the next step's operands, spread over this step's MFMAs
-                if (m == 0) aq[DA] = load_a(gchunk_b + st * 1024);
+                // one weight fragment per row tile (DA fragments ahead) and the next step's operands, spread over this step's MFMAs
+                if (m < MT) aq[m][DA] = load_a(m, gchunk_b + st * 1024);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (j < NM_n && (j * NM) / 4 == m && m < NM)
@@ -209,7 +219,9 @@ __global__ __launch_bounds__(256, FV_X_WINO44_OCC) void conv_wino44_kernel(const
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int d = 0; d < DA; ++d) aq[d] = aq[d + 1];
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int d = 0; d < DA; ++d) aq[i][d] = aq[i][d + 1];
             if constexpr (st + 1 < STEPS) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];
@@ -224,119 +236,120 @@ __global__ __launch_bounds__(256, FV_X_WINO44_OCC) void conv_wino44_kernel(const
     //       keeps  y0: s + m1,  y1: d/2 + m1        sends  y2: s/4 + m1,  y3: d/8 + m1 + m(∞)
     //   half 1 (m(-1) m(2) m(-2), its part of m(∞)):      s = m(2) + m(-2),     d = m(2) - m(-2)
     //       sends  y0: s + m(-1),  y1: 2 d - m(-1)  keeps  y2: 4 s + m(-1),  y3: 8 d - m(-1) + m(∞) ----
-    __syncthreads();   // every wave is past its last operand read: the chunk buffers become the exchange area
-    {
-        float* ex = xs + wave * 2048 + lane;
-        if (h == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float sm = acc[0][r] + acc[1][r], df = acc[0][r] - acc[1][r], m1 = acc[2][r];
-                ex[r * 64] = fmaf(0.25f, sm, m1);
-                ex[1024 + r * 64] = fmaf(0.125f, df, m1) + acc[3][r];
-                acc[0][r] = sm + m1;
-                acc[1][r] = fmaf(0.5f, df, m1);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float sm = acc[1][r] + acc[2][r], df = acc[1][r] - acc[2][r], mm = acc[0][r];
-                ex[r * 64] = sm + mm;
-                ex[1024 + r * 64] = fmaf(2.0f, df, -mm);
-                acc[0][r] = fmaf(4.0f, sm, mm);
-                acc[1][r] = fmaf(8.0f, df, -mm) + acc[3][r];
-            }
-        }
-    }
-    __syncthreads();
-    const float* pa = xs + (wave ^ 1) * 2048 + lane;          // partner's partial sum of this half's first output
-    const float* pb = xs + (wave ^ 1) * 2048 + 1024 + lane;   // ... and second
-    if (mt0 * 32 >= p.M) return;
     const int n = n0 + (lane & 31);
     const int q = n / DIL;
     const int ta = 4 * DIL * q + (n - q * DIL) + 2 * h * DIL, tb = ta + DIL;   // half 0: t0, t0 + D; half 1: t0 + 2D, t0 + 3D
-    // The common case — whole 32-row tiles, bias [+ residual] [+ post-activation], plain store — without per-element offset registers
-    // (conv_wino_impl.h): all bias and residual operands are requested before the partner's planes are read back.
-    if (p.M % 32 == 0 && p.gamma == nullptr && p.out_mode == OUT_SET && p.acc_scale == 1.0f) {
-        const unsigned span = (unsigned)(p.y_bstride * 4);
-        const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
-        const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
-        const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(p.bias, (unsigned)(p.M * 4));
-        const int mrow = 4 * (lane >> 5);                                   // lane part of the row; + mt0 * 32 + (r & 3) + 8 * (r >> 2) in SGPRs
-        const unsigned va = ta < p.N ? (unsigned)(mrow * p.N + ta) * 4u : 0xFFFFFFFFu;
-        const unsigned vb = tb < p.N ? (unsigned)(mrow * p.N + tb) * 4u : 0xFFFFFFFFu;
-        float bias[16], ra[16], rb[16];
+    const float* pa = xs + (wave ^ 1) * 2048 + lane;          // partner's partial sum of this half's first output
+    const float* pb = xs + (wave ^ 1) * 2048 + 1024 + lane;   // ... and second
+    // the common case — whole 32-row tiles, bias [+ residual] [+ post-activation], plain store — without per-element offset registers (conv_wino_impl.h)
+    const bool lean = p.M % 32 == 0 && p.gamma == nullptr && p.out_mode == OUT_SET && p.acc_scale == 1.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            bias[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, mrow * 4, (mt0 * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
-        if (p.res) {
+    for (int i = 0; i < MT; ++i) {
+        const int mt = mt0 + i;
+        __syncthreads();   // every wave is past its last operand read (i = 0: the chunk buffers become the exchange area) / past the previous tile's exchange
+        {
+            float* ex = xs + wave * 2048 + lane;
+            if (h == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sm = acc[i][0][r] + acc[i][1][r], df = acc[i][0][r] - acc[i][1][r], m1 = acc[i][2][r];
+                    ex[r * 64] = fmaf(0.25f, sm, m1);
+                    ex[1024 + r * 64] = fmaf(0.125f, df, m1) + acc[i][3][r];
+                    acc[i][0][r] = sm + m1;
+                    acc[i][1][r] = fmaf(0.5f, df, m1);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sm = acc[i][1][r] + acc[i][2][r], df = acc[i][1][r] - acc[i][2][r], mm = acc[i][0][r];
+                    ex[r * 64] = sm + mm;
+                    ex[1024 + r * 64] = fmaf(2.0f, df, -mm);
+                    acc[i][0][r] = fmaf(4.0f, sm, mm);
+                    acc[i][1][r] = fmaf(8.0f, df, -mm) + acc[i][3][r];
+                }
+            }
+        }
+        __syncthreads();
+        if (lean) {
+            // all bias and residual operands are requested before the partner's planes are read back
+            const unsigned span = (unsigned)(p.y_bstride * 4);
+            const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
+            const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
+            const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(p.bias, (unsigned)(p.M * 4));
+            const int mrow = 4 * (lane >> 5);                                   // lane part of the row; + mt * 32 + (r & 3) + 8 * (r >> 2) in SGPRs
+            const unsigned va = ta < p.N ? (unsigned)(mrow * p.N + ta) * 4u : 0xFFFFFFFFu;
+            const unsigned vb = tb < p.N ? (unsigned)(mrow * p.N + tb) * 4u : 0xFFFFFFFFu;
+            float bias[16], ra[16], rb[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bias[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, mrow * 4, (mt * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+            if (p.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int so = (int)((unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);   // (< 4 GiB per item: conv_layer_run)
+                    ra[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, va, so, 0));
+                    rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, vb, so, 0));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ra[r] = rb[r] = 0.f;
+            }
+            const bool has_res = p.res != nullptr;
+            float oa[16], ob[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int so = (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);   // (< 4 GiB per item: conv_layer_run)
-                ra[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, va, so, 0));
-                rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, vb, so, 0));
+                const float y0 = acc[i][0][r] + pa[r * 64];
+                const float y1 = acc[i][1][r] + pb[r * 64];
+                oa[r] = fmaf(y0, 1.0f, bias[r]);
+                ob[r] = fmaf(y1, 1.0f, bias[r]);
+                if (has_res) {
+                    oa[r] += ra[r];
+                    ob[r] += rb[r];
+                }
+            }
+            act_apply_all(oa, p.post_act, p.slope);   // (c1 of a ResBlock pair carries the SiLU in front of c2: hifigan.py:104-106)
+            act_apply_all(ob, p.post_act, p.slope);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = (int)((unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oa[r]), yrs, va, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ob[r]), yrs, vb, so, 0);
             }
         } else {
+            f32x16 out[1][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ra[r] = rb[r] = 0.f;
-        }
-        const bool has_res = p.res != nullptr;
-        float oa[16], ob[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float y0 = acc[0][r] + pa[r * 64];
-            const float y1 = acc[1][r] + pb[r * 64];
-            oa[r] = fmaf(y0, 1.0f, bias[r]);
-            ob[r] = fmaf(y1, 1.0f, bias[r]);
-            if (has_res) {
-                oa[r] += ra[r];
-                ob[r] += rb[r];
+            for (int r = 0; r < 16; ++r) {
+                out[0][0][r] = acc[i][0][r] + pa[r * 64];
+                out[0][1][r] = acc[i][1][r] + pb[r * 64];
             }
+            const int coff[2] = {ta, tb};
+            const bool cok[2] = {ta < p.N, tb < p.N};
+            conv_epilogue_cols<1, 2>(p, out, b, mt, coff, cok, lane);
         }
-        act_apply_all(oa, p.post_act, p.slope);   // (c1 of a ResBlock pair carries the SiLU in front of c2: hifigan.py:104-106)
-        act_apply_all(ob, p.post_act, p.slope);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int so = (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oa[r]), yrs, va, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ob[r]), yrs, vb, so, 0);
-        }
-#ifdef FV_X_CONV_TS
-        __builtin_amdgcn_s_waitcnt(0);
-#endif
-        FV_CV_STAMP(14);
-        return;
     }
-    f32x16 out[1][2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        out[0][0][r] = acc[0][r] + pa[r * 64];
-        out[0][1][r] = acc[1][r] + pb[r * 64];
-    }
-    const int coff[2] = {ta, tb};
-    const bool cok[2] = {ta < p.N, tb < p.N};
-    conv_epilogue_cols<1, 2>(p, out, b, mt0, coff, cok, lane);
 #ifdef FV_X_CONV_TS
     __builtin_amdgcn_s_waitcnt(0);
 #endif
     FV_CV_STAMP(14);
 }
 
-template <int KS, int VAR>
+template <int KS, int VAR, int MT>
 inline bool launch_wino44_kc(const ConvParams& p0, int batch, hipStream_t s) {
     ConvParams p = p0;
     p.wg_total = batch * p.m_blks * p.n_tiles;
     const int grid = (p.wg_total + 7) / 8 * 8;
     switch (p.dil) {
-        case 1: hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, VAR>), dim3(grid), dim3(256), 0, s, p); return true;
-        case 3: hipLaunchKernelGGL((conv_wino44_kernel<KS, 3, VAR>), dim3(grid), dim3(256), 0, s, p); return true;
-        case 5: hipLaunchKernelGGL((conv_wino44_kernel<KS, 5, VAR>), dim3(grid), dim3(256), 0, s, p); return true;
+        case 1: hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, VAR, MT>), dim3(grid), dim3(256), 0, s, p); return true;
+        case 3: hipLaunchKernelGGL((conv_wino44_kernel<KS, 3, VAR, MT>), dim3(grid), dim3(256), 0, s, p); return true;
+        case 5: hipLaunchKernelGGL((conv_wino44_kernel<KS, 5, VAR, MT>), dim3(grid), dim3(256), 0, s, p); return true;
         default: return false;
     }
 }
 
 template <int KS>
-inline bool launch_wino44_k(const ConvParams& p, int batch, hipStream_t s) {
-    return (p.Cin == 64 && p.M == 64) ? launch_wino44_kc<KS, 1>(p, batch, s) : launch_wino44_kc<KS, 0>(p, batch, s);
+inline bool launch_wino44_k(const ConvParams& p, int rows, int batch, hipStream_t s) {
+    if (rows == 128) return launch_wino44_kc<KS, 0, 2>(p, batch, s);
+    return (p.Cin == 64 && p.M == 64) ? launch_wino44_kc<KS, 1, 1>(p, batch, s) : launch_wino44_kc<KS, 0, 1>(p, batch, s);
 }
 
 }  // namespace fv

@@ -31,6 +31,7 @@ struct Knobs {
     int wino_cfg = -1;    // FV_WINO_CFG: forced tile (WinoCfg 0 ... 2), -1 = by shape
     int wino_min_blocks = -1;   // FV_WINO_MIN_BLOCKS: fewest workgroups of a launch that takes it, -1 = default
     int wino44 = 1;       // FV_WINO44: 1 = F(4,4) tap groups (conv_wino44_impl.h) for k = 7 / 11 where FV_WINO4 would take F(4,3), 0 = F(4,3) there
+    int wino44_rows = 0;  // FV_WINO44_ROWS: 64 = one 32-row tile per wave (64-row workgroups) everywhere; otherwise two (128 rows) where the layer has whole 128-row blocks
     int wino4_rows = 0;   // FV_WINO4_ROWS: 128 = the eight-wave F(4,3) workgroups (experiments), otherwise 64 rows
     int wino4 = 1;        // FV_WINO4: 1 = F(4,3) tap groups (conv_wino4_impl.h) for k = 7 / 11 where the Winograd path is taken and the layer has whole 64-row tiles, 2 = for k = 3 too, 0 = F(2,3) everywhere
     int wino_lat = 1;     // FV_WINO_LAT: 0 = launches below the Winograd gate run the direct split-K kernels, 1 = the Winograd latency kernel
@@ -286,8 +287,8 @@ bool launch_conv_wino4_k3(const ConvParams& p, int rows, int batch, hipStream_t 
 bool launch_conv_wino4_k7(const ConvParams& p, int rows, int batch, hipStream_t s);
 bool launch_conv_wino4_k11(const ConvParams& p, int rows, int batch, hipStream_t s);
 // conv_wino44_impl.h: F(4,4) tap groups, 64 rows x 32 quad columns per workgroup; p.wp = the layer's d_wpw44, p.m_blks = M / 64, p.n_tiles over quad columns
-bool launch_conv_wino44_k7(const ConvParams& p, int batch, hipStream_t s);
-bool launch_conv_wino44_k11(const ConvParams& p, int batch, hipStream_t s);
+bool launch_conv_wino44_k7(const ConvParams& p, int rows, int batch, hipStream_t s);
+bool launch_conv_wino44_k11(const ConvParams& p, int rows, int batch, hipStream_t s);
 // conv_wino_lat_impl.h: latency variant (16 rows x 16 nt pairs per workgroup, K split over the four waves); p.wp = the layer's d_wpwl,
 // p.m_blks = C / 16, p.n_tiles in units of 16 nt pair columns
 bool launch_conv_wino_lat_k3(const ConvParams& p, int nt, int batch, hipStream_t s);
