@@ -309,7 +309,7 @@ WINO_CASES = [
 
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
 def test_winograd_conv_matches_oracle(cfg, monkeypatch):
-    """conv_wino_impl.h (F(2,3) tap groups; FV_WINO4=0 keeps the F(4,3) kernels out) through fv_conv_* with the kernel forced (FV_WINO=2) and every
+    """conv_wino_impl.h (F(2,3) tap groups; FV_WINO4=0 keeps the quad-lattice kernels out) through fv_conv_* with the kernel forced (FV_WINO=2) and every
     tile variant (FV_WINO_CFG): SiLU + bias + residual and the plain conv against the CPU oracle; the direct-sum kernel on the same layer for
     scale (both sit ~1e-6 from the oracle)."""
     from vocoder_amd import _lib
@@ -339,24 +339,19 @@ def test_winograd_conv_matches_oracle(cfg, monkeypatch):
 
 
 WINO4_CASES = [
-    # (C, k, dil, B, T): whole 64-row tiles only; ragged lengths (odd, below one block of 4 D samples, one sample), one to four row blocks
-    (128, 11, 1, 1, 517), (128, 7, 3, 2, 300), (128, 3, 5, 1, 131), (256, 11, 5, 1, 97), (256, 3, 1, 2, 200), (192, 7, 5, 1, 1000),
-    (64, 11, 3, 2, 700), (64, 7, 1, 1, 129), (64, 3, 3, 1, 64), (128, 11, 5, 1, 9), (128, 7, 3, 1, 1), (64, 11, 1, 3, 4099), (64, 7, 5, 1, 19),
-    (128, 11, 3, 1, 12), (128, 7, 1, 2, 127), (256, 7, 1, 1, 33),
+    # (C, k, dil, B, T): whole 64-row blocks, k = 7 / 11; ragged lengths (odd, below one block of 4 D samples, one sample), one to four row blocks
+    (128, 11, 1, 1, 517), (128, 7, 3, 2, 300), (256, 11, 5, 1, 97), (192, 7, 5, 1, 1000), (64, 11, 3, 2, 700), (64, 7, 1, 1, 129), (128, 11, 5, 1, 9),
+    (128, 7, 3, 1, 1), (64, 11, 1, 3, 4099), (64, 7, 5, 1, 19), (128, 11, 3, 1, 12), (128, 7, 1, 2, 127), (256, 7, 1, 1, 33),
 ]
 
 
-@pytest.mark.parametrize("rows", [64, 128])
-def test_winograd_f43_conv_matches_oracle(rows, monkeypatch):
-    """conv_wino4_impl.h — Winograd F(4,3) tap groups on the dilated quad lattice (26 / 16 / 6 matrix products per four outputs) — through
-    fv_conv_* with the kernel forced (FV_WINO=2, FV_WINO4=2: k = 3 too; FV_WINO4_ROWS: the four- and the eight-wave workgroup): SiLU + bias +
-    residual, the plain conv and a leaky-ReLU conv with a SiLU behind it (c1 of a fused-less ResBlock pair) against the CPU oracle; the accumulate
-    epilogue runs in the model tests (the MRF sum, test_gpu_models.py)."""
+def test_winograd_f43_conv_matches_oracle(monkeypatch):
+    """conv_wino4_impl.h — Winograd F(4,3) tap groups on the dilated quad lattice (26 / 16 matrix products per four outputs; the predecessor of the F(4,4)
+    kernel, reached with FV_WINO44=0) — through fv_conv_* with the kernel forced (FV_WINO=2): SiLU + bias + residual, the plain conv and a leaky-ReLU
+    conv with a SiLU behind it against the CPU oracle; the accumulate epilogue runs in the model tests (the MRF sum, test_gpu_models.py)."""
     from vocoder_amd import _lib
     monkeypatch.setenv("FV_WINO", "2")
-    monkeypatch.setenv("FV_WINO4", "2")
     monkeypatch.setenv("FV_WINO44", "0")
-    monkeypatch.setenv("FV_WINO4_ROWS", str(rows))
     _lib.reload_env()
     try:
         for (c, k, d, B, T) in WINO4_CASES:
@@ -368,7 +363,7 @@ def test_winograd_f43_conv_matches_oracle(rows, monkeypatch):
             ref = orc.conv1d(orc.silu(x), w, b, dilation=d, padding=pad)
             res = rng.normal(size=ref.shape).astype(np.float32)
             y = _run(w, b, x, res, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
-            want = f"conv_wino4<k={k} d={d} tile={rows if c % 128 == 0 else 64}x32q>"
+            want = f"conv_wino4<k={k} d={d} tile=64x32q>"
             assert _lib.last_kernel() == want, (_lib.last_kernel(), want)
             _check(y, ref + res)
             y2 = _run(w, None, x, None, dilation=d, padding=pad)
@@ -380,9 +375,7 @@ def test_winograd_f43_conv_matches_oracle(rows, monkeypatch):
                 _check(y3, orc.silu(orc.conv1d(np.where(x >= 0, x, np.float32(0.1) * x), w, b, dilation=d, padding=pad)))
     finally:
         monkeypatch.delenv("FV_WINO")
-        monkeypatch.delenv("FV_WINO4")
         monkeypatch.delenv("FV_WINO44")
-        monkeypatch.delenv("FV_WINO4_ROWS")
         _lib.reload_env()
 
 

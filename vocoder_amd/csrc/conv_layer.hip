@@ -204,7 +204,7 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
             FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw44, p44.size() * sizeof(float)));
             FV_HIP_CHECK(hipMemcpy(L.d_wpw44, p44.data(), p44.size() * sizeof(float), hipMemcpyHostToDevice));
         }
-        if (c_in >= 64 && c_out % 64 == 0) {
+        if (c_in >= 64 && c_out % 64 == 0 && k >= 7) {
             // Winograd F(4,3) tap groups (conv_wino4_impl.h): per (32-row tile, plane half h) nv4 = 3 ng + 2 ns virtual taps = Wino4Geom::off_of / acc_of:
             // group g, i = 0..2 -> transformed weight U_p of taps 4g..4g+2 with p = i (h = 0: m0 m1 m2) or 5 - i (h = 1: m5 m4 m3); then per single tap
             // 4s + 3 two plain copies (h = 0: into m0 and S1, h = 1: into m5 and S2).  Packed as 2 M rows: row (2 mt + h) * 32 + r = (row 32 mt + r, half h)
@@ -648,7 +648,7 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
             // F(4,3) tap groups where the layer has whole 64-row tiles (conv_wino4_impl.h): the same gate, so one algorithm per layer whatever
             // the batch in batch-invariant mode
             // F(4,4) tap groups for k = 7 / 11 on layers of whole 64-row tiles (conv_wino44_impl.h: 20 / 13 products per four outputs) — the same gate as below
-            if (knobs().wino4 && knobs().wino44 && L.d_wpw44 && knobs().wino4_rows != 128) {
+            if (knobs().wino4 && knobs().wino44 && L.d_wpw44) {
                 const long long nq = (long long)L.dil * ((tout + 4 * L.dil - 1) / (4 * L.dil));   // quad columns: whole blocks of 4 D samples
                 // two 32-row tiles per wave (128-row workgroups, two waves per SIMD) wherever the layer has whole 128-row blocks: the staging of a window then feeds
                 // twice the products.  Back to back the C = 256 launches are slower that way (384 workgroups on 256 CUs), inside the three-stream step they are not:
@@ -678,16 +678,14 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
                 FV_HIP_CHECK(hipGetLastError());
                 return FV_OK;
             }
-            if (knobs().wino4 && L.d_wpw4 && (L.ks >= 7 || knobs().wino4 >= 2)) {   // (k = 3: 6 products per quad against 8, and F(2,3) measured faster)
+            if (knobs().wino4 && L.d_wpw4) {   // (k = 7 / 11 only — k = 3: 6 products per quad against 8, and F(2,3) measured faster: LOG R4.14)
                 const long long nq = (long long)L.dil * ((tout + 4 * L.dil - 1) / (4 * L.dil));   // quad columns: whole blocks of 4 D samples
-                // 64-row workgroups (four waves); the 128-row form (eight waves, half the staging per product) measured 10 - 25 % slower: LOG R4.14
-                const int rows = (knobs().wino4_rows == 128 && L.M % 128 == 0) ? 128 : 64;
+                const int rows = 64;
                 p.wp = L.d_wpw4;
                 p.m_blks = L.M / rows;
                 p.n_tiles = (int)((nq + 31) / 32);
                 const int prof_idx = prof_begin(stream);
-                const bool launched = L.ks == 3 ? launch_conv_wino4_k3(p, rows, r.batch, stream)
-                                      : L.ks == 7 ? launch_conv_wino4_k7(p, rows, r.batch, stream) : launch_conv_wino4_k11(p, rows, r.batch, stream);
+                const bool launched = L.ks == 7 ? launch_conv_wino4_k7(p, r.batch, stream) : launch_conv_wino4_k11(p, r.batch, stream);
                 if (!launched) {
                     set_error("conv_layer_run: no F(4,3) Winograd kernel for (k=%d, dilation=%d)", L.ks, L.dil);
                     return FV_ERR_UNSUPPORTED;

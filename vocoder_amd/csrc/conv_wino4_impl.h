@@ -333,9 +333,9 @@ inline bool launch_wino4_kw(const ConvParams& p0, int batch, hipStream_t s) {
     }
 }
 
+// (WM = 4 — eight-wave, 128-row workgroups — measured 10 - 25 % slower than WM = 2 and is not instantiated: LOG R4.14)
 template <int KS>
-inline bool launch_wino4_k(const ConvParams& p, int rows, int batch, hipStream_t s) {
-    if (rows == 128) return launch_wino4_kw<KS, 4, false>(p, batch, s);
+inline bool launch_wino4_k(const ConvParams& p, int batch, hipStream_t s) {
     return (p.Cin == 64 && p.M == 64) ? launch_wino4_kw<KS, 2, true>(p, batch, s) : launch_wino4_kw<KS, 2, false>(p, batch, s);
 }
 

@@ -77,7 +77,6 @@ static const Knobs* load_knobs() {
     if (const char* v = std::getenv("FV_WINO4")) k->wino4 = std::atoi(v);
     if (const char* v = std::getenv("FV_WINO44")) k->wino44 = std::atoi(v);
     if (const char* v = std::getenv("FV_WINO44_ROWS")) k->wino44_rows = std::atoi(v);
-    if (const char* v = std::getenv("FV_WINO4_ROWS")) k->wino4_rows = std::atoi(v);
     if (const char* v = std::getenv("FV_WINO_LAT")) k->wino_lat = std::atoi(v);
     return k;
 }

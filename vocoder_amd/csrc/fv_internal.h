@@ -32,8 +32,7 @@ struct Knobs {
     int wino_min_blocks = -1;   // FV_WINO_MIN_BLOCKS: fewest workgroups of a launch that takes it, -1 = default
     int wino44 = 1;       // FV_WINO44: 1 = F(4,4) tap groups (conv_wino44_impl.h) for k = 7 / 11 where FV_WINO4 would take F(4,3), 0 = F(4,3) there
     int wino44_rows = 0;  // FV_WINO44_ROWS: 64 = one 32-row tile per wave (64-row workgroups) everywhere; otherwise two (128 rows) where the layer has whole 128-row blocks
-    int wino4_rows = 0;   // FV_WINO4_ROWS: 128 = the eight-wave F(4,3) workgroups (experiments), otherwise 64 rows
-    int wino4 = 1;        // FV_WINO4: 1 = F(4,3) tap groups (conv_wino4_impl.h) for k = 7 / 11 where the Winograd path is taken and the layer has whole 64-row tiles, 2 = for k = 3 too, 0 = F(2,3) everywhere
+    int wino4 = 1;        // FV_WINO4: 1 = the quad-lattice kernels (conv_wino44_impl.h / conv_wino4_impl.h) for k = 7 / 11 where the Winograd path is taken and the layer has whole 64-row blocks, 0 = F(2,3) everywhere
     int wino_lat = 1;     // FV_WINO_LAT: 0 = launches below the Winograd gate run the direct split-K kernels, 1 = the Winograd latency kernel
     int pair_wino = 1;    // FV_PAIR_WINO: 0 = the fused (c1, c2) pairs run direct sums (resblock_pair.hip), 1 = Winograd tap groups where a kernel exists
 };
@@ -282,10 +281,9 @@ enum WinoCfg : int { WINO_128x32 = 0, WINO_64x64 = 1, WINO_32x128 = 2, WINO_128x
 bool launch_conv_wino_k3(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_wino_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_wino_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
-// conv_wino4_impl.h: F(4,3) tap groups, rows (64 | 128) x 32 quad columns per workgroup; p.wp = the layer's d_wpw4, p.m_blks = M / rows, p.n_tiles over quad columns
-bool launch_conv_wino4_k3(const ConvParams& p, int rows, int batch, hipStream_t s);
-bool launch_conv_wino4_k7(const ConvParams& p, int rows, int batch, hipStream_t s);
-bool launch_conv_wino4_k11(const ConvParams& p, int rows, int batch, hipStream_t s);
+// conv_wino4_impl.h: F(4,3) tap groups (k = 7 / 11), 64 rows x 32 quad columns per workgroup; p.wp = the layer's d_wpw4, p.m_blks = M / 64, p.n_tiles over quad columns
+bool launch_conv_wino4_k7(const ConvParams& p, int batch, hipStream_t s);
+bool launch_conv_wino4_k11(const ConvParams& p, int batch, hipStream_t s);
 // conv_wino44_impl.h: F(4,4) tap groups, 64 rows x 32 quad columns per workgroup; p.wp = the layer's d_wpw44, p.m_blks = M / 64, p.n_tiles over quad columns
 bool launch_conv_wino44_k7(const ConvParams& p, int rows, int batch, hipStream_t s);
 bool launch_conv_wino44_k11(const ConvParams& p, int rows, int batch, hipStream_t s);
