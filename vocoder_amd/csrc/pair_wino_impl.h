@@ -202,6 +202,9 @@ __device__ __forceinline__ void pw_gemm_chunk(f32x4w (&acc)[4][G::MT], const flo
     for (int i = 0; i < NB; ++i) b_cur[i] = *b_addr(i / KST, i % KST);
     static_for<G::NMS>([&](auto ms_c) __attribute__((always_inline)) {
         constexpr int ms = decltype(ms_c)::value;
+#ifdef FV_X_PW_SKIP
+        if constexpr (ms * 8 >= G::NMS * 5) return;   // timing experiment (wrong results): 5 of every 8 products, as F(4,4) tap groups would leave
+#endif
         constexpr int f0 = ms * U;
         constexpr int NLDX = U + NB;   // memory operations of this macro-step: U weight loads (DA fragments ahead), NB LDS reads (next macro-step)
         // each of them is requested BETWEEN two MFMAs: an in-order wave hides a memory instruction's issue time only under a matrix
