@@ -461,25 +461,27 @@ __device__ __forceinline__ void aa_snake4_tile(const float* __restrict__ xr, flo
         dne[q] = down_taps[2 * q + 1];   // multiplies the even sample of m = i + q + 1
     }
     __syncthreads();
+    // Every FIR step below is one packed FMA over TWO ADJACENT positions: its data operand is a register pair of consecutive LDS floats that one
+    // ds_read2_b32 delivers at any alignment (pairing the even / odd chains of one position instead left half of the pairs misaligned in the
+    // registers of the 16-byte window reads: a third of this tile's vector instructions were moves).  Same chains, same order: bit-identical.
     auto up_group = [&](int j) {   // positions m = 4j .. 4j + 3: ue(m) = sum_q upe[q] xs[m + 7 - q], uo(m) = sum_q upo[q] xs[m + 8 - q]
-        float w[12];
+        const float* wp = xs + 4 * j;
+        f32x2 P[9];   // P[i] = (w[i + 2], w[i + 3])
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const f4 t = *reinterpret_cast<const f4*>(xs + 4 * j + 4 * v);
-            w[4 * v] = t.x; w[4 * v + 1] = t.y; w[4 * v + 2] = t.z; w[4 * v + 3] = t.w;
-        }
+        for (int i = 0; i < 9; ++i) P[i] = f32x2{wp[i + 2], wp[i + 3]};
         f4 ev, od;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float ue = 0.f, uo = 0.f;
+        for (int k = 0; k < 4; k += 2) {
+            f32x2 ue = {0.f, 0.f}, uo = {0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
-                ue = fmaf(upe[q], w[k + 7 - q], ue);
-                uo = fmaf(upo[q], w[k + 8 - q], uo);
+                ue = __builtin_elementwise_fma((f32x2)(upe[q]), P[k + 5 - q], ue);
+                uo = __builtin_elementwise_fma((f32x2)(upo[q]), P[k + 6 - q], uo);
             }
-            const f32x2 a = snake2(f32x2{ue, uo}, al, ib, al_pi, al_lo, hb);
-            ev[k] = a.x;
-            od[k] = a.y;
+            // snake2 is element-wise: (ue(m), ue(m + 1)) and (uo(m), uo(m + 1)) instead of (ue(m), uo(m)) twice
+            const f32x2 ae = snake2(ue, al, ib, al_pi, al_lo, hb), ao = snake2(uo, al, ib, al_pi, al_lo, hb);
+            ev[k] = ae.x; ev[k + 1] = ae.y;
+            od[k] = ao.x; od[k + 1] = ao.y;
         }
         *reinterpret_cast<f4*>(E + 4 * j) = ev;
         *reinterpret_cast<f4*>(O + 4 * j) = od;
@@ -504,24 +506,26 @@ __device__ __forceinline__ void aa_snake4_tile(const float* __restrict__ xr, flo
         __syncthreads();
     }
     {   // outputs i = 4 tid .. 4 tid + 3: y = sum_q dno[q] O[i + q] + dne[q] E[i + q + 1]
-        float o[12], e[12];
+        const float* op = O + 4 * tid;
+        const float* ep = E + 4 * tid + 1;
+        f32x2 PO[8], PE[8];   // (O[i], O[i + 1]), (E[i + 1], E[i + 2])
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const f4 a = *reinterpret_cast<const f4*>(O + 4 * tid + 4 * v);
-            const f4 b = *reinterpret_cast<const f4*>(E + 4 * tid + 4 * v);
-            o[4 * v] = a.x; o[4 * v + 1] = a.y; o[4 * v + 2] = a.z; o[4 * v + 3] = a.w;
-            e[4 * v] = b.x; e[4 * v + 1] = b.y; e[4 * v + 2] = b.z; e[4 * v + 3] = b.w;
+        for (int i = 0; i < 8; ++i) {
+            PO[i] = f32x2{op[i], op[i + 1]};
+            PE[i] = f32x2{ep[i], ep[i + 1]};
         }
         f4 out;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float sx = 0.f, sy = 0.f;
+        for (int k = 0; k < 4; k += 2) {
+            f32x2 sx = {0.f, 0.f}, sy = {0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
-                sx = fmaf(dno[q], o[k + q], sx);
-                sy = fmaf(dne[q], e[k + q + 1], sy);
+                sx = __builtin_elementwise_fma((f32x2)(dno[q]), PO[k + q], sx);
+                sy = __builtin_elementwise_fma((f32x2)(dne[q]), PE[k + q], sy);
             }
-            out[k] = sx + sy;
+            const f32x2 o2 = sx + sy;
+            out[k] = o2.x;
+            out[k + 1] = o2.y;
         }
         if constexpr (EDGE) {
 #pragma unroll
