@@ -183,7 +183,7 @@ FV_API fv_status fv_set_precision(fv_engine* e, int32_t precision);
  * call).  Every choice computes in fp32 and stays well inside the parity bar (whole forwards differ by <= 2e-5 of full scale between them);
  * what changes is the LAST BITS of a clip's output and the speed:
  *   FV_CONV_ALGO_AUTO      per launch, whatever is fastest: Winograd F(2,3) tap groups for the dilated k = 3 / 7 / 11 ResBlock / AMPBlock convs of
- *                          launches that fill the chip (>= CUs / 2 workgroups: depends on batch size, clip length and the device's CU count),
+ *                          launches that fill the chip (>= one workgroup per CU: depends on batch size, clip length and the device's CU count),
  *                          direct sums otherwise; the fused (c1, c2) pairs of the narrow stages use Winograd whenever a kernel exists.  Default.
  *   FV_CONV_ALGO_DIRECT    direct sums everywhere.
  *   FV_CONV_ALGO_WINOGRAD  Winograd wherever a kernel exists, whatever the launch size.

@@ -992,7 +992,7 @@ def test_winograd_convs_against_the_direct_sums_and_the_oracle(model, monkeypatc
 def test_ragged_shards_against_the_global_batch_and_the_batch_invariant_switch():
     """Utterance sharding with a ragged split (37 one-second clips over 8 ranks: 5,5,5,5,5,4,4,4 — vocoder_amd.sharding.shard_slice; the
     reference's 8-device launch is configs/trainer/default.yaml:6-9).  The default engine chooses direct sums or Winograd tap groups per
-    LAUNCH (>= CUs / 2 workgroups), so a 4-clip shard and the 37-clip batch may add a clip's products in another order: the outputs agree to
+    LAUNCH (>= one workgroup per CU), so a 4-clip shard and the 37-clip batch may add a clip's products in another order: the outputs agree to
     <= 2e-5 of full scale (the parity bar is 1e-4).  With fv_set_batch_invariant every kernel choice follows from the layer shape alone and
     the shards equal the global batch — and a clip run alone — BIT FOR BIT; fv_set_conv_algorithm(direct) + batch-invariant likewise."""
     from vocoder_amd.sharding import shard_sizes, shard_slice

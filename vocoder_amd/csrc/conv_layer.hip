@@ -641,9 +641,11 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
 #endif
         const int mb = wdims[wcfg][0], pairs = wdims[wcfg][1];
         const long long blocks = blocks_of(wcfg);
-        // launches of at least half a workgroup per CU: measured per batch size (tools/sweep_wino_batch.py) — HiFiGAN-V1 B = 2 ... 32 -12 ... -16 %
-        // against the direct kernels with this gate, a single clip (86 workgroups at C = 128) +17 % without it
-        const long long min_blocks = knobs().wino_min_blocks >= 0 ? knobs().wino_min_blocks : num_cus() / 2;
+        // launches of at least one workgroup per CU (counted in the F(2,3) tiling above, whichever Winograd kernel the layer takes below): measured per batch size
+        // (tools/sweep_wino_batch.py, GATES=32,...,512).  Round 3: half a workgroup per CU; with the 128-row F(4,4) workgroups of round 4 a launch of 128 - 255 such
+        // blocks leaves CUs empty — gate 256 against 128: B = 6 2.43 / 2.76 ms, B = 8 3.10 / 3.23, B = 2 1.25 / 1.28, equal elsewhere; 512 loses at B = 3 - 4, 12 - 16.
+        // A single clip (86 blocks at C = 128) stays on the latency kernel either way
+        const long long min_blocks = knobs().wino_min_blocks >= 0 ? knobs().wino_min_blocks : num_cus();
         if (blocks >= min_blocks || algo == FV_CONV_ALGO_WINOGRAD || cur_invariant()) {
             // F(4,3) tap groups where the layer has whole 64-row tiles (conv_wino4_impl.h): the same gate, so one algorithm per layer whatever
             // the batch in batch-invariant mode
