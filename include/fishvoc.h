@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 3
+#define FV_ABI_VERSION 4
 
 /* every entry point below is exported with default visibility (the library is built -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -101,6 +101,12 @@ typedef struct fv_upsampler_config {
     int32_t use_template; /* 1: pitch-template noise_convs branch (the ctor default; every shipped YAML sets false) */
     int32_t pre_conv_kernel_size;
     int32_t post_conv_kernel_size;
+    /* `post_activation()` in front of conv_post (hifigan.py:150,213,245 — any nn.Module factory upstream; HiFiGAN only, BigVGAN has its own
+     * activation_post): an fv_act — FV_ACT_SILU is the reference default (partial(nn.SiLU, inplace=True)), FV_ACT_LEAKY_RELU with
+     * post_activation_slope covers nn.LeakyReLU(slope) of classic HiFi-GAN checkpoints and nn.ReLU (slope 0), FV_ACT_NONE nn.Identity,
+     * FV_ACT_GELU / FV_ACT_TANH their exact forms.  Anything else -> FV_ERR_UNSUPPORTED. */
+    int32_t post_activation;
+    float post_activation_slope;
 } fv_upsampler_config;
 
 /* ConvNeXtEncoder ctor kwargs (convnext.py:147-155); drop_path is identity in eval and not represented. */
@@ -112,12 +118,17 @@ typedef struct fv_convnext_config {
     int32_t kernel_size;
 } fv_convnext_config;
 
-/* ISTFTHead ctor kwargs (vocos.py:19-26); padding must be "same" (vocos.yaml:15). */
+/* ISTFTHead ctor kwargs (vocos.py:19-26).  padding: FV_ISTFT_SAME ("same", every shipped vocos YAML: output length T * hop) or
+ * FV_ISTFT_CENTER ("center": vocos 0.0.2 falls back to torch.istft(center=True) — frames overlap-added at t * hop, n_fft / 2 samples
+ * trimmed from both ends, output length (T - 1) * hop; torch raises when the window envelope has a zero there, here FV_ERR_INVALID
+ * at fv_finalize). */
+enum { FV_ISTFT_SAME = 0, FV_ISTFT_CENTER = 1 };
 typedef struct fv_istft_head_config {
     int32_t dim;
     int32_t n_fft;
     int32_t hop_length;
     int32_t win_length;
+    int32_t padding;
 } fv_istft_head_config;
 
 /* LogMelSpectrogram ctor kwargs (spectrogram.py:60-70); center must be 0 (the reference default), win_length == n_fft,

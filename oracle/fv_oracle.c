@@ -28,7 +28,7 @@
  *   fvo_gelu                 nn.GELU() exact erf form (convnext.py:114)
  *   fvo_scale_residual       gamma * x + input (convnext.py:134-141)
  *   fvo_istft_head_post      exp / clip / cos / sin of ISTFTHead (fish_vocoder/modules/generators/vocos.py:57-67)
- *   fvo_istft_same           vocos==0.0.2 spectral_ops.ISTFT(padding="same") (third-party, NOT in
+ *   fvo_istft_same / _crop   vocos==0.0.2 spectral_ops.ISTFT(padding="same" / "center") (third-party, NOT in
  *                            /root/reference; call sites vocos.py:3,33-38,69) — restated from the
  *                            package's published algorithm: PARITY UNPINNED for this piece.
  *
@@ -471,10 +471,11 @@ FVO_API void fvo_istft_head_post(const float* h, float* re, float* im, int B, in
  * crop pad=(win-hop)/2 both ends ; divide by the overlap-added window^2 envelope.  re/im: (B, NB, T) where
  * only the first n_fft/2+1 bins are read (torch.fft.irfft trims).  y: (B, T*hop).  Requires win == n_fft.
  * irfft is evaluated as a direct real DFT in double (the oracle favours obviousness over speed). */
-FVO_API void fvo_istft_same(const float* re, const float* im, float* y, int B, int NB, int T, int n_fft, int hop,
-                            int win) {
+/* pad = samples trimmed from both ends of the overlap-add: (win - hop) / 2 for padding="same" (vocos ISTFT.forward), n_fft / 2 for
+ * padding="center" (the package falls back to torch.istft(center=True): same frames, same window-envelope division, other trim) */
+FVO_API void fvo_istft_crop(const float* re, const float* im, float* y, int B, int NB, int T, int n_fft, int hop, int win,
+                            int pad) {
     const int nb = n_fft / 2 + 1;
-    const int pad = (win - hop) / 2;
     const int full = (T - 1) * hop + win;
     const int Tout = full - 2 * pad;
     double* window = (double*)malloc(sizeof(double) * win);
@@ -515,4 +516,9 @@ FVO_API void fvo_istft_same(const float* re, const float* im, float* y, int B, i
     free(env);
     free(ctab);
     free(stab);
+}
+
+FVO_API void fvo_istft_same(const float* re, const float* im, float* y, int B, int NB, int T, int n_fft, int hop,
+                            int win) {
+    fvo_istft_crop(re, im, y, B, NB, T, n_fft, hop, win, (win - hop) / 2);
 }

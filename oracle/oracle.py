@@ -66,6 +66,7 @@ def lib():
         L.fvo_scale_residual.argtypes = [_f, _f, _f, _f, _i, _i, _i]
         L.fvo_istft_head_post.argtypes = [_f, _f, _f, _i, _i, _i]
         L.fvo_istft_same.argtypes = [_f, _f, _f] + [_i] * 6
+        L.fvo_istft_crop.argtypes = [_f, _f, _f] + [_i] * 7
         _lib = L
         if "OMP_NUM_THREADS" not in os.environ:
             # default team size = the CPUs this process may actually use: the affinity mask capped by the container's cgroup CPU
@@ -221,6 +222,26 @@ def istft_same(re, im, n_fft, hop, win) -> np.ndarray:
     return y
 
 
+def istft_center(re, im, n_fft, hop, win) -> np.ndarray:
+    """vocos.spectral_ops.ISTFT(padding='center') = torch.istft(spec, n_fft, hop, win, window, center=True) on the n_fft/2+1 live bins
+    (a two-sided input of n_fft rows is cut to them before the c2r transform): the same windowed frames and envelope division as "same",
+    n_fft / 2 samples trimmed from both ends -> (T - 1) * hop samples; raises like torch when the envelope has a zero there."""
+    re, im = _c(re), _c(im)
+    B, NB, T = re.shape
+    assert win == n_fft, "the reference head always uses win_length == n_fft"
+    if T < 2:
+        raise RuntimeError("istft(center=True): a single frame leaves no samples")
+    w2 = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win) / win)).astype(np.float32).astype(np.float64) ** 2
+    env = np.zeros((T - 1) * hop + win)
+    for t in range(T):
+        env[t * hop:t * hop + win] += w2
+    if env[n_fft // 2:n_fft // 2 + (T - 1) * hop].min() < 1e-11:
+        raise RuntimeError("window overlap add min: 1")   # torch.istft's check
+    y = np.empty((B, (T - 1) * hop), np.float32)
+    lib().fvo_istft_crop(_p(re), _p(im), _p(y), B, NB, T, n_fft, hop, win, n_fft // 2)
+    return y
+
+
 # ------------------------------------------------------------------------------------------------
 # state-dict helpers (reference key names)
 # ------------------------------------------------------------------------------------------------
@@ -307,9 +328,17 @@ def hifigan_forward(sd, cfg, mel, collect=None, template=None) -> np.ndarray:
         x = np.mean(np.stack(outs, 0), axis=0, dtype=np.float32)
         if collect is not None:
             collect[f"resblocks.{i}"] = x
-    x = silu(x)                                                               # post_activation (hifigan.py:245)
+    x = _post_activation(cfg.get("post_activation", "silu"))(x)               # post_activation() (hifigan.py:150,213,245)
     x = conv1d(x, folded_weight(sd, "conv_post"), _bias(sd, "conv_post"), padding=_get_padding(qk))
     return tanh(x)
+
+
+def _post_activation(spec):
+    """cfg["post_activation"]: "silu" (the reference default, partial(nn.SiLU, inplace=True)), ("leaky_relu", slope), "relu", "gelu",
+    "tanh" or "identity" — the element-wise nn.Modules the drop-in accepts for `post_activation` (hifigan.py:150)."""
+    name, arg = (spec, None) if isinstance(spec, str) else (spec[0], spec[1])
+    return {"silu": silu, "leaky_relu": lambda x: leaky_relu(x, arg), "relu": lambda x: leaky_relu(x, 0.0), "gelu": gelu, "tanh": tanh,
+            "identity": lambda x: x}[name]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -361,6 +390,8 @@ def bigvgan_forward(sd, cfg, mel, collect=None) -> np.ndarray:
     for i, (u, k) in enumerate(zip(rates, uks)):
         x = conv_transpose1d(x, folded_weight(sd, f"ups.{i}"), _bias(sd, f"ups.{i}"),
                              stride=u, padding=(k - u) // 2)                  # no pre-activation (bigvgan.py:355-356)
+        if collect is not None:
+            collect[f"ups.{i}"] = x
         outs = [ampblock_forward(sd, f"resblocks.{i * nk + j}", x, rk, rd)
                 for j, (rk, rd) in enumerate(zip(rks, rds))]
         x = np.mean(np.stack(outs, 0), axis=0, dtype=np.float32)            # bigvgan.py:361-365
@@ -414,9 +445,10 @@ def istft_head_pre(sd, x):
 
 
 def istft_head_forward(sd, cfg, x) -> np.ndarray:
-    """ISTFTHead.forward (vocos.py:43-69) -> (B, T*hop)."""
+    """ISTFTHead.forward (vocos.py:43-69) -> (B, T*hop) (padding="same") / (B, (T-1)*hop) (padding="center")."""
     re, im = istft_head_pre(sd, x)
-    return istft_same(re, im, cfg["n_fft"], cfg["hop_length"], cfg["win_length"])
+    istft = istft_center if cfg.get("padding", "same") == "center" else istft_same
+    return istft(re, im, cfg["n_fft"], cfg["hop_length"], cfg["win_length"])
 
 
 def vocos_forward(sd, cfg, mel) -> np.ndarray:

@@ -485,3 +485,99 @@ def test_winograd_conv_offsets_beyond_2_gib(monkeypatch):
     finally:
         monkeypatch.delenv("FV_WINO", raising=False)
         _lib.reload_env()
+
+
+# ---- heavy-tailed weights: what trained weight-norm layers look like, not what a Gaussian initialiser draws ----
+def _heavy_tailed_weight(rng, c, k):
+    """A folded weight-norm layer w = g * v / ||v|| (hifigan.py:31) with the per-output-channel gain g log-uniform over 100 x and
+    0.4 % of the taps 30 x larger than their neighbours: the transforms of the Winograd kernels mix taps, so an outlier is added to
+    and subtracted from small values before the matrix product."""
+    v = rng.normal(size=(c, c, k))
+    hit = rng.random(size=v.shape) < 0.004
+    v = np.where(hit, 30.0 * v, v)
+    g = np.exp(rng.uniform(np.log(0.03), np.log(3.0), size=(c, 1, 1)))
+    return (g * v / np.sqrt((v * v).sum(axis=(1, 2), keepdims=True))).astype(np.float32)
+
+
+def _conv1d_f64(x, w, b, d):
+    """float64 direct sum of a 'same' dilated Conv1d (hifigan.py:36-57): the arbiter between two fp32 summation orders."""
+    B, C, T = x.shape
+    k = w.shape[2]
+    pad = (k - 1) * d // 2
+    xp = np.zeros((B, C, T + 2 * pad))
+    xp[:, :, pad:pad + T] = x
+    y = np.zeros((B, w.shape[0], T))
+    for j in range(k):
+        y += np.einsum("oi,bit->bot", w[:, :, j].astype(np.float64), xp[:, :, j * d:j * d + T])
+    return y + b.astype(np.float64)[None, :, None]
+
+
+def _silu64(x):
+    x = x.astype(np.float64)
+    return x / (1.0 + np.exp(-x))
+
+
+HEAVY_CASES = [
+    # (C, k, dil, B, T, kernel family the Winograd setting must dispatch)
+    (128, 11, 1, 2, 517, "conv_wino44<"), (128, 7, 3, 1, 700, "conv_wino44<"), (64, 11, 5, 2, 900, "conv_wino44<"), (256, 7, 1, 1, 260, "conv_wino44<"),
+    (256, 3, 1, 2, 200, "conv_wino<"), (32, 11, 3, 2, 1500, "conv_wino<"),
+]
+
+
+@pytest.mark.parametrize("c,k,d,B,T,family", HEAVY_CASES)
+def test_winograd_convs_with_heavy_tailed_weights_against_the_float64_sum(c, k, d, B, T, family, monkeypatch):
+    """The F(4,4) / F(2,3) tap-group kernels (conv_wino44_impl.h, conv_wino_impl.h) on a layer shaped like a TRAINED one — gains spread over
+    100 x, |w| outliers, input channels of unequal scale — against the float64 direct sum, next to the direct-sum kernel of the same layer:
+    bar 2e-5 of the output's scale (the model bar is 1e-4 absolute on a waveform in (-1, 1)), and the Winograd error within 4 x the direct
+    kernel's.  Reference: hifigan.py:101-108."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import FusedConv
+    rng = np.random.default_rng(c * 31 + k * 7 + d)
+    w = _heavy_tailed_weight(rng, c, k)
+    b = rng.normal(size=c).astype(np.float32)
+    x = (rng.normal(size=(B, c, T)) * np.exp(rng.uniform(np.log(0.3), np.log(3.0), size=(1, c, 1)))).astype(np.float32)
+    ref = _conv1d_f64(_silu64(x), w, b, d)
+    scale = float(np.abs(ref).max())
+    xd = torch.from_numpy(x).to(_dev())
+    monkeypatch.setenv("FV_WINO", "2")
+    _lib.reload_env()
+    try:
+        conv = FusedConv(w, b, dilation=d, padding=(k - 1) * d // 2, pre_act=_lib.FV_ACT_SILU)
+        yw = conv.set_algorithm("winograd")(xd).cpu().numpy()
+        assert _lib.last_kernel().startswith(family), _lib.last_kernel()
+        yd = conv.set_algorithm("direct")(xd).cpu().numpy()
+        assert _lib.last_kernel().startswith("conv_mfma<"), _lib.last_kernel()
+    finally:
+        monkeypatch.delenv("FV_WINO")
+        _lib.reload_env()
+    ew, ed = float(np.abs(yw - ref).max()), float(np.abs(yd - ref).max())
+    print(f"heavy-tailed C={c} k={k} d={d}: scale {scale:.2f}  winograd {ew:.2e}  direct {ed:.2e}  ratio {ew / max(ed, 1e-12):.2f}")
+    assert ew <= 2e-5 * max(scale, 1.0), (ew, scale)
+    assert ew <= 4.0 * ed + 1e-6 * max(scale, 1.0), (ew, ed)
+
+
+@pytest.mark.parametrize("C,k,d", [(16, 3, 1), (16, 11, 5), (32, 7, 3), (32, 11, 1), (64, 3, 3)])
+def test_winograd_pairs_with_heavy_tailed_weights_against_the_float64_sum(C, k, d):
+    """The fused (c1, c2) Winograd pairs (pair_wino_impl.h) on heavy-tailed layers against x + c2(silu(c1(silu(x)))) in float64, next to the
+    direct-sum pair kernel.  Reference: hifigan.py:102-107."""
+    from vocoder_amd.engine import FusedConv
+    rng = np.random.default_rng(C * 17 + k * 5 + d)
+    w1, w2 = _heavy_tailed_weight(rng, C, k), _heavy_tailed_weight(rng, C, k)
+    b1, b2 = rng.normal(size=C).astype(np.float32), rng.normal(size=C).astype(np.float32)
+    B, T = 2, 2100
+    x = (rng.normal(size=(B, C, T)) * np.exp(rng.uniform(np.log(0.3), np.log(3.0), size=(1, C, 1)))).astype(np.float32)
+    nb = min(B, 2)
+    xt = _conv1d_f64(_silu64(x[:nb]), w1, b1, d)
+    ref = x[:nb].astype(np.float64) + _conv1d_f64(_silu64(xt), w2, b2, 1)
+    scale = float(np.abs(ref).max())
+    c1 = FusedConv(w1, b1, dilation=d, padding=(k * d - d) // 2)
+    c2 = FusedConv(w2, b2, padding=(k - 1) // 2)
+    xd = torch.from_numpy(x).to(_dev())
+    yw = c1.set_algorithm("auto").pair(c2, xd)[:nb].cpu().numpy()
+    assert _last_kernel().startswith("pair_wino<"), _last_kernel()
+    yd = c1.set_algorithm("direct").pair(c2, xd)[:nb].cpu().numpy()
+    assert _last_kernel().startswith("resblock_pair<"), _last_kernel()
+    ew, ed = float(np.abs(yw - ref).max()), float(np.abs(yd - ref).max())
+    print(f"heavy-tailed pair C={C} k={k} d={d}: scale {scale:.2f}  winograd {ew:.2e}  direct {ed:.2e}  ratio {ew / max(ed, 1e-12):.2f}")
+    assert ew <= 2e-5 * max(scale, 1.0), (ew, scale)
+    assert ew <= 4.0 * ed + 1e-6 * max(scale, 1.0), (ew, ed)

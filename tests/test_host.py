@@ -27,13 +27,13 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_config_struct_layout_matches_header():
     # int32 fields only, so sizeof is a good canary for drift between fishvoc.h and the ctypes mirror
-    assert ctypes.sizeof(_lib.UpsamplerConfig) == 4 * (2 + 8 + 8 + 1 + 8 + 24 + 5)
+    assert ctypes.sizeof(_lib.UpsamplerConfig) == 4 * (2 + 8 + 8 + 1 + 8 + 24 + 5 + 2)
     assert ctypes.sizeof(_lib.ConvNeXtConfig) == 4 * (2 + 8 + 8 + 1)
-    assert ctypes.sizeof(_lib.IstftHeadConfig) == 16
+    assert ctypes.sizeof(_lib.IstftHeadConfig) == 20
     assert ctypes.sizeof(_lib.ConvDesc) == 40
     assert ctypes.sizeof(_lib.LogMelConfig) == 28
     assert ctypes.sizeof(_lib.RefineGANConfig) == 4 * (2 + 8 + 8 + 3)
-    assert ctypes.sizeof(_lib.Config) == (8 + ctypes.sizeof(_lib.UpsamplerConfig) + ctypes.sizeof(_lib.ConvNeXtConfig) + 16 + 28 +
+    assert ctypes.sizeof(_lib.Config) == (8 + ctypes.sizeof(_lib.UpsamplerConfig) + ctypes.sizeof(_lib.ConvNeXtConfig) + 20 + 28 +
                                           ctypes.sizeof(_lib.RefineGANConfig))
 
 

@@ -88,6 +88,38 @@ def test_hifigan_template_branch_matches_reference():
     _close(orc.hifigan_forward(sd, g["cfg"], g["mel"], template=g["template"]), g["out"], 2e-5)
 
 
+POST_ACTS = [("leaky_relu", ("leaky_relu", 0.1)), ("relu", "relu"), ("gelu", "gelu"), ("tanh", "tanh"), ("identity", "identity")]
+
+
+@pytest.mark.parametrize("tag,spec", POST_ACTS)
+def test_hifigan_post_activation_matches_reference(tag, spec):
+    """HiFiGANGenerator(post_activation=...) (hifigan.py:150,213,245): nn.LeakyReLU(0.1) — classic HiFi-GAN checkpoints —, nn.ReLU, nn.GELU,
+    nn.Tanh, nn.Identity in front of conv_post, captured from the reference class."""
+    g = load_golden("hifigan_post_activation.npz")
+    sd = syn.hifigan_state_dict(g["cfg"], g["seed"])
+    y = orc.hifigan_forward(sd, dict(g["cfg"], post_activation=spec), g["mel"])
+    _close(y, g[f"out_{tag}"], 2e-5)
+    if tag != "identity":   # the captures differ from one another: the activation is really applied
+        assert np.abs(g[f"out_{tag}"] - g["out_identity"]).max() > 1e-3
+
+
+def test_istft_center_matches_torch_istft():
+    """ISTFTHead(padding="center") (vocos.py:19-38): the package hands the spectrum to torch.istft(center=True); the capture is torch's own
+    output (pinned), length (T - 1) * hop."""
+    g = load_golden("istft_head_center.npz")
+    cfg = g["cfg"]
+    assert cfg["padding"] == "center" and bool(g["pinned_wave"])
+    sd = syn.istft_head_state_dict(cfg, g["seed"])
+    re, im = orc.istft_head_pre(sd, g["x"])
+    _close(re, g["re"], 2e-5, 1e-5)
+    y = orc.istft_center(g["re"], g["im"], cfg["n_fft"], cfg["hop_length"], cfg["win_length"])
+    assert y.shape == g["wave"].shape == (2, 8 * cfg["hop_length"])
+    _close(y, g["wave"], 2e-5, 1e-5)
+    _close(orc.istft_head_forward(sd, cfg, g["x"]), g["wave"], 2e-5, 1e-5)
+    with pytest.raises(RuntimeError):
+        orc.istft_center(g["re"][:, :, :1], g["im"][:, :, :1], cfg["n_fft"], cfg["hop_length"], cfg["win_length"])
+
+
 def test_convnext_forward_matches_reference():
     g = load_golden("convnext_small.npz")
     sd = syn.convnext_state_dict(g["cfg"], g["seed"])

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # FV_LIB_PATH points the loader at an experimental build (A/B kernel variants); default = the in-tree library
 LIB_PATH = os.environ.get("FV_LIB_PATH") or os.path.join(CSRC, "libfishvoc_hip.so")
 
-FV_ABI_VERSION = 3
+FV_ABI_VERSION = 4
 FV_MAX_STAGES = 8
 FV_MAX_KERNELS = 8
 FV_MAX_DILATIONS = 3
@@ -26,6 +26,7 @@ FV_PRECISION_F32, FV_PRECISION_F16X3 = 0, 1
 PRECISIONS = {"f32": FV_PRECISION_F32, "f16x3": FV_PRECISION_F16X3}
 FV_CONV_ALGO_AUTO, FV_CONV_ALGO_DIRECT, FV_CONV_ALGO_WINOGRAD = 0, 1, 2
 CONV_ALGOS = {"auto": FV_CONV_ALGO_AUTO, "direct": FV_CONV_ALGO_DIRECT, "winograd": FV_CONV_ALGO_WINOGRAD}
+FV_ISTFT_SAME, FV_ISTFT_CENTER = 0, 1
 FV_ACT_NONE, FV_ACT_SILU, FV_ACT_LEAKY_RELU, FV_ACT_GELU, FV_ACT_TANH, FV_ACT_LOG_CLAMP = 0, 1, 2, 3, 4, 5
 
 EXPORTS = (
@@ -48,6 +49,7 @@ class UpsamplerConfig(ctypes.Structure):
         ("resblock_dilation_sizes", (_i32 * FV_MAX_DILATIONS) * FV_MAX_KERNELS),
         ("num_mels", _i32), ("upsample_initial_channel", _i32), ("use_template", _i32),
         ("pre_conv_kernel_size", _i32), ("post_conv_kernel_size", _i32),
+        ("post_activation", _i32), ("post_activation_slope", ctypes.c_float),
     ]
 
 
@@ -57,7 +59,7 @@ class ConvNeXtConfig(ctypes.Structure):
 
 
 class IstftHeadConfig(ctypes.Structure):
-    _fields_ = [("dim", _i32), ("n_fft", _i32), ("hop_length", _i32), ("win_length", _i32)]
+    _fields_ = [("dim", _i32), ("n_fft", _i32), ("hop_length", _i32), ("win_length", _i32), ("padding", _i32)]
 
 
 class LogMelConfig(ctypes.Structure):

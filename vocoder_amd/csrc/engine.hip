@@ -319,6 +319,26 @@ struct IstftHeadModel {
     ConvLayer idft;   // (n_fft) x (2*nb) windowed inverse real-DFT basis as a 1x1 conv
     float* d_win2 = nullptr;
     int nb = 0;
+    std::vector<float> win2;   // window^2 on the host: the envelope check of padding="center"
+    bool center() const { return cfg.padding == FV_ISTFT_CENTER; }
+    int64_t out_len(int T) const { return center() ? (int64_t)(T - 1) * cfg.hop_length : (int64_t)T * cfg.hop_length; }
+    int crop() const { return center() ? cfg.n_fft / 2 : (cfg.win_length - cfg.hop_length) / 2; }
+    // torch.istft(center=True) raises "window overlap add min" when the overlap-added window^2 is below 1e-11 anywhere in the samples
+    // it keeps (vocos 0.0.2 ISTFT.forward falls back to it for padding="center").  The envelope's edge regions repeat for every T
+    // beyond a few window lengths, so a short frame count decides it.
+    bool center_envelope_ok(int T) const {
+        const int N = cfg.n_fft, hop = cfg.hop_length;
+        const int Tc = std::min(T, 2 * ((N + hop - 1) / hop) + 2);
+        const int64_t L = (int64_t)(Tc - 1) * hop;
+        for (int64_t q = 0; q < L; ++q) {
+            const int64_t pos = q + N / 2;   // position in the un-trimmed overlap-add
+            double env = 0.0;
+            for (int64_t t = std::max<int64_t>(0, (pos - N + hop) / hop); t < Tc && t * hop <= pos; ++t)
+                if (pos - t * hop < N) env += win2[(size_t)(pos - t * hop)];
+            if (!(env >= 1e-11)) return false;
+        }
+        return true;
+    }
     void destroy() {
         conv_layer_destroy(out);
         conv_layer_destroy(idft);
@@ -773,6 +793,7 @@ fv_status fv_engine::build_head(const std::string& pfx) {
     std::vector<float> win2(N);
     for (int n = 0; n < N; ++n) win2[n] = win[n] * win[n];
     if ((st = upload(win2, &head.d_win2))) return st;
+    head.win2 = win2;
     has_head = true;
     return FV_OK;
 }
@@ -1024,7 +1045,8 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
     }
     // activation_post -> conv_post -> tanh (hifigan.py:245-247 / bigvgan.py:367-369)
     const float* post_in = cur;
-    int pre = FV_ACT_SILU;
+    int pre = ups.cfg.post_activation;   // post_activation() (hifigan.py:213,245): SiLU by default
+    const float pre_slope = ups.cfg.post_activation_slope;
     if (ups.bigvgan) {
         // (XA(0) is free again: every branch has joined)
         FV_PROF(s, post_sum3 ? "aa_snake sum3" : "aa_snake", 60.0 * B * ups.post_cin * t, (post_sum3 ? 16.0 : 8.0) * B * ups.post_cin * t,
@@ -1037,13 +1059,13 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
     const int qk = ups.cfg.post_conv_kernel_size;
     if (post_sum3) {
         FV_PROF(s, "conv_post_narrow sum3", 2.0 * B * ups.post_cin * qk * t, 4.0 * B * (3 * ups.post_cin + 1) * t,
-                launch_conv_narrow(XB(0), ups.d_wpost, ups.d_bpost, d_out, B, ups.post_cin, t, 1, qk, get_padding(qk), pre, FV_ACT_TANH, 0.f,
+                launch_conv_narrow(XB(0), ups.d_wpost, ups.d_bpost, d_out, B, ups.post_cin, t, 1, qk, get_padding(qk), pre, FV_ACT_TANH, pre_slope,
                                    s, XB(1), XB(2)));
         return FV_OK;
     }
     FV_PROF(s, "conv_post_narrow", 2.0 * B * ups.post_cin * qk * t, 4.0 * B * (ups.post_cin + 1) * t,
             launch_conv_narrow(post_in, ups.d_wpost, ups.d_bpost, d_out, B, ups.post_cin, t, 1, qk, get_padding(qk), pre,
-                               FV_ACT_TANH, 0.f, s));
+                               FV_ACT_TANH, pre_slope, s));
     return FV_OK;
 }
 
@@ -1128,9 +1150,9 @@ fv_status fv_engine::run_head(const float* d_in, float* d_out, int B, int T, flo
     r.x = Sp;
     r.y = Fr;
     if ((st = conv_layer_run(head.idft, r, s))) return st;
-    const int pad = (head.cfg.win_length - head.cfg.hop_length) / 2;
-    FV_PROF(s, "istft_ola", 2.0 * B * N * T, 4.0 * B * (N * (double)T + (double)T * head.cfg.hop_length),
-            launch_istft_ola(Fr, head.d_win2, d_out, B, N, T, head.cfg.hop_length, pad, s));
+    // "same": crop (win - hop) / 2 -> T * hop samples (vocos ISTFT); "center": crop n_fft / 2 -> (T - 1) * hop (torch.istft(center=True))
+    FV_PROF(s, "istft_ola", 2.0 * B * N * T, 4.0 * B * (N * (double)T + (double)head.out_len(T)),
+            launch_istft_ola(Fr, head.d_win2, d_out, B, N, T, head.cfg.hop_length, head.crop(), head.out_len(T), s));
     return FV_OK;
 }
 
@@ -1275,6 +1297,15 @@ static fv_status validate_ups(const fv_upsampler_config& c) {
         set_error("invalid num_mels / upsample_initial_channel / pre,post kernel sizes (must be odd)");
         return FV_ERR_INVALID;
     }
+    if (c.post_activation != FV_ACT_NONE && c.post_activation != FV_ACT_SILU && c.post_activation != FV_ACT_LEAKY_RELU &&
+        c.post_activation != FV_ACT_GELU && c.post_activation != FV_ACT_TANH) {
+        set_error("post_activation %d: only nn.Identity / nn.SiLU / nn.LeakyReLU / nn.ReLU / nn.GELU / nn.Tanh have a kernel form", c.post_activation);
+        return FV_ERR_UNSUPPORTED;
+    }
+    if (!(c.post_activation_slope == c.post_activation_slope) || (c.post_activation != FV_ACT_LEAKY_RELU && c.post_activation_slope != 0.f)) {
+        set_error("post_activation_slope must be a number, and 0 unless post_activation is FV_ACT_LEAKY_RELU");
+        return FV_ERR_INVALID;
+    }
     for (int j = 0; j < c.num_kernels; ++j) {
         if (c.resblock_kernel_sizes[j] < 1 || c.resblock_kernel_sizes[j] % 2 == 0) {
             set_error("resblock kernel size %d must be odd", c.resblock_kernel_sizes[j]);
@@ -1316,10 +1347,10 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
         case FV_MODEL_ISTFT_HEAD:
             if (cfg->head.win_length != cfg->head.n_fft || cfg->head.hop_length < 1 || cfg->head.n_fft < 2 ||
                 cfg->head.n_fft % 2 || cfg->head.hop_length > cfg->head.win_length || cfg->head.dim < 1 ||
-                (cfg->head.win_length - cfg->head.hop_length) % 2 ||
+                (cfg->head.win_length - cfg->head.hop_length) % 2 || (cfg->head.padding != FV_ISTFT_SAME && cfg->head.padding != FV_ISTFT_CENTER) ||
                 (cfg->model == FV_MODEL_VOCOS &&
                  cfg->head.dim != cfg->backbone.dims[cfg->backbone.num_stages > 0 ? cfg->backbone.num_stages - 1 : 0])) {
-                set_error("istft head: need even n_fft == win_length >= hop_length, even (win-hop), dim == backbone dims[-1]");
+                set_error("istft head: need even n_fft == win_length >= hop_length, even (win-hop), padding same / center, dim == backbone dims[-1]");
                 st = FV_ERR_INVALID;
             }
             break;
@@ -1521,7 +1552,7 @@ FV_API int64_t fv_output_length(const fv_engine* e, int32_t t_in) {
         case FV_MODEL_BIGVGAN:
         case FV_MODEL_FIREFLY: return e->ups.out_len(t_in);
         case FV_MODEL_VOCOS:
-        case FV_MODEL_ISTFT_HEAD: return (int64_t)t_in * e->cfg.head.hop_length;
+        case FV_MODEL_ISTFT_HEAD: return e->head.out_len(t_in);
         case FV_MODEL_LOGMEL: return std::max(0, e->mel.frames(t_in));
         case FV_MODEL_REFINEGAN: return (int64_t)t_in * e->cfg.refine.hop_length;
         default: return t_in;
@@ -1635,6 +1666,16 @@ static fv_status forward_common(fv_engine* e, const float* d_in, const float* d_
     if (!d_workspace || workspace_bytes < need) {
         set_error("fv_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
         return FV_ERR_INVALID;
+    }
+    if ((e->cfg.model == FV_MODEL_VOCOS || e->cfg.model == FV_MODEL_ISTFT_HEAD) && e->head.center()) {
+        if (t_in < 2) {   // (T - 1) * hop = 0 samples: torch.istft fails on the empty envelope
+            set_error("istft head, padding=\"center\": %d frame(s) leave no output samples ((T - 1) * hop)", t_in);
+            return FV_ERR_INVALID;
+        }
+        if (!e->head.center_envelope_ok(t_in)) {
+            set_error("istft head, padding=\"center\": window overlap add min < 1e-11 (torch.istft raises here too)");
+            return FV_ERR_INVALID;
+        }
     }
     const bool wants_template = e->cfg.model == FV_MODEL_REFINEGAN ||
                                 ((e->cfg.model == FV_MODEL_HIFIGAN || e->cfg.model == FV_MODEL_BIGVGAN || e->cfg.model == FV_MODEL_FIREFLY) &&

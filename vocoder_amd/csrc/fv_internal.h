@@ -330,7 +330,7 @@ fv_status launch_magnitude(const float* spec, float* mag, int B, int nb, int T, 
 // rows [0,nb) = Re, [nbp, nbp+nb) = Im, zero padded to nbp = round_up(nb, 8)
 fv_status launch_istft_spec(const float* h, float* spec, int B, int n_fft, int T, int nb, int nbp, hipStream_t s);
 // frames (B, n_fft, T) (already windowed by the synthesis basis) -> overlap-add, crop, divide by the envelope.
-fv_status launch_istft_ola(const float* frames, const float* inv_env, float* y, int B, int n_fft, int T, int hop, int pad,
+fv_status launch_istft_ola(const float* frames, const float* inv_env, float* y, int B, int n_fft, int T, int hop, int pad, long long out_len,
                            hipStream_t s);
 
 

@@ -950,7 +950,7 @@ fv_status launch_istft_spec(const float* h, float* spec, int B, int n_fft, int T
 // along r.  win2 = window^2 (n_fft).
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ win2,
                                                         float* __restrict__ y, int n_fft, int T, int hop, int pad,
-                                                        int r_tiles, int tau_tiles) {
+                                                        long long out_len, int r_tiles, int tau_tiles) {
     __shared__ float tile[32][33];
     int bid = blockIdx.x;
     const int tt = bid % tau_tiles;
@@ -959,7 +959,6 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
     const int b = bid / r_tiles;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const float* fb = frames + (long long)b * n_fft * T;
-    const long long out_len = (long long)T * hop;
     const int n_tau = T + (n_fft + hop - 1) / hop;  // hop-frames touched by any analysis frame
     for (int rr = ty; rr < 32; rr += 8) {
         const int r = rt * 32 + rr, tau = tt * 32 + tx;
@@ -986,12 +985,12 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 }
 
 fv_status launch_istft_ola(const float* frames, const float* win2, float* y, int B, int n_fft, int T, int hop, int pad,
-                           hipStream_t s) {
+                           long long out_len, hipStream_t s) {
     const int r_tiles = (hop + 31) / 32;
     const int n_tau = T + (n_fft + hop - 1) / hop;
     const int tau_tiles = (n_tau + 31) / 32;
     hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((long long)B * r_tiles * tau_tiles)), dim3(256), 0, s, frames,
-                       win2, y, n_fft, T, hop, pad, r_tiles, tau_tiles);
+                       win2, y, n_fft, T, hop, pad, out_len, r_tiles, tau_tiles);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
 }

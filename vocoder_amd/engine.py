@@ -25,9 +25,32 @@ def _stream_ptr(device) -> int:
     return int(torch.cuda.current_stream(device).cuda_stream)
 
 
+def post_activation_to_act(act) -> tuple[int, float]:
+    """``post_activation()`` of the reference ctor (hifigan.py:150,213: any nn.Module factory) -> (fv_act, slope).  The element-wise modules
+    that have a kernel form map onto ``fv_act``; anything else raises NotImplementedError naming what is accepted."""
+    from torch import nn
+    if act is None or isinstance(act, nn.Identity):
+        return _lib.FV_ACT_NONE, 0.0
+    if isinstance(act, nn.SiLU):
+        return _lib.FV_ACT_SILU, 0.0
+    if isinstance(act, nn.LeakyReLU):
+        return _lib.FV_ACT_LEAKY_RELU, float(act.negative_slope)
+    if isinstance(act, nn.ReLU):
+        return _lib.FV_ACT_LEAKY_RELU, 0.0
+    if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none":
+        return _lib.FV_ACT_GELU, 0.0
+    if isinstance(act, nn.Tanh):
+        return _lib.FV_ACT_TANH, 0.0
+    raise NotImplementedError(
+        f"post_activation {act!r}: the engine applies nn.SiLU (reference default, hifigan.py:150), nn.LeakyReLU(slope), nn.ReLU, "
+        "nn.GELU() (exact), nn.Tanh or nn.Identity in front of conv_post")
+
+
 def upsampler_config(*, hop_length, upsample_rates, upsample_kernel_sizes, resblock_kernel_sizes,
                      resblock_dilation_sizes, num_mels, upsample_initial_channel, use_template=False,
-                     pre_conv_kernel_size=7, post_conv_kernel_size=7) -> _lib.UpsamplerConfig:
+                     pre_conv_kernel_size=7, post_conv_kernel_size=7, post_activation=_lib.FV_ACT_SILU,
+                     post_activation_slope=0.0) -> _lib.UpsamplerConfig:
+    """``post_activation`` / ``post_activation_slope``: an ``fv_act`` and its slope (see ``post_activation_to_act``)."""
     c = _lib.UpsamplerConfig()
     if len(upsample_rates) != len(upsample_kernel_sizes):
         raise ValueError("upsample_rates and upsample_kernel_sizes differ in length")
@@ -52,6 +75,8 @@ def upsampler_config(*, hop_length, upsample_rates, upsample_kernel_sizes, resbl
     c.use_template = int(bool(use_template))
     c.pre_conv_kernel_size = int(pre_conv_kernel_size)
     c.post_conv_kernel_size = int(post_conv_kernel_size)
+    c.post_activation = int(post_activation)
+    c.post_activation_slope = float(post_activation_slope)
     return c
 
 
@@ -67,10 +92,13 @@ def convnext_config(*, input_channels, depths, dims, kernel_size=7, **_ignored) 
 
 
 def istft_head_config(*, dim, n_fft, hop_length, win_length, padding="same") -> _lib.IstftHeadConfig:
-    if padding != "same":
-        raise NotImplementedError("ISTFTHead: only padding='same' is in scope (every shipped vocos YAML uses it)")
+    """ISTFTHead ctor kwargs (vocos.py:19-26).  ``padding``: "same" (output T * hop) or "center" (vocos 0.0.2 falls back to
+    ``torch.istft(center=True)``: output (T - 1) * hop); anything else raises the package's ValueError."""
+    if padding not in ("same", "center"):
+        raise ValueError("Padding must be 'center' or 'same'.")   # vocos.spectral_ops.ISTFT.__init__
     c = _lib.IstftHeadConfig()
     c.dim, c.n_fft, c.hop_length, c.win_length = int(dim), int(n_fft), int(hop_length), int(win_length)
+    c.padding = _lib.FV_ISTFT_CENTER if padding == "center" else _lib.FV_ISTFT_SAME
     return c
 
 
@@ -202,6 +230,8 @@ class Engine:
         if T == 0:   # the reference fails here too: conv_pre's kernel is wider than the padded input
             raise ValueError(f"empty input {tuple(x.shape)}")
         L = self.output_length(T)
+        if L <= 0:   # ISTFTHead(padding="center") on a single frame: (T - 1) * hop = 0 samples (torch.istft fails there too)
+            raise ValueError(f"input {tuple(x.shape)} leaves no output samples")
         if B == 0:   # an empty batch is a valid (empty) result upstream: nothing to launch
             return out if out is not None else torch.empty((0, self.out_channels, L), dtype=torch.float32, device=x.device)
         if out is None:

@@ -17,7 +17,7 @@ from torch.nn.utils.parametrizations import weight_norm
 
 from .. import _base
 from ... import _lib
-from ...engine import Engine, upsampler_config
+from ...engine import Engine, post_activation_to_act, upsampler_config
 
 
 def get_padding(kernel_size: int, dilation: int = 1) -> int:
@@ -91,8 +91,7 @@ class HiFiGANGenerator(_base.EngineModule):
         super().__init__()
         assert prod(upsample_rates) == hop_length, f"hop_length must be {prod(upsample_rates)}"
         act = post_activation()
-        if not isinstance(act, nn.SiLU):
-            raise NotImplementedError("post_activation must be nn.SiLU (the reference default, hifigan.py:150)")
+        fv_act, slope = post_activation_to_act(act)   # raises for modules without a kernel form
         self.activation_post = act  # no parameters; kept for repr/state parity
         self.use_template = bool(use_template)
         self.num_upsamples = len(upsample_rates)
@@ -102,7 +101,8 @@ class HiFiGANGenerator(_base.EngineModule):
             upsample_kernel_sizes=list(upsample_kernel_sizes), resblock_kernel_sizes=list(resblock_kernel_sizes),
             resblock_dilation_sizes=[list(d) for d in resblock_dilation_sizes], num_mels=num_mels,
             upsample_initial_channel=upsample_initial_channel, use_template=self.use_template,
-            pre_conv_kernel_size=pre_conv_kernel_size, post_conv_kernel_size=post_conv_kernel_size)
+            pre_conv_kernel_size=pre_conv_kernel_size, post_conv_kernel_size=post_conv_kernel_size,
+            post_activation=fv_act, post_activation_slope=slope)
 
         c0 = upsample_initial_channel
         self.conv_pre = weight_norm(nn.Conv1d(num_mels, c0, pre_conv_kernel_size, padding=get_padding(pre_conv_kernel_size)))

@@ -1,7 +1,7 @@
 """Drop-in for ``fish_vocoder.modules.generators.vocos.ISTFTHead`` (reference vocos.py:6-69).
 
 Keys: ``out.{weight,bias}`` (Conv1d(dim, 2*n_fft, 1)) and the ``istft.window`` buffer.  ``forward`` returns the 2-D
-``(B, T * hop_length)`` waveform like the reference; ``template=`` is accepted and ignored so that
+``(B, T * hop_length)`` waveform like the reference (``padding="center"``: ``(B, (T - 1) * hop_length)``, torch.istft's length); ``template=`` is accepted and ignored so that
 ``UnifyGenerator`` can call ``head(x, template=template)`` (the reference raises TypeError there).
 Engine side: only the n_fft/2+1 live rows of the 1x1 conv are computed, the inverse real DFT runs as an fp32-MFMA GEMM
 against a window-folded basis, followed by a fused overlap-add / envelope kernel.
@@ -27,7 +27,7 @@ class ISTFTHead(_base.EngineModule):
         super().__init__()
         self.n_fft, self.hop_length, self.win_length = n_fft, hop_length, win_length
         self._cfg = dict(dim=dim, n_fft=n_fft, hop_length=hop_length, win_length=win_length, padding=padding)
-        istft_head_config(**self._cfg)  # validates padding == "same"
+        istft_head_config(**self._cfg)  # validates padding ("same" | "center")
         self.istft = _IstftBuffers(win_length)
         self.out = nn.Conv1d(dim, n_fft * 2, 1)
 
