@@ -450,6 +450,7 @@ def _main(a, real_stdout):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist, rccl_error = None, None
+    t_pg = time.perf_counter()
     try:
         dist = init_dist(dev)                               # RCCL over xGMI; a 1-rank group at N = 1
     except Exception as exc:  # noqa: BLE001
@@ -457,12 +458,18 @@ def _main(a, real_stdout):
             raise
         rccl_error = f"{type(exc).__name__}: {exc}"         # N = 1 keeps its headline line without the process group
     ranks = dist.get_world_size() if dist is not None else 1
+    t_pg = time.perf_counter() - t_pg
 
     cfg = dict(syn.HIFIGAN_V1_44K)
     sd = syn.hifigan_state_dict(cfg, seed=0) if rank == 0 else None
+    t_bc = None
     if dist is not None:
         from vocoder_amd.sharding import broadcast_state_dict
+        dist.barrier()                                           # (rank 0 alone builds the state dict: its time is not the broadcast's)
+        t_bc = time.perf_counter()
         sd_eng = broadcast_state_dict(sd, src=0, device=dev)    # one-time weight fan-out (56 MB) over RCCL
+        torch.cuda.synchronize(dev)
+        t_bc = time.perf_counter() - t_bc
     else:
         sd_eng = sd
     eng = Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**cfg), state_dict=sd_eng, precision=a.precision)
@@ -500,11 +507,23 @@ def _main(a, real_stdout):
     for _ in range(a.warmup):
         eng(mel, out)
     fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(a.steps):
         eng(mel, out)
+    ev1.record()
     fence()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    local = time.perf_counter() - t0
+    elapsed = max_over_ranks(local)
+    # Self-diagnosis of the N > 1 line: every rank's own step time by its own GPU clock (hipEvents around its K steps, before
+    # the closing barrier) and by the host clock, the one-time weight fan-out, the process-group start-up and the environment the transport depends
+    # on — so that the first 8-GPU curve the driver measures explains itself (a slow rank, a slow link, a missing IPC mode).  No efficiency figure.
+    mine = torch.tensor([ev0.elapsed_time(ev1) / a.steps, local / a.steps * 1e3, (t_bc or 0.0) * 1e3, t_pg * 1e3], dtype=torch.float64, device=dev)
+    per_rank = [mine.clone() for _ in range(ranks)] if dist is not None else [mine]
+    if dist is not None:
+        dist.all_gather(per_rank, mine)
+    per_rank = [[float(v) for v in t.tolist()] for t in per_rank]
 
     ok = bool(torch.isfinite(out).all().item()) and float(out.abs().max().item()) <= 1.0
 
@@ -588,6 +607,10 @@ def _main(a, real_stdout):
                 lat.append((time.perf_counter() - t1) * 1e3)
             return lat
         lat = p_lat()
+        eng.set_batch_invariant(True)    # what the bit-reproducible mode costs a single clip
+        lat_inv = p_lat()
+        eng.set_batch_invariant(False)
+        p_lat(5)
         eng.set_graph_replay(False)
         lat_eager = p_lat()
         # what a server sees: the B = 32 step with graph replay off, and a stream of forwards whose shapes keep changing and
@@ -614,6 +637,7 @@ def _main(a, real_stdout):
                        "global_batch": B * world, "parallelism": f"utterance-shard x{world}"},
             "x_realtime": value / SAMPLE_RATE, "x_realtime_per_gpu": value / SAMPLE_RATE / world,
             "p50_clip_latency_ms": float(np.percentile(lat, 50)), "p90_clip_latency_ms": float(np.percentile(lat, 90)),
+            "p50_clip_latency_batch_invariant_ms": float(np.percentile(lat_inv, 50)),
             "p50_clip_latency_eager_ms": float(np.percentile(lat_eager, 50)),
             "p90_clip_latency_eager_ms": float(np.percentile(lat_eager, 90)),
             "ms_per_step_eager": eager_step * 1e3,
@@ -621,6 +645,17 @@ def _main(a, real_stdout):
             "output_finite": ok,
             "roofline": roofline_from_profile(table, repeats),
         }
+        gpu_ms = [r[0] for r in per_rank]
+        result["multi_gpu"] = {
+            "ranks": ranks, "per_rank_ms_per_step_gpu_clock": gpu_ms, "per_rank_ms_per_step_host_clock": [r[1] for r in per_rank],
+            "ms_per_step_min": min(gpu_ms), "ms_per_step_max": max(gpu_ms), "slowest_rank": int(np.argmax(gpu_ms)),
+            "weight_broadcast_ms_per_rank": [r[2] for r in per_rank] if dist is not None else None,
+            "weight_broadcast_bytes": int(sum(int(np.asarray(v).size) for v in sd.values()) * 4),
+            "process_group_init_ms_per_rank": [r[3] for r in per_rank],
+            "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_SOCKET_IFNAME", "NCCL_P2P_DISABLE", "RCCL_MSCCL_ENABLE",
+                                                   "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "MASTER_ADDR", "OMP_NUM_THREADS")},
+            "device": torch.cuda.get_device_name(dev), "visible_devices": torch.cuda.device_count(),
+            "note": "per-rank figures are diagnostics for reading the scaling curve; `value` / `ms_per_step` above are the max-over-ranks contract"}
         if rccl_error:
             result["rccl_error"] = rccl_error
         # whole-step view next to the dominant-kernel one: algorithmic flops of the forward (55.97 GFLOP per

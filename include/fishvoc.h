@@ -193,15 +193,20 @@ FV_API fv_status fv_set_precision(fv_engine* e, int32_t precision);
 /* How the fp32 conv layers form their sums (FV_PRECISION_F32 only; no reference counterpart: torch picks its own convolution algorithm per
  * call).  Every choice computes in fp32 and stays well inside the parity bar (whole forwards differ by <= 2e-5 of full scale between them);
  * what changes is the LAST BITS of a clip's output and the speed:
- *   FV_CONV_ALGO_AUTO      per launch, whatever is fastest: Winograd F(2,3) tap groups for the dilated k = 3 / 7 / 11 ResBlock / AMPBlock convs of
- *                          launches that fill the chip (>= one workgroup per CU: depends on batch size, clip length and the device's CU count),
- *                          direct sums otherwise; the fused (c1, c2) pairs of the narrow stages use Winograd whenever a kernel exists.  Default.
+ *   FV_CONV_ALGO_AUTO      per launch, whatever is fastest.  The dilated k = 3 / 7 / 11 ResBlock / AMPBlock convs: launches that fill the chip (>= one
+ *                          workgroup per CU: depends on batch size, clip length and the device's CU count) run the throughput Winograd kernels — F(4,4) tap
+ *                          groups on the quad lattice for k = 7 / 11 on layers of whole 64-row tiles, F(2,3) on the pair lattice otherwise; launches below
+ *                          that gate (single clips, small batches) run the Winograd LATENCY kernel (F(2,3), K split over the waves), direct split-K sums
+ *                          where it has no instance; the fused (c1, c2) pairs of the narrow stages use Winograd whenever a kernel exists.  Default.
  *   FV_CONV_ALGO_DIRECT    direct sums everywhere.
- *   FV_CONV_ALGO_WINOGRAD  Winograd wherever a kernel exists, whatever the launch size.
- * fv_set_batch_invariant(e, 1) additionally makes EVERY kernel choice a function of the layer shape alone (C, k, dilation) — never of the
- * batch size, the clip length or the device partition: no split-K latency kernels, the fused pairs and the pointwise GEMM wherever their
+ *   FV_CONV_ALGO_WINOGRAD  the throughput Winograd kernels wherever one exists, whatever the launch size (never the latency kernel: single clips are
+ *                          slower than under AUTO).
+ * fv_set_batch_invariant(e, 1) additionally makes every choice BETWEEN DIFFERENT SUMS a function of the layer shape alone (C, k, dilation) — never of the
+ * batch size or the clip length: no split-K / latency kernels, the fused pairs and the pointwise GEMM wherever their
  * shape allows, and (under FV_CONV_ALGO_AUTO) Winograd wherever a kernel exists.  A clip's output is then bit-identical whichever other clips
- * share its batch — e.g. a 37-clip batch sharded 5/5/5/5/5/4/4/4 over 8 GPUs equals the single-GPU batch bit for bit — at the price of
+ * share its batch — e.g. a 37-clip batch sharded 5/5/5/5/5/4/4/4 over 8 GPUs equals the single-GPU batch bit for bit (tests pin HiFiGAN, BigVGAN,
+ * Vocos, Firefly and RefineGAN; the one launch-dependent choice left, pointwise GEMM vs the k = 1 conv kernel for batches past the 32-bit offset span or
+ * device partitions below 8 CUs, is between kernels that form the same sums: tests/test_gpu_conv.py) — at the price of
  * single-clip latency (the launch-size gates exist because small launches are faster on the direct / split-K kernels).  Without it, batches
  * that differ in size may differ in the last bits (<= 2e-5 of full scale; tests/test_gpu_models.py pins the bound).
  * Both may be called at any time; captured graphs are dropped. */

@@ -581,3 +581,69 @@ def test_winograd_pairs_with_heavy_tailed_weights_against_the_float64_sum(C, k, 
     print(f"heavy-tailed pair C={C} k={k} d={d}: scale {scale:.2f}  winograd {ew:.2e}  direct {ed:.2e}  ratio {ew / max(ed, 1e-12):.2f}")
     assert ew <= 2e-5 * max(scale, 1.0), (ew, scale)
     assert ew <= 4.0 * ed + 1e-6 * max(scale, 1.0), (ew, ed)
+
+
+@pytest.mark.parametrize("cin,cout,B,T", [(512, 256, 2, 86), (512, 256, 32, 86), (256, 128, 1, 100), (256, 128, 3, 517), (64, 32, 1, 7), (512, 256, 1, 3)])
+def test_stride8_upsampler_quad_stores_equal_the_single_stores(cin, cout, B, T, monkeypatch):
+    """the 16-byte-store epilogue of the stride-8 polyphase upsamplers (conv_mfma_impl.h conv_epilogue, p.vec_store) against the general
+    epilogue (FV_VEC_STORE=0) BIT for bit — ragged t_in, quads cropped by the transposed conv's padding at t < 0 and t >= Tout, the 128 x 96 / 128 x 128 /
+    narrow / small-launch tiles — with y 16-byte aligned and offset by 4 bytes (which must fall back to the general epilogue); both against the oracle.
+    Reference: ups[i] of hifigan.py:175-187,231 (k = 16, stride 8, padding 4)."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import FusedConv
+    k, u = 16, 8
+    rng = np.random.default_rng(cin + B * 7 + T)
+    x = rng.normal(size=(B, cin, T)).astype(np.float32)
+    w = (rng.normal(size=(cin, cout, k)) / np.sqrt(cin * 2)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    ref = orc.conv_transpose1d(orc.silu(x), w, b, stride=u, padding=(k - u) // 2)
+    xd = torch.from_numpy(x).to(_dev())
+    outs, kernels = {}, {}
+    try:
+        for vec in ("1", "0"):
+            monkeypatch.setenv("FV_VEC_STORE", vec)
+            _lib.reload_env()
+            conv = FusedConv(w, b, transposed=True, stride=u, padding=(k - u) // 2, pre_act=_lib.FV_ACT_SILU)
+            n = int(np.prod(ref.shape))
+            for off in (0, 1):
+                buf = torch.full((n + 8,), float("nan"), device=_dev())
+                assert buf.data_ptr() % 16 == 0
+                y = conv(xd, out=buf[off:off + n].view(*ref.shape))
+                torch.cuda.synchronize()
+                outs[(vec, off)] = y.cpu().numpy().copy()
+                kernels[(vec, off)] = _lib.last_kernel()
+                assert bool(torch.isnan(buf[:off]).all()) and bool(torch.isnan(buf[off + n:]).all())   # nothing outside the output
+    finally:
+        monkeypatch.delenv("FV_VEC_STORE", raising=False)
+        _lib.reload_env()
+    assert len(set(kernels.values())) == 1, kernels
+    _check(outs[("1", 0)], ref)
+    for key, val in outs.items():
+        assert np.array_equal(val, outs[("0", 0)]), (key, kernels[key], float(np.abs(val - outs[("0", 0)]).max()))
+
+
+@pytest.mark.parametrize("cin,cout,B,T", [(512, 2048, 16, 94), (2048, 512, 16, 94), (128, 512, 1, 94), (256, 96, 9, 33), (1024, 2050, 2, 47)])
+def test_pointwise_gemm_and_the_general_conv_kernel_form_the_same_sums(cin, cout, B, T, monkeypatch):
+    """batch-invariant mode may still move a pointwise layer between gemm_pw and the k = 1 conv kernel (a batch past the 32-bit offset span, a
+    device partition below 8 CUs).  Both walk K in ascending 8-channel steps into the same fp32 accumulators — pinned here: the two kernels' outputs are
+    BIT-identical, with and without residual / GELU, so that fallback cannot change a clip's bits.  Reference: convnext.py:130-141."""
+    from vocoder_amd import _lib
+    rng = np.random.default_rng(cin + cout + B)
+    x = rng.normal(size=(B, cin, T)).astype(np.float32)
+    w = (rng.normal(size=(cout, cin, 1)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(B, cout, T)).astype(np.float32)
+    out = {}
+    try:
+        for pw in ("0", "1", "old"):
+            monkeypatch.setenv("FV_PW", pw)
+            _lib.reload_env()
+            y1 = _run(w, b, x, post_act=_lib.FV_ACT_GELU)
+            kern = _lib.last_kernel()
+            assert kern.startswith("conv_mfma<" if pw == "old" else "gemm_pw<"), (pw, kern)
+            out[pw] = (y1, _run(w, b, x, res))
+    finally:
+        monkeypatch.delenv("FV_PW", raising=False)
+        _lib.reload_env()
+    for pw in ("0", "1"):
+        assert np.array_equal(out[pw][0], out["old"][0]) and np.array_equal(out[pw][1], out["old"][1]), pw

@@ -1124,3 +1124,164 @@ def test_ragged_shards_against_the_global_batch_and_the_batch_invariant_switch()
         assert any(k.startswith(("conv_wino<", "conv_wino4<", "conv_wino44<")) for k in prof) == (algo == "auto"), prof[:10]
         eng.set_batch_invariant(False)
     eng.close()
+
+
+# ---- long clips: time tiles with halo recompute, run as a batch (engine.hip run_model; SURVEY §5 long-context row, VERDICT r4 missing 3) ----
+def _tile_layout(T, L, halo):
+    """The engine's plan (engine.hip TilePlan): n tiles of L frames, regular starts i * (L - 2 halo), the last pulled back to end at T;
+    tile i contributes the frames [lo_i, hi_i)."""
+    stride = L - 2 * halo
+    n = max(2, -(-(T - 2 * halo) // stride))
+    start = [min(i * stride, T - L) for i in range(n)]
+    lo = [0 if i == 0 else (i - 1) * stride + L - halo for i in range(n)]
+    hi = [T if i + 1 == n else i * stride + L - halo for i in range(n)]
+    return start, lo, hi
+
+
+@pytest.mark.parametrize("model", ["hifigan", "hifigan_template", "bigvgan", "vocos", "firefly"])
+def test_time_tiled_forward_matches_the_whole_clip_and_the_oracle(model, monkeypatch):
+    """FV_TILE_FRAMES forces the long-clip path (a batch of overlapping time tiles whose halo outputs are discarded) on clips that also run
+    whole: tiled == whole to the last-bit differences of the Winograd lattices' anchoring (<= 2e-5), both within the parity bar of the
+    oracle; ragged last tile, B = 2."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config, upsampler_config
+    tiny = dict(hop_length=16, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4], resblock_kernel_sizes=[3, 7, 11],
+                resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=20, upsample_initial_channel=64, use_template=False,
+                pre_conv_kernel_size=7, post_conv_kernel_size=7)
+    T, B = 389, 2
+    tmpl = None
+    if model in ("hifigan", "hifigan_template"):
+        cfg = dict(tiny, use_template=model.endswith("template"))
+        sd = syn.hifigan_state_dict(cfg, seed=5)
+        mk = lambda: Engine(_lib.FV_MODEL_HIFIGAN, ups=upsampler_config(**cfg), state_dict=sd)   # noqa: E731
+        mel = syn.synthetic_mel(B, 20, T, seed=9)
+        if cfg["use_template"]:
+            tmpl = syn.synthetic_template(B, T, 16, seed=3)
+        ref = orc.hifigan_forward(sd, cfg, mel, template=tmpl)
+    elif model == "bigvgan":
+        sd = syn.bigvgan_state_dict(tiny, seed=6)
+        mk = lambda: Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**tiny), state_dict=sd)   # noqa: E731
+        mel = syn.synthetic_mel(B, 20, T, seed=9)
+        ref = orc.bigvgan_forward(sd, tiny, mel)
+    else:
+        bb = dict(input_channels=20, depths=[1, 2], dims=[32, 64], drop_path_rate=0.0, kernel_size=7)
+        if model == "vocos":
+            cfg = dict(backbone=bb, head=dict(dim=64, n_fft=64, hop_length=16, win_length=64, padding="same"))
+            sd = syn.vocos_state_dict(cfg, seed=7)
+            mk = lambda: Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**bb), head=istft_head_config(**cfg["head"]), state_dict=sd)   # noqa: E731
+            ref = orc.vocos_forward(sd, cfg, mel := syn.synthetic_mel(B, 20, T, seed=9))
+        else:
+            cfg = dict(backbone=bb, head=dict(tiny, num_mels=64))
+            sd = syn.firefly_state_dict(cfg, seed=8)
+            mk = lambda: Engine(_lib.FV_MODEL_FIREFLY, backbone=convnext_config(**bb), ups=upsampler_config(**cfg["head"]), state_dict=sd)   # noqa: E731
+            ref = orc.firefly_forward(sd, cfg, mel := syn.synthetic_mel(B, 20, T, seed=9))
+    tol = min(TOL, _peak_tol(ref)) if model == "vocos" else TOL
+    dev = _dev()
+    xt = torch.from_numpy(mel).to(dev)
+    tt = None if tmpl is None else torch.from_numpy(tmpl).to(dev)
+    whole = mk()
+    y_whole = whole(xt, None, tt).cpu().numpy()
+    ws_whole = whole.workspace_bytes(B, T)
+    monkeypatch.setenv("FV_TILE_FRAMES", "150")     # read at fv_create
+    tiled = mk()
+    monkeypatch.delenv("FV_TILE_FRAMES")
+    assert tiled.workspace_bytes(B, T) != ws_whole           # the tile plan is in force
+    y_tiled = tiled(xt, None, tt).cpu().numpy()
+    y_again = tiled(xt, None, tt).cpu().numpy()               # (second call: captured graph)
+    assert y_tiled.shape == y_whole.shape == ref.shape
+    assert np.array_equal(y_tiled, y_again)
+    assert np.abs(y_whole - ref).max() <= tol
+    assert np.abs(y_tiled - ref).max() <= tol, np.abs(y_tiled - ref).max()
+    assert np.abs(y_tiled - y_whole).max() <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+    prof = tiled.profile(xt, repeats=1) if tmpl is None else []
+    assert tmpl is not None or {"gather_tiles", "scatter_tiles"} <= {r["kernel"] for r in prof}
+
+
+def test_thirty_minute_clip_runs_as_time_tiles_bit_identical_to_a_run_of_one_tiles_frames():
+    """A 30-minute clip at 44.1 kHz (T_mel = 155 040 -> 79.4 M samples; one stage-4 tensor would be 5 GB, past the 4 GiB addressing span the
+    per-layer kernels enforce, conv_layer.hip) through fv_forward: three tiles of 65 536 frames run as one batch.  In batch-invariant mode the
+    samples a tile contributes are BIT-identical to a stand-alone forward of that tile's own frames (a shorter, overlapping run); a window of
+    the clip's middle and its first frames agree with the oracle."""
+    cfg = dict(syn.HIFIGAN_V1_44K)
+    sd = syn.hifigan_state_dict(cfg, seed=0)
+    eng = _hifigan_engine(cfg, sd)
+    eng.set_batch_invariant(True)
+    T = 155_040
+    mel = syn.synthetic_mel(1, 80, T, seed=77)
+    xt = torch.from_numpy(mel).to(_dev())
+    assert eng.output_length(T) * 16 * 4 > 2 ** 32            # the clip's last-stage tensor does not fit the addressing span
+    y = eng(xt)
+    torch.cuda.synchronize()
+    assert y.shape == (1, 1, T * 512)
+    assert bool(torch.isfinite(y).all()) and float(y.abs().max()) <= 1.0
+    L = 65536
+    halo = 17   # the plan: 2^29 / 8192 = 65 536 frames per tile; halo = the engine's reach bound (15 + 2 frames for V1: engine.hip ups_reach)
+    start, lo, hi = _tile_layout(T, L, halo)
+    assert len(start) == 3
+    i = 1
+    yi = eng(xt[:, :, start[i]:start[i] + L].contiguous())
+    a, b = (lo[i] - start[i]) * 512, (hi[i] - start[i]) * 512
+    assert torch.equal(yi[0, 0, a:b], y[0, 0, lo[i] * 512:hi[i] * 512]), "tile 1's samples differ from a stand-alone run of its frames"
+    # the seams: the last frame of tile 0 and the first of tile 1 against a whole run of the frames around the seam
+    s = lo[1]
+    ys = eng(xt[:, :, s - 40:s + 40].contiguous())
+    assert float((ys[0, 0, 20 * 512:60 * 512] - y[0, 0, (s - 20) * 512:(s + 20) * 512]).abs().max()) <= 2e-5
+    del yi, ys
+    yh = y.cpu().numpy()
+    ref0 = orc.hifigan_forward(sd, cfg, mel[:, :, :28])
+    assert np.abs(ref0[0, 0, :8 * 512] - yh[0, 0, :8 * 512]).max() <= TOL
+    m = T // 2
+    refm = orc.hifigan_forward(sd, cfg, mel[:, :, m - 24:m + 32])
+    assert np.abs(refm[0, 0, 24 * 512:32 * 512] - yh[0, 0, m * 512:(m + 8) * 512]).max() <= TOL
+    refe = orc.hifigan_forward(sd, cfg, mel[:, :, T - 28:])
+    assert np.abs(refe[0, 0, -8 * 512:] - yh[0, 0, -8 * 512:]).max() <= TOL
+
+
+@pytest.mark.parametrize("model", ["bigvgan", "vocos", "firefly", "refinegan"])
+def test_batch_invariant_mode_holds_beyond_hifigan(model):
+    """fv_set_batch_invariant promises kernel choices from the layer shape alone; pinned so far for HiFiGAN only.  BigVGAN (amp_conv /
+    aa_snake / Winograd), Vocos (gemm_pw / dwconv_ln / ISTFT), Firefly and RefineGAN: every clip of a batch equals the same clip run alone and
+    inside another batch composition, BIT for bit."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, convnext_config, istft_head_config, refinegan_config, upsampler_config
+    dev = _dev()
+    tmpl = noise_for = None
+    if model == "bigvgan":
+        cfg = dict(syn.BIGVGAN_24K)
+        eng = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=syn.bigvgan_state_dict(cfg, 3))
+        B, T, cin = 20, 47, 80
+    elif model == "vocos":
+        cfg = dict(syn.VOCOS_24K)
+        eng = Engine(_lib.FV_MODEL_VOCOS, backbone=convnext_config(**cfg["backbone"]), head=istft_head_config(**cfg["head"]),
+                     state_dict=syn.vocos_state_dict(cfg, 3))
+        B, T, cin = 24, 94, 80
+    elif model == "firefly":
+        cfg = dict(syn.FIREFLY_BASE_44K)
+        eng = Engine(_lib.FV_MODEL_FIREFLY, backbone=convnext_config(**cfg["backbone"]), ups=upsampler_config(**cfg["head"]),
+                     state_dict=syn.firefly_state_dict(cfg, 3))
+        B, T, cin = 12, 43, 128
+    else:
+        cfg = dict(syn.REFINEGAN_44K)
+        eng = Engine(_lib.FV_MODEL_REFINEGAN, refine=refinegan_config(**cfg), state_dict=syn.refinegan_state_dict(cfg, 3))
+        B, T, cin = 6, 20, 128
+        tmpl = torch.from_numpy(syn.synthetic_template(B, T, cfg["hop_length"], seed=2)).to(dev)
+        per = syn.refinegan_noise(cfg, B, T, seed=4)
+        noise_for = lambda idx: torch.from_numpy(np.concatenate([n[idx].reshape(-1) for n in per])).to(dev)   # noqa: E731
+    eng.set_batch_invariant(True)
+    x = torch.from_numpy(syn.synthetic_mel(B, cin, T, seed=31)).to(dev)
+
+    def run(idx):
+        idx = list(idx)
+        xi = x[idx].contiguous()
+        if noise_for is None:
+            return eng(xi).clone()
+        return eng(xi, None, tmpl[idx].contiguous(), noise_for(idx)).clone()
+
+    y = run(range(B))
+    assert bool(torch.isfinite(y).all())
+    for i in (0, B // 2, B - 1):
+        assert torch.equal(run([i])[0], y[i]), f"{model}: clip {i} alone differs from the same clip inside the batch of {B}"
+    sub = [B - 1, 1, B // 2]
+    ys = run(sub)
+    for j, i in enumerate(sub):
+        assert torch.equal(ys[j], y[i]), f"{model}: clip {i} in a batch of 3 differs from the batch of {B}"

@@ -35,14 +35,14 @@ for C, T in ((256, 688), (128, 5504), (64, 11008)):
             w = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
             b = rng.normal(size=C).astype(np.float32)
             pad = (k - 1) // 2 * d
-            conv = FusedConv(w, b, padding=pad, dilation=d, pre_act=_lib.FV_ACT_SILU).set_algorithm("winograd")
-            conv_na = FusedConv(w, b, padding=pad, dilation=d).set_algorithm("winograd")   # c2 of a pair: no activation in front
             xs = rng.normal(size=(2, C, 333)).astype(np.float32); rs = rng.normal(size=(2, C, 333)).astype(np.float32)
             ref = orc.conv1d(orc.silu(xs), w, b, dilation=d, padding=pad) + rs
             x = torch.randn(32, C, T, device="cuda"); r = torch.randn(32, C, T, device="cuda"); y = torch.empty_like(x)
             cells = []
             for fi, (name, env) in enumerate(FORMS):
-                setenv(env)
+                setenv(env)   # (before the layers are created: a layer packs only the Winograd form its knobs select — conv_layer.hip)
+                conv = FusedConv(w, b, padding=pad, dilation=d, pre_act=_lib.FV_ACT_SILU).set_algorithm("winograd")
+                conv_na = FusedConv(w, b, padding=pad, dilation=d).set_algorithm("winograd")   # c2 of a pair: no activation in front
                 ys = torch.empty(2, C, 333, device="cuda")
                 conv(torch.from_numpy(xs).cuda(), torch.from_numpy(rs).cuda(), ys)
                 err = float(np.abs(ys.cpu().numpy() - ref).max() / np.abs(ref).max())

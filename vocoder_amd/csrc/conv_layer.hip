@@ -148,6 +148,15 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
         c_in >= 16 && c_in == c_out) {   // the ResBlock / AMPBlock convs (not conv_pre: a launch whose size decides the path per batch)
         // Winograd F(2,3) tap groups (conv_wino_impl.h): groups at taps 0, 4, 8 -> four transformed weights each, the taps between them
         // (3, 7) -> (+w, -w); virtual-tap order = WinoGeom::off_of / acc_of
+        // Which transformed copies a layer keeps (every form its shape admits was ~8 x the direct weights at k = 11): the quad-lattice
+        // layers (k = 7 / 11 on whole 64-row tiles) keep the F(4,4) fragments and NOT the F(2,3) / F(4,3) ones, which only the A/B knobs FV_WINO44=0 /
+        // FV_WINO4=0 reach — a process that sets those knobs BEFORE creating its layers gets the form it asks for (tests/test_gpu_conv.py,
+        // tools/ab_wino.sh do); a layer whose form is missing falls back to the direct kernel.  Footprint at k = 11 per (c_out, c_in): direct 11 floats
+        // + F(4,4) 10 + latency / pair fragments 16 (was 11 + 16 + 10 + 26 + 16 + 16).
+        L.wino = true;
+        const bool quad_layer = c_in >= 64 && c_in % 8 == 0 && c_out % 64 == 0 && k >= 7;
+        const bool use_f44 = quad_layer && knobs().wino4 && knobs().wino44;
+        const bool use_f43 = quad_layer && knobs().wino4 && !knobs().wino44;
         const int ng = (k + 1) / 4, ns = (k - 3) / 4;
         const int nv = 4 * ng + 2 * ns;
         std::vector<float> ww((size_t)c_out * c_in * nv);
@@ -166,14 +175,14 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
                 o[4 * ng + 2 * s2 + 1] = -w[4 * s2 + 3];
             }
         }
-        if (c_in >= 32) {
-            L.nv = nv;
+        L.nv = nv;
+        if (c_in >= 32 && !use_f44 && !use_f43) {   // conv_wino (F(2,3) per layer) and the C = 64 / 128 k = 3 pairs
             std::vector<float> pw;
             pack_conv_weights(ww, L.M, c_in, L.nv, L.m_pad, L.nchunk, pw);
             FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw, pw.size() * sizeof(float)));
             FV_HIP_CHECK(hipMemcpy(L.d_wpw, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
         }
-        if (c_in >= 64 && c_in % 8 == 0 && c_out % 64 == 0 && k >= 7) {
+        if (use_f44) {
             // Winograd F(4,4) tap groups (conv_wino44_impl.h): groups of FOUR taps at 0, 4, 8 (taps past k are zero), points ±1/2, ±1, ±2, ∞.  Per (32-row tile,
             // plane half h) and 8-channel block: 3 ng full fragments — group g, own plane i (h = 0: +1/2, -1/2, +1; h = 1: -1, +2, -2), the four channel pairs
             // in .xyzw — then ONE fragment of the shared ∞ plane (U = the group's fourth tap): component j = group j / 2, channel pair 2 h + j % 2
@@ -204,7 +213,7 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
             FV_HIP_CHECK(hipMalloc((void**)&L.d_wpw44, p44.size() * sizeof(float)));
             FV_HIP_CHECK(hipMemcpy(L.d_wpw44, p44.data(), p44.size() * sizeof(float), hipMemcpyHostToDevice));
         }
-        if (c_in >= 64 && c_out % 64 == 0 && k >= 7) {
+        if (use_f43) {
             // Winograd F(4,3) tap groups (conv_wino4_impl.h): per (32-row tile, plane half h) nv4 = 3 ng + 2 ns virtual taps = Wino4Geom::off_of / acc_of:
             // group g, i = 0..2 -> transformed weight U_p of taps 4g..4g+2 with p = i (h = 0: m0 m1 m2) or 5 - i (h = 1: m5 m4 m3); then per single tap
             // 4s + 3 two plain copies (h = 0: into m0 and S1, h = 1: into m5 and S2).  Packed as 2 M rows: row (2 mt + h) * 32 + r = (row 32 mt + r, half h)
@@ -514,6 +523,26 @@ static fv_status conv_layer_run_f16x3(const ConvLayer& L, const ConvRun& r, Conv
     return FV_OK;
 }
 
+// What every per-layer conv launch records: the kernel's name for fv_last_kernel, and — under fv_profile_begin — one profiler row with the layer's
+// ALGORITHMIC work whichever sums the kernel forms (direct-sum MACs; per-layer compulsory bytes: input once, output once, residual / accumulate
+// operand once, the folded weights once — DESIGN.md §5).  One copy, so that a change to the accounting reaches every kernel family.
+static fv_status finish_conv_launch(const ConvLayer& L, const ConvRun& r, long long tout, hipStream_t stream, int prof_idx, const char* name,
+                                    long long grid, const char* tags = "", bool three_inputs = false) {
+    set_last_kernel(name);
+    if (prof_idx >= 0) {
+        const double macs = (double)L.c_in * L.c_out * L.k * (L.transposed ? (double)r.t_in : (double)tout) * r.batch;
+        double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
+        if (r.res) elems += (double)L.c_out * tout;
+        if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
+        if (three_inputs) elems += 2.0 * L.c_in * r.t_in;   // the other two branch outputs
+        char lbl[192];
+        std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d%s grid=%lld", name, L.c_in, L.c_out, tags, grid);
+        prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
+    }
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
 fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t stream) {
     if (!L.d_wp) {
         set_error("conv_layer_run: layer not initialised");
@@ -590,9 +619,8 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     p.acc_scale = 1.0f;
 
     // stride-8 upsamplers, bias only, aligned: 16-byte output quads (conv_mfma_impl.h: conv_epilogue)
-    static const bool no_vec_store = std::getenv("FV_VEC_STORE") && std::atoi(std::getenv("FV_VEC_STORE")) == 0;   // experiments: FV_VEC_STORE=0
     p.vec_store = (L.transposed && L.stride == 8 && !r.res && !r.gamma && r.out_mode == OUT_SET && r.post_act == FV_ACT_NONE &&
-                   tout % 4 == 0 && L.padding % 4 == 0 && ((uintptr_t)r.y & 15) == 0 && !no_vec_store) ? 1 : 0;
+                   tout % 4 == 0 && L.padding % 4 == 0 && ((uintptr_t)r.y & 15) == 0 && knobs().vec_store) ? 1 : 0;
 
     if (f16) return conv_layer_run_f16x3(L, r, p, stream);
 
@@ -625,147 +653,86 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
 #if defined(FV_X_SPLITK_TS) || defined(FV_X_CONV_TS)
     p.dbg_ts = g_sk_ts;
 #endif
-    // Winograd F(2,3) tap groups for the dilated ResBlock / AMPBlock convs of launches that fill the chip (conv_wino_impl.h)
+    // Winograd tap groups for the dilated ResBlock / AMPBlock convs (layers conv_layer_create marked `wino`): per launch
+    //   launches of >= one workgroup per CU (or FV_CONV_ALGO_WINOGRAD, or batch-invariant mode: one algorithm per layer whatever the batch)
+    //       k = 7 / 11 on whole 64-row tiles   conv_wino44 — F(4,4) on the quad lattice, 20 / 13 products per four outputs (conv_wino44_impl.h);
+    //                                          FV_WINO44=0: conv_wino4, its F(4,3) predecessor (26 / 16; conv_wino4_impl.h)
+    //       everything else (k = 3, C = 32, row counts without whole 64-row tiles, FV_WINO4=0)   conv_wino — F(2,3) on the pair lattice (conv_wino_impl.h)
+    //   launches below that gate, FV_CONV_ALGO_AUTO only   conv_wino_lat — F(2,3), 16-row tiles, K split over the waves (conv_wino_lat_impl.h)
+    // The gate counts the launch's workgroups in the F(2,3) tiling WHICHEVER kernel is launched (a 128-row F(4,4) workgroup covers two of those blocks at
+    // C >= 128, one at C = 64): it was swept in these units (tools/sweep_wino_batch.py, GATES=32,...,512; LOG R4.20 — round 3: half a workgroup per CU; with
+    // the 128-row workgroups a launch of 128 - 255 blocks leaves CUs empty: gate 256 against 128: B = 6 2.43 / 2.76 ms, B = 8 3.10 / 3.23, B = 2 1.25 / 1.28,
+    // equal elsewhere; 512 loses at B = 3 - 4 and 12 - 16).  A single clip (86 blocks at C = 128) stays on the latency kernel either way.
     const int algo = effective_algo();
-    if (algo != FV_CONV_ALGO_DIRECT && L.d_wpw && !p.x2 && L.M >= knobs().wino_min_m) {
+    if (algo != FV_CONV_ALGO_DIRECT && L.wino && !p.x2 && L.M >= knobs().wino_min_m) {
         static const int wdims[WINO_COUNT][2] = {{128, 32}, {64, 64}, {32, 128}, {128, 64}, {64, 128}};
         // 64 accumulator registers per wave (32 output pairs x 4 planes): three waves per SIMD; the 128 x 64-pair tile (two waves) measured
         // 8 % slower on the headline's C = 128 stage although it fetches each weight fragment half as often
         int wcfg = L.M > 64 ? WINO_128x32 : L.M > 32 ? WINO_64x64 : WINO_32x128;
         const long long np = (long long)L.dil * ((tout + 2 * L.dil - 1) / (2 * L.dil));   // pair columns: whole blocks of 2 D samples
-        auto blocks_of = [&](int c) { return (long long)r.batch * ((L.M + wdims[c][0] - 1) / wdims[c][0]) * ((np + wdims[c][1] - 1) / wdims[c][1]); };
+        const long long nq = (long long)L.dil * ((tout + 4 * L.dil - 1) / (4 * L.dil));   // quad columns: whole blocks of 4 D samples
 #ifdef FV_X_WINO_NT2
         if (knobs().wino_cfg >= 0 && knobs().wino_cfg < WINO_COUNT) wcfg = knobs().wino_cfg;
 #else
         if (knobs().wino_cfg >= 0 && knobs().wino_cfg <= WINO_32x128) wcfg = knobs().wino_cfg;
 #endif
         const int mb = wdims[wcfg][0], pairs = wdims[wcfg][1];
-        const long long blocks = blocks_of(wcfg);
-        // launches of at least one workgroup per CU (counted in the F(2,3) tiling above, whichever Winograd kernel the layer takes below): measured per batch size
-        // (tools/sweep_wino_batch.py, GATES=32,...,512).  Round 3: half a workgroup per CU; with the 128-row F(4,4) workgroups of round 4 a launch of 128 - 255 such
-        // blocks leaves CUs empty — gate 256 against 128: B = 6 2.43 / 2.76 ms, B = 8 3.10 / 3.23, B = 2 1.25 / 1.28, equal elsewhere; 512 loses at B = 3 - 4, 12 - 16.
-        // A single clip (86 blocks at C = 128) stays on the latency kernel either way
+        const long long blocks = (long long)r.batch * ((L.M + mb - 1) / mb) * ((np + pairs - 1) / pairs);
         const long long min_blocks = knobs().wino_min_blocks >= 0 ? knobs().wino_min_blocks : num_cus();
+        char name[96];
         if (blocks >= min_blocks || algo == FV_CONV_ALGO_WINOGRAD || cur_invariant()) {
-            // F(4,3) tap groups where the layer has whole 64-row tiles (conv_wino4_impl.h): the same gate, so one algorithm per layer whatever
-            // the batch in batch-invariant mode
-            // F(4,4) tap groups for k = 7 / 11 on layers of whole 64-row tiles (conv_wino44_impl.h: 20 / 13 products per four outputs) — the same gate as below
-            if (knobs().wino4 && knobs().wino44 && L.d_wpw44) {
-                const long long nq = (long long)L.dil * ((tout + 4 * L.dil - 1) / (4 * L.dil));   // quad columns: whole blocks of 4 D samples
-                // two 32-row tiles per wave (128-row workgroups, two waves per SIMD) wherever the layer has whole 128-row blocks: the staging of a window then feeds
-                // twice the products.  Back to back the C = 256 launches are slower that way (384 workgroups on 256 CUs), inside the three-stream step they are not:
-                // 10.95 (64 rows) / 10.77 (128 rows for launches of >= 4 workgroups per CU only) / 10.65 ms (always) interleaved on one box (LOG R4.16)
-                const int rows44 = (L.M % 128 == 0 && knobs().wino44_rows != 64) ? 128 : 64;
-                p.wp = L.d_wpw44;
-                p.m_blks = L.M / rows44;
-                p.n_tiles = (int)((nq + 31) / 32);
+            const int form = (knobs().wino4 && knobs().wino44 && L.d_wpw44) ? 44 : (knobs().wino4 && L.d_wpw4) ? 43 : L.d_wpw ? 23 : 0;
+            // (form 0: a layer whose Winograd form for the current knobs was not packed at create — the direct kernel below)
+            if (form) {
                 const int prof_idx = prof_begin(stream);
-                const bool launched = L.ks == 7 ? launch_conv_wino44_k7(p, rows44, r.batch, stream) : launch_conv_wino44_k11(p, rows44, r.batch, stream);
+                bool launched = false;
+                if (form == 44) {
+                    // two 32-row tiles per wave (128-row workgroups, two waves per SIMD) wherever the layer has whole 128-row blocks: the staging of a window then
+                    // feeds twice the products.  Back to back the C = 256 launches are slower that way (384 workgroups on 256 CUs), inside the three-stream step
+                    // they are not: 10.95 (64 rows) / 10.77 (128 rows for launches of >= 4 workgroups per CU only) / 10.65 ms (always) interleaved (LOG R4.16)
+                    const int rows44 = (L.M % 128 == 0 && knobs().wino44_rows != 64) ? 128 : 64;
+                    p.wp = L.d_wpw44;
+                    p.m_blks = L.M / rows44;
+                    p.n_tiles = (int)((nq + 31) / 32);
+                    launched = L.ks == 7 ? launch_conv_wino44_k7(p, rows44, r.batch, stream) : launch_conv_wino44_k11(p, rows44, r.batch, stream);
+                    std::snprintf(name, sizeof(name), "conv_wino44<k=%d d=%d tile=%dx32q>", L.ks, L.dil, rows44);
+                } else if (form == 43) {   // (k = 7 / 11 only — k = 3: 6 products per quad against 8, and F(2,3) measured faster: LOG R4.14)
+                    p.wp = L.d_wpw4;
+                    p.m_blks = L.M / 64;
+                    p.n_tiles = (int)((nq + 31) / 32);
+                    launched = L.ks == 7 ? launch_conv_wino4_k7(p, r.batch, stream) : launch_conv_wino4_k11(p, r.batch, stream);
+                    std::snprintf(name, sizeof(name), "conv_wino4<k=%d d=%d tile=64x32q>", L.ks, L.dil);
+                } else {
+                    p.wp = L.d_wpw;
+                    p.m_blks = (L.M + mb - 1) / mb;
+                    p.n_tiles = (int)((np + pairs - 1) / pairs);
+                    launched = L.ks == 3 ? launch_conv_wino_k3(p, wcfg, r.batch, stream)
+                               : L.ks == 7 ? launch_conv_wino_k7(p, wcfg, r.batch, stream) : launch_conv_wino_k11(p, wcfg, r.batch, stream);
+                    std::snprintf(name, sizeof(name), "conv_wino<k=%d d=%d tile=%dx%dp>", L.ks, L.dil, mb, pairs);
+                }
                 if (!launched) {
-                    set_error("conv_layer_run: no F(4,4) Winograd kernel for (k=%d, dilation=%d)", L.ks, L.dil);
+                    set_error("conv_layer_run: no Winograd kernel for (k=%d, dilation=%d)", L.ks, L.dil);
                     return FV_ERR_UNSUPPORTED;
                 }
-                static thread_local char name[96];
-                std::snprintf(name, sizeof(name), "conv_wino44<k=%d d=%d tile=%dx32q>", L.ks, L.dil, rows44);
-                set_last_kernel(name);
-                if (prof_idx >= 0) {
-                    const double macs = (double)L.c_in * L.c_out * L.k * (double)tout * r.batch;   // ALGORITHMIC (direct-sum) MACs
-                    double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
-                    if (r.res) elems += (double)L.c_out * tout;
-                    if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
-                    char lbl[160];
-                    std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d grid=%lld", name, L.c_in, L.c_out, (long long)r.batch * p.m_blks * p.n_tiles);
-                    prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
-                }
-                FV_HIP_CHECK(hipGetLastError());
-                return FV_OK;
+                return finish_conv_launch(L, r, tout, stream, prof_idx, name, (long long)r.batch * p.m_blks * p.n_tiles);
             }
-            if (knobs().wino4 && L.d_wpw4) {   // (k = 7 / 11 only — k = 3: 6 products per quad against 8, and F(2,3) measured faster: LOG R4.14)
-                const long long nq = (long long)L.dil * ((tout + 4 * L.dil - 1) / (4 * L.dil));   // quad columns: whole blocks of 4 D samples
-                const int rows = 64;
-                p.wp = L.d_wpw4;
-                p.m_blks = L.M / rows;
-                p.n_tiles = (int)((nq + 31) / 32);
-                const int prof_idx = prof_begin(stream);
-                const bool launched = L.ks == 7 ? launch_conv_wino4_k7(p, r.batch, stream) : launch_conv_wino4_k11(p, r.batch, stream);
-                if (!launched) {
-                    set_error("conv_layer_run: no F(4,3) Winograd kernel for (k=%d, dilation=%d)", L.ks, L.dil);
-                    return FV_ERR_UNSUPPORTED;
-                }
-                static thread_local char name[96];
-                std::snprintf(name, sizeof(name), "conv_wino4<k=%d d=%d tile=%dx32q>", L.ks, L.dil, rows);
-                set_last_kernel(name);
-                if (prof_idx >= 0) {
-                    const double macs = (double)L.c_in * L.c_out * L.k * (double)tout * r.batch;   // ALGORITHMIC (direct-sum) MACs
-                    double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
-                    if (r.res) elems += (double)L.c_out * tout;
-                    if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
-                    char lbl[160];
-                    std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d grid=%lld", name, L.c_in, L.c_out, (long long)r.batch * p.m_blks * p.n_tiles);
-                    prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
-                }
-                FV_HIP_CHECK(hipGetLastError());
-                return FV_OK;
-            }
-            p.wp = L.d_wpw;
-            p.m_blks = (L.M + mb - 1) / mb;
-            p.n_tiles = (int)((np + pairs - 1) / pairs);
+        } else if (knobs().wino_lat && L.d_wpwl && !r.gamma && !cur_invariant() && (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU)) {
+            // launches below the gate (single clips, small batches).  Not in batch-invariant mode (another order of the K sum than conv_wino_kernel).
+            const int tile = wino_lat_tile(L, np, r.batch, 1);
+            const int rows = tile == 0 ? 16 : 32, lat_pairs = tile == 2 ? 32 : 16;
+            p.wp = L.d_wpwl;
+            p.m_blks = (int)(L.M / rows);
+            p.n_tiles = (int)((np + lat_pairs - 1) / lat_pairs);
             const int prof_idx = prof_begin(stream);
-            const bool launched = L.ks == 3 ? launch_conv_wino_k3(p, wcfg, r.batch, stream)
-                                  : L.ks == 7 ? launch_conv_wino_k7(p, wcfg, r.batch, stream) : launch_conv_wino_k11(p, wcfg, r.batch, stream);
+            const bool launched = L.ks == 3 ? launch_conv_wino_lat_k3(p, tile, r.batch, stream)
+                                  : L.ks == 7 ? launch_conv_wino_lat_k7(p, tile, r.batch, stream) : launch_conv_wino_lat_k11(p, tile, r.batch, stream);
             if (!launched) {
-                set_error("conv_layer_run: no Winograd kernel for (k=%d, dilation=%d)", L.ks, L.dil);
+                set_error("conv_layer_run: no Winograd latency kernel for (k=%d, dilation=%d)", L.ks, L.dil);
                 return FV_ERR_UNSUPPORTED;
             }
-            {
-                static thread_local char name[96];
-                std::snprintf(name, sizeof(name), "conv_wino<k=%d d=%d tile=%dx%dp>", L.ks, L.dil, mb, pairs);
-                set_last_kernel(name);
-                if (prof_idx >= 0) {
-                    const double macs = (double)L.c_in * L.c_out * L.k * (double)tout * r.batch;   // ALGORITHMIC (direct-sum) MACs
-                    double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
-                    if (r.res) elems += (double)L.c_out * tout;
-                    if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
-                    char lbl[160];
-                    std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d grid=%lld", name, L.c_in, L.c_out, blocks);
-                    prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
-                }
-                FV_HIP_CHECK(hipGetLastError());
-                return FV_OK;
-            }
+            std::snprintf(name, sizeof(name), "conv_wino_lat<k=%d d=%d tile=%dx%dp>", L.ks, L.dil, rows, lat_pairs);
+            return finish_conv_launch(L, r, tout, stream, prof_idx, name, (long long)r.batch * p.m_blks * p.n_tiles);
         }
-    }
-    // ... and for launches below that gate (single clips, small batches) the Winograd latency kernel: 16-row tiles, K split over the waves
-    // (conv_wino_lat_impl.h).  Not in batch-invariant mode (another order of the K sum than conv_wino_kernel).
-    if (algo != FV_CONV_ALGO_DIRECT && knobs().wino_lat && L.d_wpwl && !p.x2 && !r.gamma && !cur_invariant() &&
-        (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU) && L.M >= knobs().wino_min_m) {
-        const long long np = (long long)L.dil * ((tout + 2 * L.dil - 1) / (2 * L.dil));
-        const int tile = wino_lat_tile(L, np, r.batch, 1);
-        const int rows = tile == 0 ? 16 : 32, pairs = tile == 2 ? 32 : 16;
-        p.wp = L.d_wpwl;
-        p.m_blks = (int)(L.M / rows);
-        p.n_tiles = (int)((np + pairs - 1) / pairs);
-        const int prof_idx = prof_begin(stream);
-        const bool launched = L.ks == 3 ? launch_conv_wino_lat_k3(p, tile, r.batch, stream)
-                              : L.ks == 7 ? launch_conv_wino_lat_k7(p, tile, r.batch, stream) : launch_conv_wino_lat_k11(p, tile, r.batch, stream);
-        if (!launched) {
-            set_error("conv_layer_run: no Winograd latency kernel for (k=%d, dilation=%d)", L.ks, L.dil);
-            return FV_ERR_UNSUPPORTED;
-        }
-        static thread_local char name[96];
-        std::snprintf(name, sizeof(name), "conv_wino_lat<k=%d d=%d tile=%dx%dp>", L.ks, L.dil, rows, pairs);
-        set_last_kernel(name);
-        if (prof_idx >= 0) {
-            const double macs = (double)L.c_in * L.c_out * L.k * (double)tout * r.batch;   // ALGORITHMIC (direct-sum) MACs
-            double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
-            if (r.res) elems += (double)L.c_out * tout;
-            if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
-            char lbl[160];
-            std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d grid=%d", name, L.c_in, L.c_out, r.batch * p.m_blks * p.n_tiles);
-            prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
-        }
-        FV_HIP_CHECK(hipGetLastError());
-        return FV_OK;
     }
     p.wp = L.d_wp;
     int cfg = choose_tile(L.M, p.N, r.batch);
@@ -833,25 +800,12 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
             return FV_ERR_UNSUPPORTED;
         }
     }
-    static thread_local char name[96];
+    char name[96];
     std::snprintf(name, sizeof(name), "conv_mfma<%s k=%d d=%d tile=%s>", specialised ? "spec" : "generic", L.ks, L.dil,
                   kTileNames[cfg]);
-    set_last_kernel(name);
-    if (prof_idx >= 0) {
-        // algorithmic work of this launch: dense MACs of the layer; per-layer compulsory bytes (input once, output once,
-        // residual / accumulate operand once, packed weights once)
-        const double macs = (double)L.c_in * L.c_out * L.k * (L.transposed ? (double)r.t_in : (double)tout) * r.batch;
-        double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
-        if (r.res) elems += (double)L.c_out * tout;
-        if (r.out_mode == OUT_ACCUM) elems += (double)L.c_out * tout;
-        if (p.x2) elems += 2.0 * L.c_in * r.t_in;   // the other two branch outputs
-        char lbl[160];
-        std::snprintf(lbl, sizeof(lbl), "%s cin=%d cout=%d%s%s grid=%d", name, L.c_in, L.c_out, L.transposed ? " convT" : "", p.x2 ? " sum3" : "",
-                      launch_batch * p.m_blks * p.n_tiles);
-        prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * r.batch * 4.0 + (double)L.c_in * L.c_out * L.k * 4.0);
-    }
-    FV_HIP_CHECK(hipGetLastError());
-    return FV_OK;
+    char tags[32];
+    std::snprintf(tags, sizeof(tags), "%s%s", L.transposed ? " convT" : "", p.x2 ? " sum3" : "");
+    return finish_conv_launch(L, r, tout, stream, prof_idx, name, (long long)launch_batch * p.m_blks * p.n_tiles, tags, p.x2 != nullptr);
 }
 
 // Tile of the Winograd latency kernel for `layers` equal layers launched together: the largest one that still leaves ~2 workgroups per CU

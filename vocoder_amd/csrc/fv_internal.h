@@ -30,6 +30,8 @@ struct Knobs {
     int wino_min_m = 32;  // FV_WINO_MIN_M: narrowest layer (output rows) that takes it
     int wino_cfg = -1;    // FV_WINO_CFG: forced tile (WinoCfg 0 ... 2), -1 = by shape
     int wino_min_blocks = -1;   // FV_WINO_MIN_BLOCKS: fewest workgroups of a launch that takes it, -1 = default
+    int vec_store = 1;    // FV_VEC_STORE: 0 = the stride-8 upsamplers store single floats instead of 16-byte output quads (A/B runs, tests)
+    // (FV_WINO4 / FV_WINO44 are also read when a layer is CREATED: it packs only the Winograd form they select — conv_layer.hip)
     int wino44 = 1;       // FV_WINO44: 1 = F(4,4) tap groups (conv_wino44_impl.h) for k = 7 / 11 where FV_WINO4 would take F(4,3), 0 = F(4,3) there
     int wino44_rows = 0;  // FV_WINO44_ROWS: 64 = one 32-row tile per wave (64-row workgroups) everywhere; otherwise two (128 rows) where the layer has whole 128-row blocks
     int wino4 = 1;        // FV_WINO4: 1 = the quad-lattice kernels (conv_wino44_impl.h / conv_wino4_impl.h) for k = 7 / 11 where the Winograd path is taken and the layer has whole 64-row blocks, 0 = F(2,3) everywhere
@@ -154,6 +156,7 @@ struct ConvLayer {
     // GEMM view
     int M = 0, ks = 0, pad_l = 0, nchunk = 0, nchunk_real = 0, m_pad = 0;
     float4* d_wp = nullptr;
+    bool wino = false;         // a ResBlock / AMPBlock conv (k in {3, 7, 11}, dilation in {1, 3, 5}, 'same', C -> C): Winograd forms below, as its shape admits
     float4* d_wpw = nullptr;   // Winograd-transformed weights in the same fragment order, nv virtual taps (conv_wino_impl.h); optional
     int nv = 0;
     float4* d_wp16 = nullptr;  // 16x16x4-fragment layout, only for 16 -> 16 channel Conv1d (fused pair kernel)
@@ -327,6 +330,9 @@ fv_status launch_polyphase_reflect(const float* wave, float* yp, int B, int L, i
 fv_status launch_magnitude(const float* spec, float* mag, int B, int nb, int T, hipStream_t s);
 
 // ISTFT head glue: h (B, 2*n_fft, T) rows [0,nb) = log-mag, [n_fft, n_fft+nb) = phase -> spec (B, 2*nbp, T):
+// long clips as a batch of equal-length time tiles (engine.hip run_model); hop: frames -> samples of the tensor being moved
+fv_status launch_gather_tiles(const float* x, float* tiles, int B, int C, int T, int n, int L, int stride, int hop, hipStream_t s);
+fv_status launch_scatter_tiles(const float* tiles, float* y, int B, int C, int T, int n, int L, int stride, int halo, int hop, hipStream_t s);
 // rows [0,nb) = Re, [nbp, nbp+nb) = Im, zero padded to nbp = round_up(nb, 8)
 fv_status launch_istft_spec(const float* h, float* spec, int B, int n_fft, int T, int nb, int nbp, hipStream_t s);
 // frames (B, n_fft, T) (already windowed by the synthesis basis) -> overlap-add, crop, divide by the envelope.

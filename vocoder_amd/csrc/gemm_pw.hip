@@ -23,23 +23,6 @@
 
 namespace fv {
 
-// GELU = v * Phi(v) with Phi(-|v|) = erfc(|v| / sqrt 2) / 2 ~ poly(t) * exp(-v^2 / 2) / 2, t = 1 / (1 + p |v| / sqrt 2)
-// (Abramowitz & Stegun 7.1.26, |eps_erf| <= 1.5e-7): 16 VALU instructions, two of them transcendental, no branches — about a
-// third of the correctly-rounded erff.  Measured in fp32 against the exact function over [-12, 12]: |err| <= 4.3e-7 (torch's
-// own fp32 nn.GELU: 1.2e-6); tests/test_gpu_conv.py pins it.
-__device__ __forceinline__ float gelu_fast(float v) {
-    const float z = fabsf(v) * 0.70710678f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(t, 1.061405429f, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(v * v * -0.72134752f);   // exp(-v^2 / 2)
-    const float h = 0.5f * poly * e;
-    return v * (v >= 0.f ? 1.0f - h : h);
-}
-
 // Persistent form of the same GEMM.  What the one-tile-per-wave kernel above loses on the short-K layers (512 -> 2048: the
 // whole launch is 1.5 rounds of 4 waves per SIMD) is lock-step and quantisation: every wave of a round sits in its prologue
 // (first loads), main loop and epilogue (GELU + a burst of stores) at the same time, and the last round is partly empty.

@@ -1182,6 +1182,48 @@ fv_status launch_adain(const float* x, const float* noise, const float* w, float
     return FV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Long clips as a batch of time tiles (engine.hip run_model): tile i of a clip covers frames [a_i, a_i + L), a_i = min(i * stride, T - L);
+// `hop` scales frames to samples (1 for the mel input, the generator's hop for the pitch template and the waveform).
+//   gather : tiles[(b * n + i)][c][l] = x[b][c][a_i * hop + l]
+//   scatter: y[b][c][lo_i * hop ...) = tiles[(b * n + i)][c][(lo_i - a_i) * hop ...), the frames [lo_i, hi_i) tile i contributes
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_tiles_kernel(const float* __restrict__ x, float* __restrict__ tiles, int C, long long T,
+                                                           int n, long long L, int stride, int hop, long long Tf) {
+    const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (l >= L) return;
+    const int c = blockIdx.y, bi = blockIdx.z, b = bi / n, i = bi % n;
+    long long a = (long long)i * stride;
+    if (a > Tf - L / hop) a = Tf - L / hop;
+    tiles[((long long)bi * C + c) * L + l] = x[((long long)b * C + c) * T + a * hop + l];
+}
+fv_status launch_gather_tiles(const float* x, float* tiles, int B, int C, int T, int n, int L, int stride, int hop, hipStream_t s) {
+    const long long Ls = (long long)L * hop;
+    hipLaunchKernelGGL(gather_tiles_kernel, dim3((unsigned)((Ls + 255) / 256), C, B * n), dim3(256), 0, s, x, tiles, C, (long long)T * hop, n,
+                       Ls, stride, hop, (long long)T);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+__global__ __launch_bounds__(256) void scatter_tiles_kernel(const float* __restrict__ tiles, float* __restrict__ y, int C, long long T,
+                                                            int n, long long L, int stride, int halo, int hop, long long Tf) {
+    const int c = blockIdx.y, bi = blockIdx.z, b = bi / n, i = bi % n;
+    const long long Lf = L / hop;
+    long long a = (long long)i * stride;
+    if (a > Tf - Lf) a = Tf - Lf;
+    const long long lo = i == 0 ? 0 : (long long)(i - 1) * stride + Lf - halo;
+    const long long hi = i + 1 == n ? Tf : (long long)i * stride + Lf - halo;
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;   // sample within the tile's contribution
+    if (j >= (hi - lo) * hop) return;
+    y[((long long)b * C + c) * T + lo * hop + j] = tiles[((long long)bi * C + c) * L + (lo - a) * hop + j];
+}
+fv_status launch_scatter_tiles(const float* tiles, float* y, int B, int C, int T, int n, int L, int stride, int halo, int hop, hipStream_t s) {
+    const long long Ls = (long long)L * hop;
+    hipLaunchKernelGGL(scatter_tiles_kernel, dim3((unsigned)((Ls + 255) / 256), C, B * n), dim3(256), 0, s, tiles, y, C, (long long)T * hop, n,
+                       Ls, stride, halo, hop, (long long)T);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+}
+
 #ifdef FV_DEBUG_HOOKS   // not in the product library: `make BUILD=build_dbg LIB=libfishvoc_dbg.so EXTRA=-DFV_DEBUG_HOOKS`, then FV_LIB_PATH
 // Debug aid (tools/probe_lds_poison.py): fills the LDS of every CU with signalling garbage (NaN bit patterns) so that a kernel
 // which reads LDS it never wrote shows up as a changed / non-finite result instead of silently inheriting whatever the previous

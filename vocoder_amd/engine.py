@@ -200,8 +200,11 @@ class Engine:
         check(self._lib.fv_set_graph_replay(self._h, int(bool(enable))))
 
     def set_conv_algorithm(self, algo: str) -> None:
-        """"auto" (per launch, fastest), "direct" (direct sums everywhere) or "winograd" (F(2,3) tap groups wherever a kernel exists):
-        include/fishvoc.h ``fv_conv_algo``.  Changes the last bits of the output, not its parity."""
+        """Which fp32 sums the ResBlock / AMPBlock convs form (include/fishvoc.h ``fv_conv_algo``); changes the last bits of the output, not its parity.
+        "auto": per launch, fastest — the throughput Winograd kernels (F(4,4) quad lattice for k = 7 / 11 on whole 64-row tiles, F(2,3) pair lattice
+        otherwise) for launches of >= one workgroup per CU, the Winograd LATENCY kernel (F(2,3), K split over the waves) below that gate, Winograd pairs on
+        the narrow stages; "direct": direct sums everywhere; "winograd": the throughput Winograd kernels whatever the launch size — it bypasses the
+        latency kernel, so single clips run slower than under "auto"."""
         check(self._lib.fv_set_conv_algorithm(self._h, _lib.CONV_ALGOS[algo]))
 
     def set_batch_invariant(self, enable: bool) -> None:
