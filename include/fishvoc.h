@@ -205,8 +205,8 @@ FV_API fv_status fv_set_precision(fv_engine* e, int32_t precision);
  * batch size or the clip length: no split-K / latency kernels, the fused pairs and the pointwise GEMM wherever their
  * shape allows, and (under FV_CONV_ALGO_AUTO) Winograd wherever a kernel exists.  A clip's output is then bit-identical whichever other clips
  * share its batch — e.g. a 37-clip batch sharded 5/5/5/5/5/4/4/4 over 8 GPUs equals the single-GPU batch bit for bit (tests pin HiFiGAN, BigVGAN,
- * Vocos, Firefly and RefineGAN; the one launch-dependent choice left, pointwise GEMM vs the k = 1 conv kernel for batches past the 32-bit offset span or
- * device partitions below 8 CUs, is between kernels that form the same sums: tests/test_gpu_conv.py) — at the price of
+ * Vocos, Firefly and RefineGAN; a pointwise-GEMM launch past the 32-bit offset span — > 4 GiB per layer: the default engine moves it to the k = 1 conv
+ * kernel, which forms other sums — is refused with FV_ERR_UNSUPPORTED in this mode: split the batch) — at the price of
  * single-clip latency (the launch-size gates exist because small launches are faster on the direct / split-K kernels).  Without it, batches
  * that differ in size may differ in the last bits (<= 2e-5 of full scale; tests/test_gpu_models.py pins the bound).
  * Both may be called at any time; captured graphs are dropped. */

@@ -620,30 +620,3 @@ def test_stride8_upsampler_quad_stores_equal_the_single_stores(cin, cout, B, T, 
     _check(outs[("1", 0)], ref)
     for key, val in outs.items():
         assert np.array_equal(val, outs[("0", 0)]), (key, kernels[key], float(np.abs(val - outs[("0", 0)]).max()))
-
-
-@pytest.mark.parametrize("cin,cout,B,T", [(512, 2048, 16, 94), (2048, 512, 16, 94), (128, 512, 1, 94), (256, 96, 9, 33), (1024, 2050, 2, 47)])
-def test_pointwise_gemm_and_the_general_conv_kernel_form_the_same_sums(cin, cout, B, T, monkeypatch):
-    """batch-invariant mode may still move a pointwise layer between gemm_pw and the k = 1 conv kernel (a batch past the 32-bit offset span, a
-    device partition below 8 CUs).  Both walk K in ascending 8-channel steps into the same fp32 accumulators — pinned here: the two kernels' outputs are
-    BIT-identical, with and without residual / GELU, so that fallback cannot change a clip's bits.  Reference: convnext.py:130-141."""
-    from vocoder_amd import _lib
-    rng = np.random.default_rng(cin + cout + B)
-    x = rng.normal(size=(B, cin, T)).astype(np.float32)
-    w = (rng.normal(size=(cout, cin, 1)) / np.sqrt(cin)).astype(np.float32)
-    b = rng.normal(size=cout).astype(np.float32)
-    res = rng.normal(size=(B, cout, T)).astype(np.float32)
-    out = {}
-    try:
-        for pw in ("0", "1", "old"):
-            monkeypatch.setenv("FV_PW", pw)
-            _lib.reload_env()
-            y1 = _run(w, b, x, post_act=_lib.FV_ACT_GELU)
-            kern = _lib.last_kernel()
-            assert kern.startswith("conv_mfma<" if pw == "old" else "gemm_pw<"), (pw, kern)
-            out[pw] = (y1, _run(w, b, x, res))
-    finally:
-        monkeypatch.delenv("FV_PW", raising=False)
-        _lib.reload_env()
-    for pw in ("0", "1"):
-        assert np.array_equal(out[pw][0], out["old"][0]) and np.array_equal(out[pw][1], out["old"][1]), pw

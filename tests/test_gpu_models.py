@@ -1285,3 +1285,25 @@ def test_batch_invariant_mode_holds_beyond_hifigan(model):
     ys = run(sub)
     for j, i in enumerate(sub):
         assert torch.equal(ys[j], y[i]), f"{model}: clip {i} in a batch of 3 differs from the batch of {B}"
+
+
+def test_batch_invariant_mode_refuses_the_launch_dependent_pointwise_fallback():
+    """the pointwise GEMM (gemm_pw.hip) addresses a launch with 32-bit byte offsets; past 4 GiB the default engine moves the layer to the k = 1
+    conv kernel, which forms OTHER sums (measured: equal bits at K = 512, different at K = 2048) — a batch-size-dependent choice, so batch-invariant
+    mode refuses the launch instead (FV_ERR_UNSUPPORTED: "split the batch").  Reference: convnext.py:130-141."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, FishVocError, convnext_config
+    cfg = dict(input_channels=16, depths=[1], dims=[64], drop_path_rate=0.0, kernel_size=7)
+    eng = Engine(_lib.FV_MODEL_CONVNEXT, backbone=convnext_config(**cfg), state_dict=syn.convnext_state_dict(cfg, 2))
+    B, T = 45_000, 94                                   # hidden layer: 45 000 x 256 x 94 x 4 B = 4.3 GB
+    x = torch.zeros((B, 16, T), device=_dev())
+    x[:, :, :] = torch.from_numpy(syn.synthetic_mel(1, 16, T, seed=5)).to(_dev())
+    eng.set_batch_invariant(True)
+    with pytest.raises(FishVocError, match="batch-invariant mode"):
+        eng(x)
+    y_small = eng(x[:8].contiguous()).clone()
+    eng.set_batch_invariant(False)
+    y = eng(x)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all())
+    assert float((y[:8] - y_small).abs().max()) <= 2e-5 and float((y[-1] - y_small[0]).abs().max()) <= 2e-5

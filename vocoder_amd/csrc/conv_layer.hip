@@ -420,8 +420,11 @@ static const char* const kGemmPwNames[GEMM_PW_COUNT] = {"64x64 w2", "32x64 w3"};
 static int choose_gemm_pw(const ConvLayer& L, const ConvRun& r, long long tout) {
     // 32-bit byte offsets over all batch items
     const long long bytes = 4LL * r.batch * std::max<long long>((long long)L.c_in * r.t_in, (long long)L.c_out * tout);
-    if (bytes >= 0xFFFFFF00LL || L.c_in < 64) return -1;   // (>= 8 chunks: the operand ring is primed unconditionally)
-    if (num_cus() < 8) return -1;   // a partition below one CU per XCD (or a failed query): the persistent grid would be empty
+    if (L.c_in < 64) return -1;   // (>= 8 chunks: the operand ring is primed unconditionally)
+    // The two launch-dependent exits.  gemm_pw and the k = 1 conv kernel do NOT form the same sums (measured round 5: equal bits at K = 512, not at
+    // K = 2048), so in batch-invariant mode they are refused (-2) instead of silently changing a clip's last bits with the batch it is part of.
+    if (bytes >= 0xFFFFFF00LL) return cur_invariant() ? -2 : -1;
+    if (num_cus() < 8) return -1;   // a partition below one CU per XCD (or a failed query): the persistent grid would be empty (fixed per device, not per call)
     if (knobs().pw != -2) return knobs().pw;   // experiments (FV_PW): force a configuration, or "old" / -1 for the conv kernel
     const long long simds = (long long)(num_cus() / 8 * 8) * 4;
     const long long n64 = ((long long)tout * r.batch + 63) / 64;
@@ -627,6 +630,12 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     // pointwise convs of the MFMA-bound kind (ConvNeXt's Linear layers): the LDS-free GEMM kernel (gemm_pw.hip)
     if (!L.transposed && L.ks == 1 && L.pad_l == 0 && L.c_in % 8 == 0 && r.pre_act == FV_ACT_NONE && r.out_mode == OUT_SET) {
         const int variant = p.x2 ? -1 : choose_gemm_pw(L, r, tout);   // (gemm_pw stages one input tensor)
+        if (variant == -2) {
+            set_error("conv_layer_run: batch-invariant mode: a pointwise layer over %d items of %lld elements is past the 32-bit offset span of the "
+                      "pointwise GEMM, and the general conv kernel forms other sums — split the batch", r.batch,
+                      (long long)std::max<long long>((long long)L.c_in * r.t_in, (long long)L.c_out * tout));
+            return FV_ERR_UNSUPPORTED;
+        }
         if (variant >= 0) {
             p.flat = 1;
             p.n_total = p.N * r.batch;
