@@ -65,8 +65,13 @@ struct Wino44Geom {
 // conv_wino_kernel: an instance whose last workgroup idles two waves measured no faster there, and the test for it in the common instance cost 3 %: LOG R4.15)
 // MT: 32-row tiles per wave.  1: workgroup = 64 rows, three waves per SIMD.  2: workgroup = 128 rows — the same staging feeds twice the products, each operand read from LDS
 // serves two MFMAs — with 128 accumulator registers per wave, two waves per SIMD.
-template <int KS, int DIL, int VAR, int MT>
+// PRE: the activation in front of the conv at compile time — 0 none (c2 of a pair: its SiLU sits in c1's epilogue), 1 SiLU (c1), 2 p.pre_act at run time
+// (leaky-ReLU: RefineGAN).  With the switch gone the staging is one basic block, and the compiler's vmcnt bookkeeping across it stays exact (round 5).
+// QR (D = 1 only): the row-split epilogue with 16-byte stores; the host launches it when the layer qualifies (wino44_quad_rows) — an instance of its own: with
+// both lean epilogues in one kernel the register allocator spills 40 - 70 values.
+template <int KS, int DIL, int VAR, int MT, int PRE, bool QR = false>
 __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_wino44_kernel(const ConvParams p) {
+    static_assert(!QR || DIL == 1, "the row-split epilogue needs contiguous quads");
     using G = Wino44Geom<KS, DIL>;
     constexpr bool C64 = VAR == 1;
     constexpr int NV = G::NV, NBQ = G::NBQ, WR = G::WR, ROW = G::ROW, SUBS = G::SUBS, CH = G::CH, RPW = G::RPW, NE = G::NE;
@@ -115,19 +120,34 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
         }
         lo[i] = row * ROW + c;
     }
-    float sx[4 * NE];   // [j * NE + i]
-    auto load_chunk = [&](int c) {
+    // Two register sets of raw activations, chunks c and c + 1 (round 5): a chunk's loads are issued at the END of the matrix loop two chunks earlier, not
+    // at the start of the previous one.  Loads return in order (one vmcnt counter), so every weight fragment requested after the activation loads waits for
+    // them too — HBM / MALL latency against the weights' L2 latency: at the loop's start that put the activation latency minus three steps of matrix work
+    // (DA fragments in flight) on every chunk's critical path (-6 % of the launch with the loads removed: tools/ablate_w44.sh, LOG R5.1).  Behind the loop
+    // the next weight wait is a whole staging phase + barrier + DA steps away.
+    float sx_a[4 * NE], sx_b[4 * NE];   // [j * NE + i]
+    // (always issued, never under a branch — the compiler's vmcnt bookkeeping falls back to "wait for everything" behind a conditional load: a chunk past
+    // the layer's last one gets an empty descriptor, its loads return 0 without touching memory)
+    auto load_chunk = [&](int c, float (&sx)[4 * NE]) {
         const int cbase = c * CH;
         const long long span = p.x_bstride - (long long)cbase * p.Tin;
         const long long rows = (long long)(p.Cin - cbase) * p.Tin;
-        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)cbase * p.Tin, (unsigned)((rows < span ? rows : span) * 4));
+        const long long lim = rows < span ? rows : span;
+        const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)(lim > 0 ? cbase : 0) * p.Tin, lim > 0 ? (unsigned)(lim * 4) : 0u);
 #pragma unroll
         for (int i = 0; i < NE; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) sx[j * NE + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, vo[i][j], 0, 0));
     };
-    auto store_chunk = [&](float* dst) {
-        act_apply_all(sx, p.pre_act, p.slope);   // act(0) == 0 keeps the zero padding
+#ifndef FV_X_W44_ABL
+#define FV_X_W44_ABL 0   // timing ablations (WRONG results; tools/probe_w44_ablation.py, LOG R5.x): 1 no transform arithmetic, 2 no scratch exchange,
+#endif                   // 4 one B read per step, 8 no plane writes, 16 no weight loads in the loop, 32 no pre-activation, 64 no activation loads after chunk 0,
+                         // 128 one store / residual load of every sixteen, 256 no post-activation
+    constexpr int ABL = FV_X_W44_ABL;
+    auto store_chunk = [&](float* dst, float (&sx)[4 * NE]) {
+        if constexpr (!(ABL & 32) && PRE != 0) act_apply_all(sx, PRE == 1 ? (int)FV_ACT_SILU : p.pre_act, p.slope);   // act(0) == 0 keeps the zero padding
+        float x4[NE], x5[NE], x6[NE];
+        if constexpr (!(ABL & 2)) {
 #pragma unroll
         for (int i = 0; i < NE; ++i)
 #pragma unroll
@@ -137,12 +157,36 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float x4[NE], x5[NE], x6[NE];
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             x4[i] = dst[lo[i] + G::X_OFF + DIL];
             x5[i] = dst[lo[i] + G::X_OFF + WR + DIL];
             x6[i] = dst[lo[i] + G::X_OFF + 2 * WR + DIL];
+        }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                x4[i] = sx[i];
+                x5[i] = sx[NE + i];
+                x6[i] = sx[2 * NE + i];
+            }
+        }
+        if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                if constexpr (!(ABL & 8)) {
+                    dst[lo[i]] = sx[i];
+                    dst[lo[i] + WR] = sx[NE + i];
+                    dst[lo[i] + 2 * WR] = sx[2 * NE + i];
+                    dst[lo[i] + 3 * WR] = sx[3 * NE + i];
+                    dst[lo[i] + 4 * WR] = x4[i];
+                    dst[lo[i] + 5 * WR] = x5[i];
+                    dst[lo[i] + G::V_INF] = x6[i];
+                } else if (p.Tin < 0) {
+                    dst[lo[i]] = sx[i] + sx[NE + i] + sx[2 * NE + i] + sx[3 * NE + i] + x4[i] + x5[i] + x6[i];
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
@@ -150,6 +194,10 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
             const float eh = fmaf(4.0f, x0, fmaf(-5.0f, x2, x4[i])), oh = fmaf(4.0f, x1, fmaf(-5.0f, x3, x5[i]));          // a = 1/2
             const float e1 = fmaf(-4.25f, x2, x4[i]) + x0, o1 = fmaf(-4.25f, x3, x5[i]) + x1;                                // a = 1
             const float e2 = fmaf(0.25f, x0, fmaf(-1.25f, x2, x4[i])), o2 = fmaf(0.25f, x1, fmaf(-1.25f, x3, x5[i]));        // a = 2
+            if constexpr ((ABL & 8) != 0) {
+                if (p.Tin < 0) dst[lo[i]] = eh + oh + e1 + o1 + e2 + o2 + x6[i];
+                continue;
+            }
             dst[lo[i]] = fmaf(0.5f, eh, oh);
             dst[lo[i] + WR] = fmaf(-0.5f, eh, oh);
             dst[lo[i] + 2 * WR] = o1 + e1;
@@ -179,18 +227,23 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
     constexpr int DA = FV_X_WINO44_DA;   // weight prefetch distance in fragments
     float4 aq[MT][DA + 1];
     float b_cur[4], b_nxt[4];
-    const int nch = C64 ? 8 / SUBS : (p.nchunk_real + SUBS - 1) / SUBS;   // (compile-time counts for C = 128 / 256 too: no difference in the step)
-    load_chunk(0);
+    // chunks in pairs (the two register sets alternate at compile time): p.nchunk is a multiple of four 8-channel blocks — the packed weights of the padding are zero
+    const int nch = C64 ? 8 / SUBS : (p.nchunk / SUBS + 1) / 2 * 2;   // (compile-time counts for C = 128 / 256 too: no difference in the step)
+    // (the same issue order as around the loop's back edge — set a, weight prefetch, set b: where the two paths into the loop header disagree the compiler
+    //  assumes the worst of both and waits for set b at the end of the first staging phase)
+    load_chunk(0, sx_a);
 #pragma unroll
     for (int d = 0; d < DA; ++d)
 #pragma unroll
         for (int i = 0; i < MT; ++i) aq[i][d] = load_a(i, d * 1024);
-    for (int c = 0; c < nch; ++c) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_chunk(1, sx_b);
+    __builtin_amdgcn_sched_barrier(0);
+    auto chunk_body = [&](int c, float (&sx)[4 * NE]) __attribute__((always_inline)) {
         float* xsb = xs + (c & 1) * (CH * ROW);
-        store_chunk(xsb);
+        store_chunk(xsb, sx);
         __syncthreads();
         if (c < 12) FV_CV_STAMP(1 + c);
-        if (c + 1 < nch) load_chunk(c + 1);
         const int gchunk_b = __builtin_amdgcn_readfirstlane((c * STEPS + DA) * 1024);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b_cur[j] = xsb[b_lane_g + G::off_of(0, j)];
@@ -210,10 +263,10 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
                     }
                 }
                 // one weight fragment per row tile (DA fragments ahead) and the next step's operands, spread over this step's MFMAs
-                if (m < MT) aq[m][DA] = load_a(m, gchunk_b + st * 1024);
+                if (m < MT && (!(ABL & 16) || st == 0)) aq[m][DA] = load_a(m, gchunk_b + st * 1024);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (j < NM_n && (j * NM) / 4 == m && m < NM)
+                    if (j < NM_n && (j * NM) / 4 == m && m < NM && (!(ABL & 4) || j == 0))
                         b_nxt[j] = xsb[(G::shared_of(v_n) ? b_lane_s : b_lane_g) + sub_n * kChunk * ROW + G::off_of(v_n, j)];
                 if (m < NM) __builtin_amdgcn_sched_barrier(0);
             }
@@ -224,9 +277,16 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
                 for (int d = 0; d < DA; ++d) aq[i][d] = aq[i][d + 1];
             if constexpr (st + 1 < STEPS) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];
+                for (int j = 0; j < 4; ++j) b_cur[j] = ((ABL & 4) && j > 0) ? b_nxt[0] : b_nxt[j];
             }
         });
+        // the chunk after next, behind every weight request of this loop (see sx_a / sx_b above)
+        if constexpr (!(ABL & 64)) load_chunk(c + 2, sx);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int c = 0; c < nch; c += 2) {
+        chunk_body(c, sx_a);
+        chunk_body(c + 1, sx_b);
     }
 
     FV_CV_STAMP(13);
@@ -243,6 +303,107 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
     const float* pb = xs + (wave ^ 1) * 2048 + 1024 + lane;   // ... and second
     // the common case — whole 32-row tiles, bias [+ residual] [+ post-activation], plain store — without per-element offset registers (conv_wino_impl.h)
     const bool lean = p.M % 32 == 0 && p.gamma == nullptr && p.out_mode == OUT_SET && p.acc_scale == 1.0f;
+    // D = 1 (every c2, a third of the c1 launches): a quad's four outputs are CONTIGUOUS samples, so the halves split a tile's ROWS instead of a quad's
+    // outputs — half h keeps accumulator registers 8 h .. 8 h + 7 (rows 16 h .. 16 h + 15 of the 32-row tile) with all four outputs of its quad column and
+    // sends the other eight — and every lane moves 16 bytes per row: 8 residual loads + 8 stores per tile, each covering whole 64-byte lines, instead of
+    // 32 + 32 single floats on a 16-byte stride.  The stores and residual loads were 11 - 18 % of a c2 launch (tools/ablate_w44.sh mask 128, LOG R5.3).
+    // Same sums in the same order as the split by outputs: y_j = (this half's partial) + (the partner's), fp32 addition commutes.
+    if constexpr (QR) {
+        {
+            const unsigned span = (unsigned)(p.y_bstride * 4);
+            const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
+            const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
+            const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(p.bias, (unsigned)(p.M * 4));
+            const int mrow = 4 * (lane >> 5);
+            const int t4 = 4 * n;                                    // first of the quad's four samples
+            const unsigned vq = t4 < p.N ? (unsigned)(mrow * p.N + t4) * 4u : 0xFFFFFFFFu;
+            const bool has_res = p.res != nullptr;
+            const float* pq = xs + (wave ^ 1) * 2048 + lane;        // partner's partials of the rows this half keeps: [kept register][output] x 64 lanes
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int mt = mt0 + i;
+                __syncthreads();
+                // partial sums of all four outputs, in place: register r of accumulator plane j becomes y_j's partial; the registers of the OTHER half's rows go
+                // to the exchange area (H at compile time under a wave-uniform branch: no selects, no copies)
+                auto phase1 = [&](auto h_c) __attribute__((always_inline)) {
+                    constexpr int H = decltype(h_c)::value;
+                    float* ex = xs + wave * 2048 + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float y0, y1, y2, y3;
+                        if constexpr (H == 0) {
+                            const float sm = acc[i][0][r] + acc[i][1][r], df = acc[i][0][r] - acc[i][1][r], m1 = acc[i][2][r];
+                            y0 = sm + m1;
+                            y1 = fmaf(0.5f, df, m1);
+                            y2 = fmaf(0.25f, sm, m1);
+                            y3 = fmaf(0.125f, df, m1) + acc[i][3][r];
+                        } else {
+                            const float sm = acc[i][1][r] + acc[i][2][r], df = acc[i][1][r] - acc[i][2][r], mm = acc[i][0][r];
+                            y0 = sm + mm;
+                            y1 = fmaf(2.0f, df, -mm);
+                            y2 = fmaf(4.0f, sm, mm);
+                            y3 = fmaf(8.0f, df, -mm) + acc[i][3][r];
+                        }
+                        if ((r >> 3) == H) {   // (r is an unrolled loop index: folded at compile time)
+                            acc[i][0][r] = y0;
+                            acc[i][1][r] = y1;
+                            acc[i][2][r] = y2;
+                            acc[i][3][r] = y3;
+                        } else {
+                            ex[((r & 7) * 4 + 0) * 64] = y0;
+                            ex[((r & 7) * 4 + 1) * 64] = y1;
+                            ex[((r & 7) * 4 + 2) * 64] = y2;
+                            ex[((r & 7) * 4 + 3) * 64] = y3;
+                        }
+                    }
+                };
+                if (h == 0) phase1(std::integral_constant<int, 0>{}); else phase1(std::integral_constant<int, 1>{});
+                __syncthreads();
+                // kept register rr <-> r = 8 H + rr <-> row mt * 32 + (r & 3) + 8 * (r >> 2) + mrow; four rows at a time (their operands requested together)
+                auto phase2 = [&](auto h_c) __attribute__((always_inline)) {
+                    constexpr int H = decltype(h_c)::value;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        float bias[4];
+                        u32x4 rq[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int row_s = mt * 32 + k + 8 * (2 * H + g);
+                            bias[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, mrow * 4, row_s * 4, 0));
+                            if (has_res) rq[k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, vq, (int)((unsigned)row_s * (unsigned)p.N * 4u), 0);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int rr = 4 * g + k, r = 8 * H + rr;
+                            const int row_s = mt * 32 + k + 8 * (2 * H + g);
+                            float o[4];
+                            // (the split by outputs forms  own + partner  in half 0 for j = 0, 1 and in half 1 for j = 2, 3: the same two addends)
+                            o[0] = fmaf(acc[i][0][r] + pq[(rr * 4 + 0) * 64], 1.0f, bias[k]);
+                            o[1] = fmaf(acc[i][1][r] + pq[(rr * 4 + 1) * 64], 1.0f, bias[k]);
+                            o[2] = fmaf(acc[i][2][r] + pq[(rr * 4 + 2) * 64], 1.0f, bias[k]);
+                            o[3] = fmaf(acc[i][3][r] + pq[(rr * 4 + 3) * 64], 1.0f, bias[k]);
+                            if (has_res) {
+                                o[0] += __uint_as_float(rq[k].x);
+                                o[1] += __uint_as_float(rq[k].y);
+                                o[2] += __uint_as_float(rq[k].z);
+                                o[3] += __uint_as_float(rq[k].w);
+                            }
+                            act_apply_all(o, p.post_act, p.slope);
+                            u32x4 v;
+                            v.x = __float_as_uint(o[0]);
+                            v.y = __float_as_uint(o[1]);
+                            v.z = __float_as_uint(o[2]);
+                            v.w = __float_as_uint(o[3]);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, yrs, vq, (int)((unsigned)row_s * (unsigned)p.N * 4u), 0);
+                        }
+                    }
+                };
+                if (h == 0) phase2(std::integral_constant<int, 0>{}); else phase2(std::integral_constant<int, 1>{});
+            }
+            FV_CV_STAMP(14);
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int mt = mt0 + i;
@@ -287,6 +448,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int so = (int)((unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);   // (< 4 GiB per item: conv_layer_run)
+                    if ((ABL & 128) && r > 0) { ra[r] = ra[0]; rb[r] = rb[0]; continue; }
                     ra[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, va, so, 0));
                     rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, vb, so, 0));
                 }
@@ -307,10 +469,23 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
                     ob[r] += rb[r];
                 }
             }
+            if constexpr (!(ABL & 256)) {
             act_apply_all(oa, p.post_act, p.slope);   // (c1 of a ResBlock pair carries the SiLU in front of c2: hifigan.py:104-106)
             act_apply_all(ob, p.post_act, p.slope);
+            }
+            if constexpr ((ABL & 128) != 0) {
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sa += oa[r];
+                    sb += ob[r];
+                }
+                oa[0] = sa;
+                ob[0] = sb;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                if ((ABL & 128) && r > 0) continue;
                 const int so = (int)((unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oa[r]), yrs, va, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ob[r]), yrs, vb, so, 0);
@@ -333,23 +508,34 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
     FV_CV_STAMP(14);
 }
 
-template <int KS, int VAR, int MT>
+// the row-split epilogue: whole quads per row (N % 4 == 0), 16-byte aligned rows of y and the residual, the lean operand set
+inline bool wino44_quad_rows(const ConvParams& p) {
+    static const bool off = std::getenv("FV_X_W44_NO_QR") != nullptr;   // A/B runs
+    return !off && p.dil == 1 && p.M % 32 == 0 && p.gamma == nullptr && p.out_mode == OUT_SET && p.acc_scale == 1.0f && p.N % 4 == 0 && (p.y_bstride & 3) == 0 &&
+           (((unsigned long long)p.y | (unsigned long long)(p.res ? p.res : p.y)) & 15ull) == 0;
+}
+
+template <int KS, int VAR, int MT, int PRE>
 inline bool launch_wino44_kc(const ConvParams& p0, int batch, hipStream_t s) {
     ConvParams p = p0;
     p.wg_total = batch * p.m_blks * p.n_tiles;
     const int grid = (p.wg_total + 7) / 8 * 8;
     switch (p.dil) {
-        case 1: hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, VAR, MT>), dim3(grid), dim3(256), 0, s, p); return true;
-        case 3: hipLaunchKernelGGL((conv_wino44_kernel<KS, 3, VAR, MT>), dim3(grid), dim3(256), 0, s, p); return true;
-        case 5: hipLaunchKernelGGL((conv_wino44_kernel<KS, 5, VAR, MT>), dim3(grid), dim3(256), 0, s, p); return true;
+        case 1:
+            if (wino44_quad_rows(p)) hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, VAR, MT, PRE, true>), dim3(grid), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, VAR, MT, PRE>), dim3(grid), dim3(256), 0, s, p);
+            return true;
+        case 3: hipLaunchKernelGGL((conv_wino44_kernel<KS, 3, VAR, MT, PRE>), dim3(grid), dim3(256), 0, s, p); return true;
+        case 5: hipLaunchKernelGGL((conv_wino44_kernel<KS, 5, VAR, MT, PRE>), dim3(grid), dim3(256), 0, s, p); return true;
         default: return false;
     }
 }
 
-template <int KS>
+// one translation unit per (kernel size, PRE): conv_wino44_k{7,11}_{none,silu,any}.hip
+template <int KS, int PRE>
 inline bool launch_wino44_k(const ConvParams& p, int rows, int batch, hipStream_t s) {
-    if (rows == 128) return launch_wino44_kc<KS, 0, 2>(p, batch, s);
-    return (p.Cin == 64 && p.M == 64) ? launch_wino44_kc<KS, 1, 1>(p, batch, s) : launch_wino44_kc<KS, 0, 1>(p, batch, s);
+    if (rows == 128) return launch_wino44_kc<KS, 0, 2, PRE>(p, batch, s);
+    return (p.Cin == 64 && p.M == 64) ? launch_wino44_kc<KS, 1, 1, PRE>(p, batch, s) : launch_wino44_kc<KS, 0, 1, PRE>(p, batch, s);
 }
 
 }  // namespace fv

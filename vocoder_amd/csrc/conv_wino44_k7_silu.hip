@@ -1,0 +1,5 @@
+// Winograd F(4,4) conv kernels for kernel size 7, activation in front: silu (one translation unit per size and PRE: parallel builds).
+#include "conv_wino44_impl.h"
+namespace fv {
+bool launch_conv_wino44_k7_silu(const ConvParams& p, int rows, int batch, hipStream_t s) { return launch_wino44_k<7, 1>(p, rows, batch, s); }
+}  // namespace fv

@@ -32,7 +32,10 @@ struct WLGeom {
     static constexpr int TCG = (WD + 15) / 16;                // transform: 16-column groups
     // weight ring: RA = MU NF fragments (MU = blocks per unrolled loop iteration), prefetch distance RA - 1 fragments of 4 MT NT MFMAs each:
     // at least ~900 cycles of matrix time
-    static constexpr int NEED = (7 + MT * NT - 1) / (MT * NT);
+#ifndef FV_X_LAT_RING
+#define FV_X_LAT_RING 7
+#endif
+    static constexpr int NEED = (FV_X_LAT_RING + MT * NT - 1) / (MT * NT);
     static constexpr int MU = (NEED + 1 + NF - 1) / NF;
     static constexpr int RA = MU * NF;
     static_assert(16 * TCG <= PW, "the transform's column groups stay inside a plane row");

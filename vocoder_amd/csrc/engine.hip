@@ -443,6 +443,7 @@ struct fv_engine {
     void drop_graphs();
     bool fuse_pairs = true;   // FV_NO_PAIR_FUSION=1 in the environment disables the fused (c1, c2) kernels (A/B runs)
     bool post_mean_fused = true;   // FV_NO_POST_SUM3=1: mean_of_three_kernel before conv_post instead of the mean formed in its staging (A/B runs)
+    int chain_max_c = 0;      // FV_CHAIN_MAX_C: stages this narrow accumulate the branch mean in the branches' last epilogues (ordered by events) instead of keeping three outputs
     int pair_max_c = 128;     // FV_PAIR_MAXC: widest stage whose (c1, c2) pairs fuse where a kernel exists (experiments)
     bool fuse_amp_convs = true;   // FV_NO_AMP_FUSION=1: BigVGAN's narrow stages run aa_snake + conv launches instead of amp_conv (A/B runs)
     // Measured in the step (BigVGAN-24k B = 64, interleaved, tools/ab_bigvgan.py): none 37.35 ms; k = 3 only 37.15; k <= 7 37.5; all 38.1.
@@ -910,7 +911,9 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
         // outputs in the last branch's final epilogue instead of a separate kernel measured 15.02 / 1.04 ms: not kept.  Neither
         // were: two streams, the longest branch on the caller's stream, a wake-up kernel on the side queues, stream priorities.
         static const char* const mean_env = std::getenv("FV_BRANCH_MEAN");   // experiments: "chain"
-        const bool tree = multi && nk == 3 && !(mean_env && mean_env[0] == 'c');
+        // Narrow stages (ch <= chain_max_c, FV_CHAIN_MAX_C): the chain, so that the HBM-bound consumers — the last upsamplers, conv_post — read ONE
+        // tensor instead of three; the k = 3 / 7 / 11 branches finish in that order anyway
+        const bool tree = multi && nk == 3 && !(mean_env && mean_env[0] == 'c') && stg->ch > chain_max_c;
         const bool order_desc = true;
         for (int jj = 0; jj < nk; ++jj) {
             const int j = (tree && order_desc) ? nk - 1 - jj : jj;
@@ -1420,6 +1423,7 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
     e->cfg = *cfg;
     if (const char* v = std::getenv("FV_NO_PAIR_FUSION")) e->fuse_pairs = !(v[0] == '1');
     if (const char* v = std::getenv("FV_PAIR_MAXC")) e->pair_max_c = std::atoi(v);
+    if (const char* v = std::getenv("FV_CHAIN_MAX_C")) e->chain_max_c = std::atoi(v);
     if (const char* v = std::getenv("FV_NO_POST_SUM3")) e->post_mean_fused = !(v[0] == '1');
     if (const char* v = std::getenv("FV_NO_AMP_FUSION")) e->fuse_amp_convs = !(v[0] == '1');
     if (const char* v = std::getenv("FV_AMP_MAXC")) e->fuse_amp_max_c = std::atoi(v);
