@@ -1,7 +1,5 @@
-python -m pytest tests/test_gpu_conv.py -q -k "f44 or heavy or 2_gib" 2>&1 | tail -3
-python -m pytest tests/test_gpu_models.py -q -x -k "hifigan or winograd or golden" 2>&1 | tail -3
-for r in 1 2; do
-  FV_X_W44_NO_QR=1 python tools/probe_w44_ablation.py "no QR" 2>/dev/null
-  python tools/probe_w44_ablation.py "QR" 2>/dev/null
-done
-bash tools/ab_env.sh FV_X_W44_NO_QR "1 0" 3
+python -m pytest tests/test_gpu_conv.py -q -k "pair" 2>&1 | tail -3
+python -m pytest tests/test_gpu_models.py -q -x -k "hifigan or narrow or template or fuzz" 2>&1 | tail -3
+python tools/probe_pair_wino.py 2>/dev/null | tail -25
+FV_LIB_PATH=$PWD/vocoder_amd/csrc/libfishvoc_x_nopair8.so python tools/probe_pair_wino.py 2>/dev/null | tail -25
+bash tools/ab_libs.sh "x_nopair8 base" 3

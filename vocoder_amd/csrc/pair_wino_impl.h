@@ -361,6 +361,13 @@ __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p)
         const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)b * C * T), 0, (unsigned)(C * T) * 4u, 0x00020000);
         const float* xl = Xr + 4 * krow * G::XS + (tl < G::TT ? tl : 0);
         const bool accum = p.out_mode == OUT_ACCUM;
+        // the lane's two outputs are adjacent samples: one 8-byte store (and accumulate load) per row where every row starts 8-byte aligned — whole 64-byte
+        // lines per 16 lanes instead of two passes over every other float (round 5; the 16-byte form of conv_wino44's epilogue, LOG R5.3)
+#ifdef FV_X_NO_PAIR8
+        const bool pair8 = false;
+#else
+        const bool pair8 = (T & 1) == 0 && ((unsigned long long)p.y & 7ull) == 0;
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const f32x4w y0 = (acc[0][i] + acc[1][i]) + acc[2][i];
@@ -371,6 +378,27 @@ __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p)
                 const f32x2w xr = *(const f32x2w*)(xl + (16 * i + rg) * G::XS);
                 o0[rg] = y0[rg] + xr.x;
                 o1[rg] = y1[rg] + xr.y;
+            }
+            if (pair8) {   // (TT and t0 are even: a pair is inside the tile and the row, or outside both)
+                if (accum) {
+                    u32x2 a[4];
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        a[rg] = __builtin_amdgcn_raw_buffer_load_b64(yrs, va, __builtin_amdgcn_readfirstlane((16 * i + rg) * T * 4), 0);
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        o0[rg] = (__uint_as_float(a[rg].x) + o0[rg]) * p.out_scale;
+                        o1[rg] = (__uint_as_float(a[rg].y) + o1[rg]) * p.out_scale;
+                    }
+                }
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    u32x2 v;
+                    v.x = __float_as_uint(o0[rg]);
+                    v.y = __float_as_uint(o1[rg]);
+                    __builtin_amdgcn_raw_buffer_store_b64(v, yrs, va, __builtin_amdgcn_readfirstlane((16 * i + rg) * T * 4), 0);
+                }
+                continue;
             }
             if (accum) {
                 float a0[4], a1[4];
@@ -591,14 +619,30 @@ __global__ __launch_bounds__(256, 2) void pair_wino32_kernel(const PairParams p)
     const unsigned va = (tl < G::TT && t < T) ? (unsigned)(mrow0 * T + t) * 4u : 0xFFFFFFFFu;
     const unsigned vb = (tl + 1 < G::TT && t + 1 < T) ? (unsigned)(mrow0 * T + t + 1) * 4u : 0xFFFFFFFFu;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)b * C * T), 0, (unsigned)(C * T) * 4u, 0x00020000);
+    // the lane's two outputs are adjacent samples: 8-byte residual loads / accumulate loads / stores where every row of x and y starts 8-byte aligned
+    // (pair_wino16_kernel's epilogue)
+#ifdef FV_X_NO_PAIR8
+    const bool pair8 = false;
+#else
+    const bool pair8 = (T & 1) == 0 && (((unsigned long long)p.y | (unsigned long long)p.x) & 7ull) == 0;
+#endif
     float ra[XRES ? 1 : 16], rb[XRES ? 1 : 16];
     if constexpr (!XRES) {
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)(C * T) * 4u, 0x00020000);
+        if (pair8) {
 #pragma unroll
-        for (int rg = 0; rg < 16; ++rg) {
-            const int so = __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4);
-            ra[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, va, so, 0));
-            rb[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, vb, so, 0));
+            for (int rg = 0; rg < 16; ++rg) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, va, __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4), 0);
+                ra[rg] = __uint_as_float(v.x);
+                rb[rg] = __uint_as_float(v.y);
+            }
+        } else {
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int so = __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4);
+                ra[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, va, so, 0));
+                rb[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, vb, so, 0));
+            }
         }
     }
     __syncthreads();
@@ -642,11 +686,20 @@ __global__ __launch_bounds__(256, 2) void pair_wino32_kernel(const PairParams p)
         }
         if (accum) {
             float a0[16], a1[16];
+            if (pair8) {
 #pragma unroll
-            for (int rg = 0; rg < 16; ++rg) {
-                const int so = __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4);
-                a0[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, va, so, 0));
-                a1[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, vb, so, 0));
+                for (int rg = 0; rg < 16; ++rg) {
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(yrs, va, __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4), 0);
+                    a0[rg] = __uint_as_float(v.x);
+                    a1[rg] = __uint_as_float(v.y);
+                }
+            } else {
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int so = __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4);
+                    a0[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, va, so, 0));
+                    a1[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, vb, so, 0));
+                }
             }
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) {
@@ -654,11 +707,21 @@ __global__ __launch_bounds__(256, 2) void pair_wino32_kernel(const PairParams p)
                 o1[rg] = (a1[rg] + o1[rg]) * p.out_scale;
             }
         }
+        if (pair8) {
 #pragma unroll
-        for (int rg = 0; rg < 16; ++rg) {
-            const int so = __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0[rg]), yrs, va, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1[rg]), yrs, vb, so, 0);
+            for (int rg = 0; rg < 16; ++rg) {
+                u32x2 v;
+                v.x = __float_as_uint(o0[rg]);
+                v.y = __float_as_uint(o1[rg]);
+                __builtin_amdgcn_raw_buffer_store_b64(v, yrs, va, __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4), 0);
+            }
+        } else {
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int so = __builtin_amdgcn_readfirstlane(((rg & 3) + 8 * (rg >> 2)) * T * 4);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0[rg]), yrs, va, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1[rg]), yrs, vb, so, 0);
+            }
         }
     }
 }
