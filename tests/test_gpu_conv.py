@@ -210,7 +210,7 @@ def test_winograd_pair_matches_oracle_and_direct_pair(C, k, d):
         xd = torch.from_numpy(x).to(_dev())
         y = c1.set_algorithm("auto").pair(c2, xd)
         torch.cuda.synchronize()
-        assert _last_kernel().startswith("pair_wino<"), _last_kernel()
+        assert _last_kernel().startswith(("pair_wino<", "pair_wino44<")), _last_kernel()
         _check(y.cpu().numpy(), ref)
         yd = c1.set_algorithm("direct").pair(c2, xd)
         torch.cuda.synchronize()
@@ -574,7 +574,7 @@ def test_winograd_pairs_with_heavy_tailed_weights_against_the_float64_sum(C, k, 
     c2 = FusedConv(w2, b2, padding=(k - 1) // 2)
     xd = torch.from_numpy(x).to(_dev())
     yw = c1.set_algorithm("auto").pair(c2, xd)[:nb].cpu().numpy()
-    assert _last_kernel().startswith("pair_wino<"), _last_kernel()
+    assert _last_kernel().startswith(("pair_wino<", "pair_wino44<")), _last_kernel()
     yd = c1.set_algorithm("direct").pair(c2, xd)[:nb].cpu().numpy()
     assert _last_kernel().startswith("resblock_pair<"), _last_kernel()
     ew, ed = float(np.abs(yw - ref).max()), float(np.abs(yd - ref).max())

@@ -253,6 +253,34 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
             FV_HIP_CHECK(hipMalloc((void**)&L.d_wpwl, pl.size() * sizeof(float)));
             FV_HIP_CHECK(hipMemcpy(L.d_wpwl, pl.data(), pl.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+        if ((c_in == 16 || c_in == 32) && k >= 7) {
+            // pair_wino44_impl.h: F(4,4) tap groups (the G44 transform of conv_wino44 above) as A fragments of v_mfma_f32_16x16x4_f32 (row = lane & 15, k = lane >> 4).
+            // Virtual tap v of a channel: group v / 7, plane v % 7 (+1/2 -1/2 +1 -1 +2 -2 inf; the last group has no inf tap).  Fragment (m-tile mt, chunk c of 8
+            // channels, f): .{x,y} = tap 2 f, k-steps 0 / 1 (channels 8 c + {0..3}, {4..7}); .{z,w} = tap 2 f + 1; + 8 zero fragments of prefetch overrun
+            static const double G44[6][4] = {{16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45}, {-16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45}, {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                             {2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},   {1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},    {-1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45}};
+            const int ng4 = (k + 3) / 4, nvq = 7 * (ng4 - 1) + 6, nfq = (nvq + 1) / 2, nchk = c_in / 8, mts = c_in / 16;
+            auto tap = [&](int co, int ci, int j) -> double { return j < k ? (double)wc[((size_t)co * c_in + ci) * k + j] : 0.0; };
+            auto utap = [&](int co, int ci, int v) -> float {
+                if (v >= nvq) return 0.f;
+                const int g = v / 7, pl = v % 7;
+                if (pl == 6) return (float)tap(co, ci, 4 * g + 3);
+                double u = 0.0;
+                for (int t = 0; t < 4; ++t) u += G44[pl][t] * tap(co, ci, 4 * g + t);
+                return (float)u;
+            };
+            std::vector<float> pq(((size_t)mts * nchk * nfq + 8) * 64 * 4, 0.f);
+            for (int mt = 0; mt < mts; ++mt)
+                for (int c = 0; c < nchk; ++c)
+                    for (int f = 0; f < nfq; ++f)
+                        for (int l = 0; l < 64; ++l)
+                            for (int q = 0; q < 4; ++q) {
+                                const int co = 16 * mt + (l & 15), ci = 8 * c + 4 * (q & 1) + (l >> 4), v = 2 * f + (q >> 1);
+                                pq[((((size_t)mt * nchk + c) * nfq + f) * 64 + l) * 4 + q] = utap(co, ci, v);
+                            }
+            FV_HIP_CHECK(hipMalloc((void**)&L.d_wpq16, pq.size() * sizeof(float)));
+            FV_HIP_CHECK(hipMemcpy(L.d_wpq16, pq.data(), pq.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         if (c_in == 16 || c_in == 32) {
             // pair_wino_impl.h: A fragments of v_mfma_f32_16x16x4_f32 (row = lane & 15, k = lane >> 4), one float4 per lane = four MFMAs.
             //   C = 16: fragment v            .{x,y,z,w}[s]       = W'[lane & 15][4 s + (lane >> 4)][v]                      (16 channels)
@@ -328,6 +356,8 @@ void conv_layer_destroy(ConvLayer& L) {
     L.d_wpw = nullptr;
     if (L.d_wpw16) (void)hipFree(L.d_wpw16);
     L.d_wpw16 = nullptr;
+    if (L.d_wpq16) (void)hipFree(L.d_wpq16);
+    L.d_wpq16 = nullptr;
     if (L.d_wpw44) (void)hipFree(L.d_wpw44);
     L.d_wpw44 = nullptr;
     if (L.d_wpw4) (void)hipFree(L.d_wpw4);
@@ -959,6 +989,42 @@ fv_status conv_pair_run(const ConvLayer& c1, const ConvLayer& c2, const float* x
     if (x == y) {
         set_error("conv_pair_run: output must not alias the input (halo reads)");
         return FV_ERR_INVALID;
+    }
+    // the narrow stages at k = 7 / 11: F(4,4) tap groups in both convs (pair_wino44_impl.h; round 5) — 20 / 13 products per four outputs against F(2,3)'s 32 / 20
+    if (knobs().pair_wino && knobs().pair_wino44 && effective_algo() != FV_CONV_ALGO_DIRECT && c1.d_wpq16 && c2.d_wpq16 && (C == 16 || C == 32) &&
+        (c1.k == 7 || c1.k == 11)) {
+        PairParams p;
+        std::memset(&p, 0, sizeof(p));
+        p.x = x;
+        p.y = y;
+        p.w1 = c1.d_wpq16;
+        p.w2 = c2.d_wpq16;
+        p.b1 = c1.d_bias;
+        p.b2 = c2.d_bias;
+        p.T = t;
+        p.out_mode = out_mode;
+        p.out_scale = out_scale;
+        const int prof_idx = prof_begin(stream);
+        const bool ok = c1.k == 7 ? launch_pair_wino44_k7(p, C, c1.dil, batch, stream) : launch_pair_wino44_k11(p, C, c1.dil, batch, stream);
+        if (!ok) {
+            if (dynamic_lds_refused()) return FV_ERR_HIP;
+            set_error("conv_pair_run: no F(4,4) pair kernel for (C=%d k=%d d=%d)", C, c1.k, c1.dil);
+            return FV_ERR_UNSUPPORTED;
+        }
+        char name[96];
+        std::snprintf(name, sizeof(name), "pair_wino44<k=%d d=%d C=%d>", c1.k, c1.dil, C);
+        set_last_kernel(name);
+        if (prof_idx >= 0) {
+            const int nbq = 16 * (4 / (C / 16));
+            const int tt = 4 * (nbq / c1.dil * c1.dil) - (c1.k - 1);   // PQGeom::TT
+            char lbl[128];
+            std::snprintf(lbl, sizeof(lbl), "%s grid=%d", name, batch * ((t + tt - 1) / tt));
+            const double macs = 2.0 * C * C * c1.k * (double)t * batch;   // ALGORITHMIC (direct-sum) MACs of the two convs
+            const double elems = (out_mode == OUT_ACCUM ? 3.0 : 2.0) * C * (double)t * batch;
+            prof_end(stream, prof_idx, lbl, 2.0 * macs, elems * 4.0 + 2.0 * C * C * c1.k * 4.0);
+        }
+        FV_HIP_CHECK(hipGetLastError());
+        return FV_OK;
     }
     const bool wide = C >= 64;   // 32x32x2 kernels on the layers' d_wpw; C <= 32: 16x16x4 kernels on d_wpw16
     if (knobs().pair_wino && effective_algo() != FV_CONV_ALGO_DIRECT && (wide ? (c1.d_wpw && c2.d_wpw) : (c1.d_wpw16 && c2.d_wpw16)) &&

@@ -241,11 +241,21 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
         const int mrow = 4 * (lane >> 5);                                   // lane part of the row; + mt0 * 32 + (r & 3) + 8 * (r >> 2) in SGPRs
         const unsigned va = ta < p.N ? (unsigned)(mrow * p.N + ta) * 4u : 0xFFFFFFFFu;
         const unsigned vb = tb < p.N ? (unsigned)(mrow * p.N + tb) * 4u : 0xFFFFFFFFu;
+        // D = 1: the pair's two outputs are adjacent samples — 8-byte residual loads and stores where every row starts 8-byte aligned (round 5, LOG R5.3)
+        const bool pair8 = DIL == 1 && (p.N & 1) == 0 && (p.y_bstride & 1) == 0 &&
+                           (((unsigned long long)p.y | (unsigned long long)(p.res ? p.res : p.y)) & 7ull) == 0;
         float bias[16], ra[16], rb[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             bias[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, mrow * 4, (mt0 * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
-        if (p.res) {
+        if (p.res && pair8) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rrs, va, (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u), 0);
+                ra[r] = __uint_as_float(v.x);
+                rb[r] = __uint_as_float(v.y);
+            }
+        } else if (p.res) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int so = (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);   // (< 4 GiB per item: conv_layer_run)
@@ -271,11 +281,21 @@ __global__ __launch_bounds__(256, (NT == 1 ? FV_X_WINO_OCC1 : 2)) void conv_wino
         }
         act_apply_all(oa, p.post_act, p.slope);   // (c1 of a ResBlock pair carries the SiLU in front of c2: hifigan.py:104-106)
         act_apply_all(ob, p.post_act, p.slope);
+        if (pair8) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int so = (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oa[r]), yrs, va, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ob[r]), yrs, vb, so, 0);
+            for (int r = 0; r < 16; ++r) {
+                u32x2 v;
+                v.x = __float_as_uint(oa[r]);
+                v.y = __float_as_uint(ob[r]);
+                __builtin_amdgcn_raw_buffer_store_b64(v, yrs, va, (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u), 0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = (int)((unsigned)(mt0 * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oa[r]), yrs, va, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ob[r]), yrs, vb, so, 0);
+            }
         }
 #ifdef FV_X_CONV_TS
         __builtin_amdgcn_s_waitcnt(0);

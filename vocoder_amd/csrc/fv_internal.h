@@ -32,6 +32,7 @@ struct Knobs {
     int wino_min_blocks = -1;   // FV_WINO_MIN_BLOCKS: fewest workgroups of a launch that takes it, -1 = default
     int vec_store = 1;    // FV_VEC_STORE: 0 = the stride-8 upsamplers store single floats instead of 16-byte output quads (A/B runs, tests)
     // (FV_WINO4 / FV_WINO44 are also read when a layer is CREATED: it packs only the Winograd form they select — conv_layer.hip)
+    int pair_wino44 = 1;  // FV_PAIR_WINO44: 1 = the fused narrow pairs at k = 7 / 11 on F(4,4) tap groups (pair_wino44_impl.h), 0 = F(2,3) (pair_wino_impl.h)
     int wino44 = 1;       // FV_WINO44: 1 = F(4,4) tap groups (conv_wino44_impl.h) for k = 7 / 11 where FV_WINO4 would take F(4,3), 0 = F(4,3) there
     int wino44_rows = 0;  // FV_WINO44_ROWS: 64 = one 32-row tile per wave (64-row workgroups) everywhere; otherwise two (128 rows) where the layer has whole 128-row blocks
     int wino4 = 1;        // FV_WINO4: 1 = the quad-lattice kernels (conv_wino44_impl.h / conv_wino4_impl.h) for k = 7 / 11 where the Winograd path is taken and the layer has whole 64-row blocks, 0 = F(2,3) everywhere
@@ -164,6 +165,7 @@ struct ConvLayer {
     float4* d_wpw4 = nullptr;  // Winograd F(4,3)-transformed weights (conv_wino4_impl.h): (32-row tile, plane half) x chunk x nv4 fragments; optional
     int nv4 = 0;
     float4* d_wpwl = nullptr;  // Winograd-transformed weights of the latency kernel: 16-row tiles, 8-channel blocks, tap pairs (conv_wino_lat_impl.h); optional
+    float4* d_wpq16 = nullptr; // Winograd F(4,4)-transformed weights in 16x16x4 fragment order, C -> C with C in {16, 32}, k in {7, 11} (pair_wino44_impl.h); optional
     float4* d_wpw16 = nullptr; // Winograd-transformed weights in 16x16x4 fragment order, C -> C with C in {16, 32} (pair_wino_impl.h); optional
     void* d_wph16 = nullptr;   // f16x3 mode, 16 -> 16 channel Conv1d: (wh, wl) planes of the two-samples-per-row layout (pair16_f16x3.hip)
     void* d_wph = nullptr;     // f16x3 mode: (wh, wl, wh * 2^-11) fp16 planes in 32x32x16 fragment order (optional)
@@ -288,6 +290,8 @@ bool launch_conv_wino_k11(const ConvParams& p, int cfg, int batch, hipStream_t s
 bool launch_conv_wino4_k7(const ConvParams& p, int batch, hipStream_t s);
 bool launch_conv_wino4_k11(const ConvParams& p, int batch, hipStream_t s);
 // conv_wino44_impl.h: F(4,4) tap groups, 64 rows x 32 quad columns per workgroup; p.wp = the layer's d_wpw44, p.m_blks = M / 64, p.n_tiles over quad columns
+bool launch_pair_wino44_k7(const PairParams& p, int C, int dil, int batch, hipStream_t s);
+bool launch_pair_wino44_k11(const PairParams& p, int C, int dil, int batch, hipStream_t s);
 bool launch_conv_wino44_k7(const ConvParams& p, int rows, int batch, hipStream_t s);
 bool launch_conv_wino44_k11(const ConvParams& p, int rows, int batch, hipStream_t s);
 // conv_wino_lat_impl.h: latency variant (16 rows x 16 nt pairs per workgroup, K split over the four waves); p.wp = the layer's d_wpwl,
