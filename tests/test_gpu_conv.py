@@ -190,32 +190,42 @@ def test_fused_resblock_pair_matches_oracle(C, k, d, B, T):
 PAIR_WINO_CASES = [(C, k, d) for C in (16, 32) for k in (3, 7, 11) for d in (1, 3, 5)]
 
 
-@pytest.mark.parametrize("C,k,d", PAIR_WINO_CASES)
-def test_winograd_pair_matches_oracle_and_direct_pair(C, k, d):
-    """pair_wino_impl.h: every (C, k, dilation) variant of the Winograd fused pair on ragged shapes — several tiles with a ragged last one,
-    a row shorter than one tile, T = 1 and an odd T — against the CPU oracle (reference hifigan.py:102-107), and against the direct-sum pair
-    kernel selected through the C ABI (fv_conv_set_algorithm): same outputs to fp32 rounding, other sums."""
+@pytest.mark.parametrize("C,k,d,form", [(C, k, d, f) for (C, k, d) in PAIR_WINO_CASES for f in (("f44", "f23") if k >= 7 else ("f44",))])
+def test_winograd_pair_matches_oracle_and_direct_pair(C, k, d, form, monkeypatch):
+    """Every (C, k, dilation) variant of the Winograd fused pairs on ragged shapes — several tiles with a ragged last one, a row shorter than one tile,
+    T = 1, odd T (no 8-byte stores), a length that ends on a partly valid quad — against the CPU oracle (reference hifigan.py:102-107), and against the
+    direct-sum pair kernel selected through the C ABI (fv_conv_set_algorithm): same outputs to fp32 rounding, other sums.  form f44 (the default): k = 7 / 11
+    on F(4,4) tap groups (pair_wino44_impl.h, round 5), k = 3 on F(2,3); f23 (FV_PAIR_WINO44=0): F(2,3) everywhere (pair_wino_impl.h)."""
+    from vocoder_amd import _lib
     from vocoder_amd.engine import FusedConv
     rng = np.random.default_rng(7 * C + 13 * k + d)
     w1 = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
     w2 = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
     b1 = rng.normal(size=C).astype(np.float32)
     b2 = rng.normal(size=C).astype(np.float32)
-    c1 = FusedConv(w1, b1, dilation=d, padding=(k * d - d) // 2)
-    c2 = FusedConv(w2, b2, padding=(k - 1) // 2)
-    for B, T in ((2, 1000 + 37 * d), (1, 61), (3, 1), (1, 2 * 128 - k)):
-        x = rng.normal(size=(B, C, T)).astype(np.float32)
-        xt = orc.conv1d(orc.silu(x), w1, b1, dilation=d, padding=(k * d - d) // 2)
-        ref = x + orc.conv1d(orc.silu(xt), w2, b2, padding=(k - 1) // 2)
-        xd = torch.from_numpy(x).to(_dev())
-        y = c1.set_algorithm("auto").pair(c2, xd)
-        torch.cuda.synchronize()
-        assert _last_kernel().startswith(("pair_wino<", "pair_wino44<")), _last_kernel()
-        _check(y.cpu().numpy(), ref)
-        yd = c1.set_algorithm("direct").pair(c2, xd)
-        torch.cuda.synchronize()
-        assert _last_kernel().startswith("resblock_pair<"), _last_kernel()
-        assert float((y - yd).abs().max()) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+    if form == "f23":
+        monkeypatch.setenv("FV_PAIR_WINO44", "0")
+    _lib.reload_env()
+    try:
+        c1 = FusedConv(w1, b1, dilation=d, padding=(k * d - d) // 2)
+        c2 = FusedConv(w2, b2, padding=(k - 1) // 2)
+        want = "pair_wino44<" if (form == "f44" and k >= 7) else "pair_wino<"
+        for B, T in ((2, 1000 + 37 * d), (1, 61), (3, 1), (1, 2 * 128 - k), (2, 1302), (1, 3)):
+            x = rng.normal(size=(B, C, T)).astype(np.float32)
+            xt = orc.conv1d(orc.silu(x), w1, b1, dilation=d, padding=(k * d - d) // 2)
+            ref = x + orc.conv1d(orc.silu(xt), w2, b2, padding=(k - 1) // 2)
+            xd = torch.from_numpy(x).to(_dev())
+            y = c1.set_algorithm("auto").pair(c2, xd)
+            torch.cuda.synchronize()
+            assert _last_kernel().startswith(want), (_last_kernel(), want)
+            _check(y.cpu().numpy(), ref)
+            yd = c1.set_algorithm("direct").pair(c2, xd)
+            torch.cuda.synchronize()
+            assert _last_kernel().startswith("resblock_pair<"), _last_kernel()
+            assert float((y - yd).abs().max()) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+    finally:
+        monkeypatch.delenv("FV_PAIR_WINO44", raising=False)
+        _lib.reload_env()
 
 
 def test_fused_pair_rejects_unsupported_shapes():

@@ -17,7 +17,8 @@ def key_of(kernel_name: str, grid_threads: int):
     if m:
         ks, dil, wm, wn, nt = map(int, m.groups())
         return f"conv_wino k={ks} d={dil} tile={wm * 32}x{wn * nt * 32}p grid={blocks}"
-    m = re.search(r"conv_wino44_kernel<(\d+), (\d+), (\d+), (\d+)>", kernel_name)   # (KS, DIL, VAR: 1 = the 64-channel layers, MT): 64 MT rows x 32 quad columns, 256 threads
+    # (KS, DIL, VAR: 1 = the 64-channel layers, MT [, PRE, QR: round 5 — the activation in front and the row-split epilogue do not change the key]): 64 MT rows x 32 quad columns
+    m = re.search(r"conv_wino44_kernel<(\d+), (\d+), (\d+), (\d+)(?:, \d+)?(?:, (?:true|false))?>", kernel_name)
     if m:
         return f"conv_wino44 k={m.group(1)} d={m.group(2)} tile={64 * int(m.group(4))}x32q{' c64' if m.group(3) == '1' else ''} grid={blocks}"
     m = re.search(r"conv_wino4_kernel<(\d+), (\d+), (\d+), (true|false)>", kernel_name)   # (KS, DIL, WM, C64): tile = rows x QUAD columns, 128 WM threads
@@ -37,6 +38,9 @@ def key_of(kernel_name: str, grid_threads: int):
     m = re.search(r"pair16_f16x3_kernel<(\d+), (\d+)>", kernel_name)
     if m:
         return f"pair_f16x3 k={m.group(1)} d={m.group(2)} C=16 grid={blocks}"
+    m = re.search(r"pair_wino44_kernel<(\d+), (\d+), (\d+)>", kernel_name)   # (KS, DIL, C)
+    if m:
+        return f"pair_wino44 k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={blocks}"
     m = re.search(r"pair_wino(?:16|32)_kernel<(\d+), (\d+), (\d+),", kernel_name)   # (KS, DIL, C, chunk, ...)
     if m:
         return f"pair_wino k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={blocks}"
@@ -69,6 +73,9 @@ def bench_key(label: str):
     m = re.search(r"resblock_pair<k=(\d+) d=(\d+) C=(\d+)> grid=(\d+)", label)
     if m:
         return f"resblock_pair k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={m.group(4)}"
+    m = re.search(r"pair_wino44<k=(\d+) d=(\d+) C=(\d+)> grid=(\d+)", label)
+    if m:
+        return f"pair_wino44 k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={(int(m.group(4)) + 7) // 8 * 8}"
     m = re.search(r"pair_wino<k=(\d+) d=(\d+) C=(\d+)> grid=(\d+)", label)
     if m:   # (the launch's grid is rounded up to a multiple of the 8 XCDs: key_of sees the rounded count)
         return f"pair_wino k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={(int(m.group(4)) + 7) // 8 * 8}"

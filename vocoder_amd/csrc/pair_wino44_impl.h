@@ -48,7 +48,10 @@ struct PQGeom {
     static constexpr int X_F = C * SX, XR_F = C * XS + 16;
     static constexpr int TRASH = X_F + V_F + XR_F;
     static constexpr int LDS_FLOATS = TRASH + 4;
-    static constexpr int DA = 4, RA = DA + 1;            // weight prefetch distance / ring slots (fragments)
+#ifndef FV_X_PQ_DA
+#define FV_X_PQ_DA 4
+#endif
+    static constexpr int DA = FV_X_PQ_DA, RA = DA + 1;   // weight prefetch distance / ring slots (fragments)
     static_assert(PX >= WR1 && PX >= WR2 && PV >= WD1 && PV >= WD2, "plane strides cover both convs");
     static constexpr int g_of(int v) { return v / 7; }
     static constexpr int a_of(int v) { return v % 7; }
@@ -218,7 +221,10 @@ __device__ __forceinline__ void pq_output_transform(const f32x4w (&m)[7], f32x4w
 }
 
 template <int KS, int DIL, int C>
-__global__ __launch_bounds__(256, 3) void pair_wino44_kernel(const PairParams p) {
+#ifndef FV_X_PQ_OCC
+#define FV_X_PQ_OCC 3
+#endif
+__global__ __launch_bounds__(256, FV_X_PQ_OCC) void pair_wino44_kernel(const PairParams p) {
     using G = PQGeom<KS, DIL, C>;
     constexpr int DA = G::DA, NCHK = G::NCHK, NF = G::NF;
     extern __shared__ __attribute__((aligned(16))) float lds[];
