@@ -305,13 +305,16 @@ def roofline_from_profile(table: list[dict], repeats: int) -> dict:
     if os.path.exists(tpath):
         try:
             sys.path.insert(0, os.path.join(REPO, "tools"))
-            from pmc_traffic import bench_key
+            from pmc_traffic import bench_key, kernel_source_sha16
             tj = json.load(open(tpath))
             ent = tj.get(bench_key(top["kernel"]))
             traffic = ent["hbm_bytes_per_launch"] if ent else None
             if ent:
+                # looked up, so it can go stale: the collection records a hash of the kernel sources, compared with this tree's
+                same = tj.get("_src_sha16") == kernel_source_sha16()
                 traffic_src = ("profiles/traffic.json (rocprofv3 PMC passes of " + str(tj.get("_build", "round-1 build r01f")) +
-                               "; looked up by kernel name, not measured in this run)")
+                               "; looked up by kernel name, not measured in this run; kernel sources " +
+                               ("unchanged since that collection)" if same else "CHANGED since that collection: figure may be stale)"))
         except Exception:
             traffic = None
     if t_mfma >= t_hbm:

@@ -7,6 +7,19 @@ usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> [out.json] [--merge] 
 import collections, csv, glob, json, os, re, sys
 
 
+def kernel_source_sha16() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources (vocoder_amd/csrc/*.hip, *.h, sorted by name): recorded next to a PMC collection, and
+    compared by bench.py with the tree it runs from — a traffic figure looked up for a kernel whose source changed since is flagged stale."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vocoder_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def key_of(kernel_name: str, grid_threads: int):
     blocks = grid_threads // 256
     m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", kernel_name)
@@ -122,5 +135,6 @@ if __name__ == "__main__":
     for i, a in enumerate(sys.argv):   # --build NAME: recorded as "_build" (bench.py quotes it in roofline.traffic_source)
         if a == "--build" and i + 1 < len(sys.argv):
             res["_build"] = sys.argv[i + 1]
+            res["_src_sha16"] = kernel_source_sha16()
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(f"{len(res)} kernels -> {out}")
