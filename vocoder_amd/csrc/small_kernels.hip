@@ -433,25 +433,47 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
 // of the up-sampler input), every position is computed the same way, then the positions outside [0, T) are overwritten with the
 // first even / last odd sample (replicate padding of the 2x-rate signal: aa_snake_tile's a.y = a.x / a.x = a.y) and the stores
 // are masked — the same values as the pair form, element for element.
+// A tile's raw samples in registers: 1024 centre samples as one dwordx4 per thread, 6 + 7 halo samples by the first lanes of waves 0 / 1.  Split from the
+// tile's arithmetic (round 5) so that a workgroup can request its SECOND tile before it computes the first: the pass is bound by bytes in flight (one 4 KB
+// tile per workgroup and eight workgroups per CU cover ~2 us of latency at ~4.6 TB/s), not by its instruction count (LOG R4.19, R5.9).
+typedef float aa_f4 __attribute__((ext_vector_type(4)));
+struct AaRegs {
+    aa_f4 c;
+    float h;
+};
 template <bool EDGE>
-__device__ __forceinline__ void aa_snake4_tile(const float* __restrict__ xr, float* __restrict__ yr, float* __restrict__ xs,
+__device__ __forceinline__ AaRegs aa4_load(const float* __restrict__ xr, int t0, int T) {
+    const int tid = threadIdx.x;
+    AaRegs r;
+    r.h = 0.f;
+    if constexpr (EDGE) {
+        auto cl = [&](int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.c[k] = xr[cl(t0 + 4 * tid + k)];
+        if (tid < 6) r.h = xr[cl(t0 - 6 + tid)];
+        if (tid >= 64 && tid < 71) r.h = xr[cl(t0 + AA_TT + tid - 64)];
+    } else {
+        r.c = *reinterpret_cast<const aa_f4*>(xr + t0 + 4 * tid);
+        if (tid < 6) r.h = xr[t0 - 6 + tid];
+        if (tid >= 64 && tid < 71) r.h = xr[t0 + AA_TT + tid - 64];
+    }
+    return r;
+}
+__device__ __forceinline__ void aa4_commit(const AaRegs& r, float* __restrict__ xs) {
+    const int tid = threadIdx.x;
+    *reinterpret_cast<aa_f4*>(xs + 8 + 4 * tid) = r.c;
+    if (tid < 6) xs[2 + tid] = r.h;
+    if (tid >= 64 && tid < 71) xs[8 + AA_TT + tid - 64] = r.h;
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void aa_snake4_tile(const AaRegs& regs, float* __restrict__ yr, float* __restrict__ xs,
                                                float* __restrict__ E, float* __restrict__ O, const float* __restrict__ up_taps,
                                                const float* __restrict__ down_taps, float al, float ib, int t0, int T) {
     const int tid = threadIdx.x;
     const float al_pi = al * 0.318309886183790672f, al_lo = snake_al_lo(al, al_pi), hb = 0.5f * ib;
     typedef float f4 __attribute__((ext_vector_type(4)));
-    if constexpr (EDGE) {
-        auto cl = [&](int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
-#pragma unroll
-        for (int k = 0; k < 4; ++k) xs[8 + 4 * tid + k] = xr[cl(t0 + 4 * tid + k)];
-        if (tid < 6) xs[2 + tid] = xr[cl(t0 - 6 + tid)];
-        if (tid >= 64 && tid < 71) xs[8 + AA_TT + tid - 64] = xr[cl(t0 + AA_TT + tid - 64)];
-    } else {
-    // rows: 1024 centre samples as one dwordx4 per thread, 6 + 7 halo samples by the first lanes
-    *reinterpret_cast<f4*>(xs + 8 + 4 * tid) = *reinterpret_cast<const f4*>(xr + t0 + 4 * tid);
-    if (tid < 6) xs[2 + tid] = xr[t0 - 6 + tid];
-    if (tid >= 64 && tid < 71) xs[8 + AA_TT + tid - 64] = xr[t0 + AA_TT + tid - 64];
-    }
+    aa4_commit(regs, xs);
     float upe[6], upo[6], dne[6], dno[6];   // wave-uniform taps (SGPRs): even / odd phase of the up-sampler (gain 2 folded in), low-pass
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -545,20 +567,38 @@ __global__ __launch_bounds__(256) void aa_snake_pk_kernel(const float* __restric
                                                           int vec4, const float* __restrict__ x2, const float* __restrict__ x3) {
     __shared__ __attribute__((aligned(16))) float xs[AA_TT + 16];
     __shared__ __attribute__((aligned(16))) float A[2 * AA_ODD];
-    const int tile = blockIdx.x % n_tiles;
-    const long long row = blockIdx.x / n_tiles;  // b * C + c
+    // a workgroup owns TWO adjacent tiles of a row (vec4 form): both tiles' samples are requested before the first is computed
+    const int n_wg = (n_tiles + 1) / 2;
+    const int tile = (blockIdx.x % n_wg) * 2;
+    const long long row = blockIdx.x / n_wg;  // b * C + c
     const int c = (int)(row % C);
-    const int t0 = tile * AA_TT;
     const float al = alpha_eff[c], ib = inv_beta[c];
     const float* x2r = x2 ? x2 + row * T : nullptr;
     const float* x3r = x2 ? x3 + row * T : nullptr;
-    if (t0 >= 6 && t0 + AA_TT + 6 < T) {
-        if (vec4 && !x2) aa_snake4_tile<false>(x + row * T, y + row * T, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t0, T);
-        else aa_snake_tile<false>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T, x2r, x3r);
-    } else if (vec4 && !x2 && T >= 8)
-        aa_snake4_tile<true>(x + row * T, y + row * T, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t0, T);
-    else
-        aa_snake_tile<true>(x + row * T, y + row * T, xs, A, up_taps, down_taps, al, ib, t0, T, x2r, x3r);
+    const float* xr = x + row * T;
+    float* yr = y + row * T;
+    auto interior = [&](int t0) { return t0 >= 6 && t0 + AA_TT + 6 < T; };
+    if (vec4 && !x2 && T >= 8) {
+        const int t0 = tile * AA_TT, t1 = t0 + AA_TT;
+        const bool two = tile + 1 < n_tiles;
+        const AaRegs r0 = interior(t0) ? aa4_load<false>(xr, t0, T) : aa4_load<true>(xr, t0, T);
+        AaRegs r1 = r0;
+        if (two) r1 = interior(t1) ? aa4_load<false>(xr, t1, T) : aa4_load<true>(xr, t1, T);
+        if (interior(t0)) aa_snake4_tile<false>(r0, yr, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t0, T);
+        else aa_snake4_tile<true>(r0, yr, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t0, T);
+        if (two) {
+            __syncthreads();   // (every thread is past the first tile's low-pass before the planes are overwritten)
+            if (interior(t1)) aa_snake4_tile<false>(r1, yr, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t1, T);
+            else aa_snake4_tile<true>(r1, yr, xs, A, A + AA_ODD, up_taps, down_taps, al, ib, t1, T);
+        }
+        return;
+    }
+    for (int k = 0; k < 2 && tile + k < n_tiles; ++k) {
+        const int t0 = (tile + k) * AA_TT;
+        if (k) __syncthreads();
+        if (interior(t0)) aa_snake_tile<false>(xr, yr, xs, A, up_taps, down_taps, al, ib, t0, T, x2r, x3r);
+        else aa_snake_tile<true>(xr, yr, xs, A, up_taps, down_taps, al, ib, t0, T, x2r, x3r);
+    }
 }
 
 fv_status launch_aa_snake(const float* x, float* y, const float* alpha_eff, const float* inv_beta, const float* up_taps,
@@ -571,7 +611,7 @@ fv_status launch_aa_snake(const float* x, float* y, const float* alpha_eff, cons
     // interior tiles move 16 bytes per lane when every row starts 16-byte aligned (aa_snake4_tile); FV_AA_VEC4=0: the pair form
     static const bool no_vec4 = std::getenv("FV_AA_VEC4") && std::getenv("FV_AA_VEC4")[0] == '0';
     const int vec4 = !no_vec4 && T % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
-    hipLaunchKernelGGL(aa_snake_pk_kernel, dim3((unsigned)((long long)B * C * n_tiles)), dim3(256), 0, s, x, y, alpha_eff,
+    hipLaunchKernelGGL(aa_snake_pk_kernel, dim3((unsigned)((long long)B * C * ((n_tiles + 1) / 2))), dim3(256), 0, s, x, y, alpha_eff,
                        inv_beta, up_taps, down_taps, C, T, n_tiles, vec4, x2, x3);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
