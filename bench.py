@@ -277,12 +277,12 @@ def executed_flops(rec: dict) -> float:
     pair_wino_impl.h), which compute the same outputs with 4 / 10 / 16 products per output pair instead of 6 / 14 / 22, and the F(4,3) ones
     (conv_wino4_impl.h): 6 / 16 / 26 per four outputs instead of 12 / 28 / 44; F(4,4) (conv_wino44_impl.h): 13 / 20 instead of 28 / 44."""
     k = rec["kernel"]
-    for pre in ("conv_wino44<k=", "pair_wino44<k="):   # (pair_wino44_impl.h, round 5: the fused narrow pairs at k = 7 / 11)
+    for pre in ("conv_wino44<k=", "pair_wino44<k=", "conv_wino_lat44<k="):   # (round 5: the fused narrow pairs and the latency kernel at k = 7 / 11)
         if k.startswith(pre):
             return rec["flops_per_launch"] * _WINO44_PRODUCTS[int(k[len(pre):].split()[0])]
     if k.startswith("conv_wino4<k="):
         return rec["flops_per_launch"] * _WINO4_PRODUCTS[int(k[len("conv_wino4<k="):].split()[0])]
-    for pre in ("conv_wino<k=", "pair_wino<k="):
+    for pre in ("conv_wino<k=", "pair_wino<k=", "conv_wino_lat<k="):
         if k.startswith(pre):
             return rec["flops_per_launch"] * _WINO_PRODUCTS[int(k[len(pre):].split()[0])]
     return rec["flops_per_launch"]

@@ -439,32 +439,66 @@ LAT_CASES = [
 ]
 
 
-def test_winograd_latency_conv_matches_oracle():
-    """conv_wino_lat_impl.h — the Winograd conv of launches too small to fill the chip (the reference's single-utterance forward,
+@pytest.mark.parametrize("form", ["f44", "f23"])
+def test_winograd_latency_conv_matches_oracle(form, monkeypatch):
+    """conv_wino_lat44_impl.h (k = 7 / 11 on whole 32-row blocks: F(4,4) tap groups on the quad lattice, the default) and conv_wino_lat_impl.h (k = 3;
+    everything under FV_LAT_WINO44=0: F(2,3)) — the Winograd convs of launches too small to fill the chip (the reference's single-utterance forward,
     test.py:88-90): 16-row tiles on 16x16x4 MFMAs, K split over the four waves.  SiLU + bias + residual, the plain conv, and
     c1's fused post-activation against the CPU oracle on ragged shapes; the direct split-K kernels on the same layer via fv_conv_set_algorithm."""
     from vocoder_amd import _lib
     from vocoder_amd.engine import FusedConv
-    for (c, k, d, B, T) in LAT_CASES:
-        rng = np.random.default_rng(c * 1000 + k * 7 + d + T)
-        x = rng.normal(size=(B, c, T)).astype(np.float32)
-        w = (rng.normal(size=(c, c, k)) / np.sqrt(c * k)).astype(np.float32)
-        b = rng.normal(size=c).astype(np.float32)
-        pad = (k - 1) * d // 2
-        ref = orc.conv1d(orc.silu(x), w, b, dilation=d, padding=pad)
-        res = rng.normal(size=ref.shape).astype(np.float32)
-        y = _run(w, b, x, res, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
-        assert _lib.last_kernel().startswith("conv_wino_lat<"), (_lib.last_kernel(), c, k, d, B, T)
-        _check(y, ref + res)
-        y2 = _run(w, None, x, None, dilation=d, padding=pad)
-        _check(y2, orc.conv1d(x, w, None, dilation=d, padding=pad))
-        y3 = _run(w, b, x, None, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU, post_act=_lib.FV_ACT_SILU)
-        _check(y3, orc.silu(ref))
-        conv = FusedConv(w, b, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU).set_algorithm("direct")
-        yd = conv(torch.from_numpy(x).to(_dev()), torch.from_numpy(res).to(_dev()))
-        torch.cuda.synchronize()
-        assert _lib.last_kernel().startswith("conv_mfma<"), _lib.last_kernel()
-        assert np.abs(yd.cpu().numpy() - y).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    monkeypatch.setenv("FV_LAT_WINO44", "1" if form == "f44" else "0")
+    _lib.reload_env()
+    try:
+        for (c, k, d, B, T) in LAT_CASES:
+            rng = np.random.default_rng(c * 1000 + k * 7 + d + T)
+            x = rng.normal(size=(B, c, T)).astype(np.float32)
+            w = (rng.normal(size=(c, c, k)) / np.sqrt(c * k)).astype(np.float32)
+            b = rng.normal(size=c).astype(np.float32)
+            pad = (k - 1) * d // 2
+            ref = orc.conv1d(orc.silu(x), w, b, dilation=d, padding=pad)
+            res = rng.normal(size=ref.shape).astype(np.float32)
+            y = _run(w, b, x, res, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
+            want = "conv_wino_lat44<" if (form == "f44" and k >= 7 and c % 32 == 0) else "conv_wino_lat<"
+            assert _lib.last_kernel().startswith(want), (_lib.last_kernel(), c, k, d, B, T)
+            _check(y, ref + res)
+            y2 = _run(w, None, x, None, dilation=d, padding=pad)
+            assert _lib.last_kernel().startswith(want), _lib.last_kernel()
+            _check(y2, orc.conv1d(x, w, None, dilation=d, padding=pad))
+            y3 = _run(w, b, x, None, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU, post_act=_lib.FV_ACT_SILU)
+            _check(y3, orc.silu(ref))
+            conv = FusedConv(w, b, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU).set_algorithm("direct")
+            yd = conv(torch.from_numpy(x).to(_dev()), torch.from_numpy(res).to(_dev()))
+            torch.cuda.synchronize()
+            assert _lib.last_kernel().startswith("conv_mfma<"), _lib.last_kernel()
+            assert np.abs(yd.cpu().numpy() - y).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    finally:
+        monkeypatch.delenv("FV_LAT_WINO44")
+        _lib.reload_env()
+
+
+@pytest.mark.parametrize("c,k,d,T", [(128, 11, 1, 5504), (256, 7, 3, 688), (64, 11, 5, 3000), (128, 7, 1, 2049)])
+def test_winograd_latency_conv_with_heavy_tailed_weights_against_the_float64_sum(c, k, d, T):
+    """conv_wino_lat44_impl.h on a layer shaped like a TRAINED one (gains over 100 x, |w| outliers, channels of unequal scale) against the float64
+    direct sum, next to the direct-sum kernel of the same layer: the bars of the batch kernels' test above.  Reference: hifigan.py:101-108."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import FusedConv
+    rng = np.random.default_rng(c * 31 + k * 7 + d)
+    w = _heavy_tailed_weight(rng, c, k)
+    b = rng.normal(size=c).astype(np.float32)
+    x = (rng.normal(size=(1, c, T)) * np.exp(rng.uniform(np.log(0.3), np.log(3.0), size=(1, c, 1)))).astype(np.float32)
+    ref = _conv1d_f64(_silu64(x), w, b, d)
+    scale = float(np.abs(ref).max())
+    xd = torch.from_numpy(x).to(_dev())
+    conv = FusedConv(w, b, dilation=d, padding=(k - 1) * d // 2, pre_act=_lib.FV_ACT_SILU)
+    yw = conv(xd).cpu().numpy()
+    assert _lib.last_kernel().startswith("conv_wino_lat44<"), _lib.last_kernel()
+    yd = conv.set_algorithm("direct")(xd).cpu().numpy()
+    assert _lib.last_kernel().startswith("conv_mfma<"), _lib.last_kernel()
+    ew, ed = float(np.abs(yw - ref).max()), float(np.abs(yd - ref).max())
+    print(f"heavy-tailed latency C={c} k={k} d={d}: scale {scale:.2f}  winograd {ew:.2e}  direct {ed:.2e}  ratio {ew / max(ed, 1e-12):.2f}")
+    assert ew <= 2e-5 * max(scale, 1.0), (ew, scale)
+    assert ew <= 4.0 * ed + 1e-6 * max(scale, 1.0), (ew, ed)
 
 
 def test_winograd_conv_offsets_beyond_2_gib(monkeypatch):

@@ -60,6 +60,9 @@ def key_of(kernel_name: str, grid_threads: int):
     m = re.search(r"conv_wino_lat_kernel<(\d+), (\d+), (\d+), (\d+)>", kernel_name)      # (KS, DIL, NT, MT)
     if m:
         return f"conv_wino_lat k={m.group(1)} d={m.group(2)} tile={16 * int(m.group(4))}x{16 * int(m.group(3))}p grid={blocks}"
+    m = re.search(r"conv_wino_lat44_kernel<(\d+), (\d+), (\d+)>", kernel_name)      # (KS, DIL, MT)
+    if m:
+        return f"conv_wino_lat44 k={m.group(1)} d={m.group(2)} tile={16 * int(m.group(3))}x16q grid={blocks}"
     m = re.search(r"resblock_pair16_kernel<(\d+), (\d+)>", kernel_name)
     if m:
         return f"resblock_pair k={m.group(1)} d={m.group(2)} C=16 grid={blocks}"
@@ -100,6 +103,9 @@ def bench_key(label: str):
     if m:
         c64 = " c64" if (m.group(4), m.group(5)) == ("64", "64") else ""
         return f"conv_wino4 k={m.group(1)} d={m.group(2)} tile={m.group(3)}{c64} grid={(int(m.group(6)) + 7) // 8 * 8}"
+    m = re.search(r"conv_wino_lat44<k=(\d+) d=(\d+) tile=(\w+)>.*grid=(\d+)", label)
+    if m:
+        return f"conv_wino_lat44 k={m.group(1)} d={m.group(2)} tile={m.group(3)} grid={m.group(4)}"
     m = re.search(r"conv_wino_lat<k=(\d+) d=(\d+) tile=(\w+)>.*grid=(\d+)", label)
     if m:
         return f"conv_wino_lat k={m.group(1)} d={m.group(2)} tile={m.group(3)} grid={m.group(4)}"

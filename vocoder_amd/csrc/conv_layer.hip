@@ -253,8 +253,8 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
             FV_HIP_CHECK(hipMalloc((void**)&L.d_wpwl, pl.size() * sizeof(float)));
             FV_HIP_CHECK(hipMemcpy(L.d_wpwl, pl.data(), pl.size() * sizeof(float), hipMemcpyHostToDevice));
         }
-        if ((c_in == 16 || c_in == 32) && k >= 7) {
-            // pair_wino44_impl.h: F(4,4) tap groups (the G44 transform of conv_wino44 above) as A fragments of v_mfma_f32_16x16x4_f32 (row = lane & 15, k = lane >> 4).
+        if ((c_in == 16 || c_in == 32 || c_in % 32 == 0) && k >= 7) {
+            // pair_wino44_impl.h (C = 16 / 32), conv_wino_lat44_impl.h (whole 32-row blocks): F(4,4) tap groups (the G44 transform of conv_wino44 above) as A fragments of v_mfma_f32_16x16x4_f32 (row = lane & 15, k = lane >> 4).
             // Virtual tap v of a channel: group v / 7, plane v % 7 (+1/2 -1/2 +1 -1 +2 -2 inf; the last group has no inf tap).  Fragment (m-tile mt, chunk c of 8
             // channels, f): .{x,y} = tap 2 f, k-steps 0 / 1 (channels 8 c + {0..3}, {4..7}); .{z,w} = tap 2 f + 1; + 8 zero fragments of prefetch overrun
             static const double G44[6][4] = {{16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45}, {-16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45}, {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
@@ -757,6 +757,27 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
             }
         } else if (knobs().wino_lat && L.d_wpwl && !r.gamma && !cur_invariant() && (r.pre_act == FV_ACT_NONE || r.pre_act == FV_ACT_SILU)) {
             // launches below the gate (single clips, small batches).  Not in batch-invariant mode (another order of the K sum than conv_wino_kernel).
+            if (knobs().lat_wino44 && L.d_wpq16 && (L.ks == 7 || L.ks == 11) && L.M % 32 == 0 && L.c_in % 32 == 0) {
+                // k = 7 / 11: F(4,4) tap groups — 13 / 20 products per four outputs against conv_wino_lat's 20 / 32.  32-row workgroups (every staged window
+                // feeds two m-tiles) while they still leave ~1.3 workgroups per CU
+                const long long nt44 = (nq + 15) / 16;
+                const long long wgs16 = (long long)r.batch * (L.M / 16) * nt44;
+                if (knobs().lat_wino44 < 2 || 2 * wgs16 >= (long long)knobs().lat_wino44 * num_cus()) {
+                    int rows44 = (wgs16 / 2) * 3 >= 4LL * num_cus() ? 32 : 16;
+                    if (const char* v = std::getenv("FV_X_LAT44_ROWS")) { if (std::atoi(v) > 0) rows44 = std::atoi(v); }
+                    p.wp = L.d_wpq16;
+                    p.m_blks = L.M / rows44;
+                    p.n_tiles = (int)nt44;
+                    const int prof_idx = prof_begin(stream);
+                    const bool launched = L.ks == 7 ? launch_conv_wino_lat44_k7(p, rows44, r.batch, stream) : launch_conv_wino_lat44_k11(p, rows44, r.batch, stream);
+                    if (!launched) {
+                        set_error("conv_layer_run: no Winograd F(4,4) latency kernel for (k=%d, dilation=%d)", L.ks, L.dil);
+                        return FV_ERR_UNSUPPORTED;
+                    }
+                    std::snprintf(name, sizeof(name), "conv_wino_lat44<k=%d d=%d tile=%dx16q>", L.ks, L.dil, rows44);
+                    return finish_conv_launch(L, r, tout, stream, prof_idx, name, (long long)r.batch * p.m_blks * p.n_tiles);
+                }
+            }
             const int tile = wino_lat_tile(L, np, r.batch, 1);
             const int rows = tile == 0 ? 16 : 32, lat_pairs = tile == 2 ? 32 : 16;
             p.wp = L.d_wpwl;

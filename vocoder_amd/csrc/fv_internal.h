@@ -36,6 +36,8 @@ struct Knobs {
     int wino44 = 1;       // FV_WINO44: 1 = F(4,4) tap groups (conv_wino44_impl.h) for k = 7 / 11 where FV_WINO4 would take F(4,3), 0 = F(4,3) there
     int wino44_rows = 0;  // FV_WINO44_ROWS: 64 = one 32-row tile per wave (64-row workgroups) everywhere; otherwise two (128 rows) where the layer has whole 128-row blocks
     int wino4 = 1;        // FV_WINO4: 1 = the quad-lattice kernels (conv_wino44_impl.h / conv_wino4_impl.h) for k = 7 / 11 where the Winograd path is taken and the layer has whole 64-row blocks, 0 = F(2,3) everywhere
+    int lat_wino44 = 1;   // FV_LAT_WINO44: 1 = launches below the Winograd gate at k = 7 / 11 run F(4,4) tap groups (conv_wino_lat44_impl.h), 0 = F(2,3) (conv_wino_lat_impl.h);
+                          //   n >= 2: ... only launches of >= n / 2 workgroups per CU in its 16-row tiling (experiments)
     int wino_lat = 1;     // FV_WINO_LAT: 0 = launches below the Winograd gate run the direct split-K kernels, 1 = the Winograd latency kernel
     int pair_wino = 1;    // FV_PAIR_WINO: 0 = the fused (c1, c2) pairs run direct sums (resblock_pair.hip), 1 = Winograd tap groups where a kernel exists
 };
@@ -165,7 +167,7 @@ struct ConvLayer {
     float4* d_wpw4 = nullptr;  // Winograd F(4,3)-transformed weights (conv_wino4_impl.h): (32-row tile, plane half) x chunk x nv4 fragments; optional
     int nv4 = 0;
     float4* d_wpwl = nullptr;  // Winograd-transformed weights of the latency kernel: 16-row tiles, 8-channel blocks, tap pairs (conv_wino_lat_impl.h); optional
-    float4* d_wpq16 = nullptr; // Winograd F(4,4)-transformed weights in 16x16x4 fragment order, C -> C with C in {16, 32}, k in {7, 11} (pair_wino44_impl.h); optional
+    float4* d_wpq16 = nullptr; // Winograd F(4,4)-transformed weights in 16x16x4 fragment order, C -> C, k in {7, 11}: C in {16, 32} for pair_wino44_impl.h, whole 32-row blocks for conv_wino_lat44_impl.h; optional
     float4* d_wpw16 = nullptr; // Winograd-transformed weights in 16x16x4 fragment order, C -> C with C in {16, 32} (pair_wino_impl.h); optional
     void* d_wph16 = nullptr;   // f16x3 mode, 16 -> 16 channel Conv1d: (wh, wl) planes of the two-samples-per-row layout (pair16_f16x3.hip)
     void* d_wph = nullptr;     // f16x3 mode: (wh, wl, wh * 2^-11) fp16 planes in 32x32x16 fragment order (optional)
@@ -299,6 +301,10 @@ bool launch_conv_wino44_k11(const ConvParams& p, int rows, int batch, hipStream_
 bool launch_conv_wino_lat_k3(const ConvParams& p, int nt, int batch, hipStream_t s);
 bool launch_conv_wino_lat_k7(const ConvParams& p, int nt, int batch, hipStream_t s);
 bool launch_conv_wino_lat_k11(const ConvParams& p, int nt, int batch, hipStream_t s);
+// conv_wino_lat44_impl.h: the same on F(4,4) tap groups (16 or 32 rows x 16 quad columns per workgroup); p.wp = the layer's d_wpq16, p.m_blks = C / rows,
+// p.n_tiles in units of 16 quad columns
+bool launch_conv_wino_lat44_k7(const ConvParams& p, int rows, int batch, hipStream_t s);
+bool launch_conv_wino_lat44_k11(const ConvParams& p, int rows, int batch, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Small fused kernels (elementwise / narrow-output / reduction)
