@@ -1,2 +1,3 @@
 mkdir -p gpurun_out/lat44
-bash tools/ab_env.sh FV_X_LAT44_ROWS "0 32" 4 --steps 5 2>&1 | tee gpurun_out/lat44/ab_rows_bench.txt
+python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/lat44/gpu_suite.txt
+python tools/fuzz_all.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/lat44/fuzz_all.txt
