@@ -33,8 +33,16 @@ constexpr int pw_up(int v, int m, int r) { return v + ((r - v % m) % m + m) % m;
 // the fragments of a chunk wherever the chunk loop is a real loop (C = 32), so every chunk starts at slot 0 and nothing is moved.
 constexpr int pw_da(int ks, int mt) { return mt == 2 ? (ks == 7 ? 4 : 3) : 4; }
 
+// k = 3 is ONE tap group: every transformed value d0..d3 of a (channel, pair column) feeds exactly one matrix product per m-tile, in the wave that owns
+// the column — so the narrow k = 3 pairs form their B operands in registers straight from the E / O planes (pw_gemm_k3) instead of passing them
+// through a d-plane buffer in LDS: no chunk buffer, no barrier inside a conv, a third of the LDS instructions.  0 = the LDS transform (A/B builds).
+#ifndef FV_X_PW_K3_REG
+#define FV_X_PW_K3_REG 1
+#endif
+
 template <int KS, int DIL, int C, int CH>
 struct PWGeom {
+    static constexpr bool K3R = KS == 3 && FV_X_PW_K3_REG != 0;
     static_assert(C == 16 || C == 32, "16x16x4 kernel: one or two 16-row m-tiles");
     static_assert(CH == 8 || CH == 16, "chunk = 8 or 16 channels");
     static_assert(C % CH == 0 && CH * (C / 16) >= 16, "a chunk holds whole weight fragments");
@@ -56,7 +64,7 @@ struct PWGeom {
     static constexpr int PD = pw_up(WD1, 8, 4);          // d plane stride:     row stride 4 PD == 16 (mod 32)  puts lanes 0-15 / 16-31 on disjoint banks
     static constexpr int SE = 2 * PE, SD = 4 * PD;
     static constexpr int XS = TT + 2;                    // raw-tile row stride (column TT: dump for the window's halo positions)
-    static constexpr int EO_F = C * SE, D_F = CH * SD, XR_F = C * XS + 16;
+    static constexpr int EO_F = C * SE, D_F = K3R ? 0 : CH * SD, XR_F = C * XS + 16;
     static constexpr int TRASH = EO_F + D_F + XR_F;      // one float nobody reads
     static constexpr int LDS_FLOATS = TRASH + 4;
     static constexpr int CHN = CH;
@@ -250,6 +258,65 @@ __device__ __forceinline__ void pw_gemm_chunk(f32x4w (&acc)[4][G::MT], const flo
     });
 }
 
+// k = 3: one conv's whole MFMA loop with the Winograd input transform in registers.  el: the lane's base into the E / O planes (k-quarter row and pair
+// column folded in).  w0: the weight fragments of channel block 0 (virtual taps 0..3) on entry; block sb + 1's travel while block sb is multiplied.
+// Per block of FCH channels: KST k-steps x (E, E', O, O') -> d0..d3 (d0 = E - E', d1 = O + E', d2 = E' - O, d3 = O - O'; E' = E[n + D]), then
+// 4 KST MT MFMAs, virtual tap fastest: consecutive instructions never share an accumulator plane.
+template <class G, int DX>
+__device__ __forceinline__ void pw_gemm_k3(f32x4w (&acc)[4][G::MT], const float* __restrict__ el, const __amdgpu_buffer_rsrc_t wrs, int wvoff,
+                                           float4 (&w0)[4]) {
+    static_assert(G::KSZ == 3 && G::NV == 4, "one tap group");
+    constexpr int KST = G::KST, MT = G::MT, FCH = G::FCH, NSB = 16 * MT / FCH;
+    float raw[2][KST][4];
+    float4 wq[2][4];
+    auto read_raw = [&](int sb, float (&r)[KST][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < KST; ++s) {
+            const float* e = el + (sb * FCH + 4 * s) * G::SE;
+            r[s][0] = e[0];
+            r[s][1] = e[DX];
+            r[s][2] = e[G::PE];
+            r[s][3] = e[G::PE + DX];
+        }
+    };
+#pragma unroll
+    for (int v = 0; v < 4; ++v) wq[0][v] = w0[v];
+    read_raw(0, raw[0]);
+    static_for<NSB>([&](auto sb_c) __attribute__((always_inline)) {
+        constexpr int sb = decltype(sb_c)::value;
+        constexpr int cur = sb & 1, nxt = cur ^ 1;
+        if constexpr (sb + 1 < NSB) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, ((sb + 1) * 4 + v) * 1024, 0);
+                wq[nxt][v] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+            }
+            read_raw(sb + 1, raw[nxt]);
+        }
+        float d[KST][4];
+#pragma unroll
+        for (int s = 0; s < KST; ++s) {
+            const float E = raw[cur][s][0], E1 = raw[cur][s][1], O = raw[cur][s][2], O1 = raw[cur][s][3];
+            d[s][0] = E - E1;
+            d[s][1] = O + E1;
+            d[s][2] = E1 - O;
+            d[s][3] = O - O1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4 * KST * MT; ++m) {
+            const int v = m % 4, mt = (m / 4) % MT, ks = m / (4 * MT);
+            const int comp = MT == 2 ? 2 * ks + mt : ks;          // (the fragment layouts of conv_layer.hip: C = 16 .[s], C = 32 .[2 s + mt])
+            const float4 a4 = wq[cur][v];
+            float apin = comp == 0 ? a4.x : comp == 1 ? a4.y : comp == 2 ? a4.z : a4.w;
+            asm volatile("" : "+v"(apin));                        // (pins the MFMA in program order: pw_gemm_chunk)
+            acc[v][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(apin, d[ks][v], acc[v][mt], 0, 0, 0);
+            asm volatile("" : "+v"(acc[v][mt]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
 template <int KS, int DIL, int C, int CH>
 __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p) {
     using G = PWGeom<KS, DIL, C, CH>;
@@ -274,12 +341,18 @@ __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p)
     const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 0x7fffffff, 0x00020000);
     const int wvoff = lane * 16;
     float4 aq[G::RA];
+    float4 w0[4];                                 // k = 3 (pw_gemm_k3): the fragments of the conv's first channel block
     auto load_w = [&](const __amdgpu_buffer_rsrc_t rs, int f) __attribute__((always_inline)) {
         const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, wvoff, f * 1024, 0);
         return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
     };
+    if constexpr (G::K3R) {
 #pragma unroll
-    for (int d = 0; d < DA; ++d) aq[d] = load_w(w1rs, d);
+        for (int v = 0; v < 4; ++v) w0[v] = load_w(w1rs, v);
+    } else {
+#pragma unroll
+        for (int d = 0; d < DA; ++d) aq[d] = load_w(w1rs, d);
+    }
 
     pw_stage_window<G, C, true>(xb, T, t0, wave, lane, lds);
 
@@ -302,15 +375,22 @@ __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p)
     __syncthreads();
 
     // ---- c1 ----
-    for (int c = 0; c < NCHK; ++c) {
-        pw_transform<G, DIL, G::WD1>(EO + c * CH * G::SE, Db, tid);
-        __syncthreads();
-        pw_gemm_chunk<G, DIL>(acc, dl, el + c * CH * G::SE, w1rs, wvoff, __builtin_amdgcn_readfirstlane((c * G::NF4 + DA) * 1024), aq);
-        __syncthreads();   // the chunk buffer (next transform) and the E / O planes (c1 epilogue) are free again
-    }
-    // c2's first weight fragments travel while the epilogue runs (the ring holds c1's overrun fragments: zeros, never used)
+    if constexpr (G::K3R) {
+        pw_gemm_k3<G, DIL>(acc, el, w1rs, wvoff, w0);
+        __syncthreads();   // every wave has read its E / O columns: the c1 epilogue overwrites the planes
 #pragma unroll
-    for (int d = 0; d < DA; ++d) aq[d] = load_w(w2rs, d);
+        for (int v = 0; v < 4; ++v) w0[v] = load_w(w2rs, v);
+    } else {
+        for (int c = 0; c < NCHK; ++c) {
+            pw_transform<G, DIL, G::WD1>(EO + c * CH * G::SE, Db, tid);
+            __syncthreads();
+            pw_gemm_chunk<G, DIL>(acc, dl, el + c * CH * G::SE, w1rs, wvoff, __builtin_amdgcn_readfirstlane((c * G::NF4 + DA) * 1024), aq);
+            __syncthreads();   // the chunk buffer (next transform) and the E / O planes (c1 epilogue) are free again
+        }
+        // c2's first weight fragments travel while the epilogue runs (the ring holds c1's overrun fragments: zeros, never used)
+#pragma unroll
+        for (int d = 0; d < DA; ++d) aq[d] = load_w(w2rs, d);
+    }
 
     // ---- c1 epilogue: silu(c1 + b1) -> E / O planes of c2's lattice (mid[u], u = position - (t0 - H2): E2[u >> 1] / O2[u >> 1]) ----
     {
@@ -345,11 +425,15 @@ __global__ __launch_bounds__(256, 4) void pair_wino16_kernel(const PairParams p)
     __syncthreads();
 
     // ---- c2 (dilation 1) ----
-    for (int c = 0; c < NCHK; ++c) {
-        pw_transform<G, 1, G::WD2>(EO + c * CH * G::SE, Db, tid);
-        __syncthreads();
-        pw_gemm_chunk<G, 1>(acc, dl, el + c * CH * G::SE, w2rs, wvoff, __builtin_amdgcn_readfirstlane((c * G::NF4 + DA) * 1024), aq);
-        if (c + 1 < NCHK) __syncthreads();
+    if constexpr (G::K3R) {
+        pw_gemm_k3<G, 1>(acc, el, w2rs, wvoff, w0);
+    } else {
+        for (int c = 0; c < NCHK; ++c) {
+            pw_transform<G, 1, G::WD2>(EO + c * CH * G::SE, Db, tid);
+            __syncthreads();
+            pw_gemm_chunk<G, 1>(acc, dl, el + c * CH * G::SE, w2rs, wvoff, __builtin_amdgcn_readfirstlane((c * G::NF4 + DA) * 1024), aq);
+            if (c + 1 < NCHK) __syncthreads();
+        }
     }
 
     // ---- c2 epilogue: + raw x (LDS) -> y ----
