@@ -54,6 +54,7 @@ template <int KS, int DIL, int NT, int MT>
 __device__ __forceinline__ void wino_lat_body(const ConvParams& p, float* __restrict__ lds, int wg) {
     using G = WLGeom<KS, DIL, NT, MT>;
     constexpr int NF = G::NF, NSLOT = G::NSLOT, PW = G::PW, PLANE = G::PLANE, MU = G::MU, RA = G::RA;
+    constexpr bool K3R = KS == 3 && FV_X_PW_K3_REG != 0;   // the Winograd input transform in registers
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,18 +151,34 @@ __device__ __forceinline__ void wino_lat_body(const ConvParams& p, float* __rest
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     // d0 = E - E', d1 = O + E', d2 = E' - O, d3 = O - O'   (E' = E[n + D])
+                    float dk3[K3R ? 2 : 1][4][NT];   // k = 3: [quad][virtual tap][n-tile], formed in registers (pair_wino_impl.h, pw_gemm_k3)
+                    if constexpr (K3R) {
+                        // one tap group: every d value is the B operand of exactly one product per m-tile — no d planes, no second pass through LDS
 #pragma unroll
-                    for (int g = 0; g < 2 * G::TCG; ++g) {
-                        const int ro = (4 * (g & 1)) * PW + 16 * (g >> 1);
-                        const float E = tl[4 * PLANE + ro], E1 = tl[4 * PLANE + ro + DIL], O = tl[5 * PLANE + ro], O1 = tl[5 * PLANE + ro + DIL];
-                        tl[ro] = E - E1;
-                        tl[PLANE + ro] = O + E1;
-                        tl[2 * PLANE + ro] = E1 - O;
-                        tl[3 * PLANE + ro] = O - O1;
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int jn = 0; jn < NT; ++jn) {
+                                const float* e = bl + 4 * PLANE + (4 * q) * PW + 16 * jn;
+                                const float E = e[0], E1 = e[DIL], O = e[PLANE], O1 = e[PLANE + DIL];
+                                dk3[q][0][jn] = E - E1;
+                                dk3[q][1][jn] = O + E1;
+                                dk3[q][2][jn] = E1 - O;
+                                dk3[q][3][jn] = O - O1;
+                            }
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 2 * G::TCG; ++g) {
+                            const int ro = (4 * (g & 1)) * PW + 16 * (g >> 1);
+                            const float E = tl[4 * PLANE + ro], E1 = tl[4 * PLANE + ro + DIL], O = tl[5 * PLANE + ro], O1 = tl[5 * PLANE + ro + DIL];
+                            tl[ro] = E - E1;
+                            tl[PLANE + ro] = O + E1;
+                            tl[2 * PLANE + ro] = E1 - O;
+                            tl[3 * PLANE + ro] = O - O1;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (s == 0) FV_CV_STAMP(1);
                     // byte offsets of the blocks the prefetch reaches (this one + 1 ... MU ahead; past the wave's last block: that block again)
                     int wbs[MU + 1];
@@ -171,7 +188,7 @@ __device__ __forceinline__ void wino_lat_body(const ConvParams& p, float* __rest
 #pragma unroll
                     for (int h = 0; h < 4; ++h)   // h = 2 * tap-of-pair + quad
 #pragma unroll
-                        for (int jn = 0; jn < NT; ++jn) b_cur[h][jn] = bl[G::off_of(h >> 1) + (4 * (h & 1)) * PW + 16 * jn];
+                        for (int jn = 0; jn < NT; ++jn) b_cur[h][jn] = K3R ? dk3[h & 1][h >> 1][jn] : bl[G::off_of(h >> 1) + (4 * (h & 1)) * PW + 16 * jn];
                     static_for<NF>([&](auto f_c) __attribute__((always_inline)) {
                         constexpr int f = decltype(f_c)::value;
                         constexpr int A0 = G::acc_of(2 * f), A1 = G::acc_of(2 * f + 1);
@@ -197,7 +214,8 @@ __device__ __forceinline__ void wino_lat_body(const ConvParams& p, float* __rest
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             if (f + 1 < NF && i == MT - 1) {
-                                b_nxt[h][jn] = bl[G::off_of(2 * (f + 1) + (h >> 1)) + (4 * (h & 1)) * PW + 16 * jn];
+                                if constexpr (K3R) b_nxt[h][jn] = dk3[h & 1][(2 * (f + 1) + (h >> 1)) % 4][jn];
+                                else b_nxt[h][jn] = bl[G::off_of(2 * (f + 1) + (h >> 1)) + (4 * (h & 1)) * PW + 16 * jn];
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }

@@ -129,38 +129,50 @@ __device__ __forceinline__ void pq_stage_window(const float* __restrict__ xb, in
 // even / odd parts shared by +-a).  32 threads per channel row, consecutive columns.
 template <class G, int DX, int WD>
 __device__ __forceinline__ void pq_transform(const float* __restrict__ xr, float* __restrict__ v, int tid) {
-    constexpr int TPR = 256 / G::CH, SLOTS = (WD + TPR - 1) / TPR;
+    // FULL whole slots of TPR consecutive columns per channel row; the TW columns left over (WD = 64 + D (NG - 1): 1 ... 10 of a 32-column slot) are
+    // flattened over (row, column) into the first CH * TW threads — the waves past them skip the slot instead of running it all but empty
+    // (-DFV_X_PQ_TAIL=0: the masked third slot of every wave, A/B builds)
+#ifndef FV_X_PQ_TAIL
+#define FV_X_PQ_TAIL 1
+#endif
+    constexpr int TPR = 256 / G::CH;
+    constexpr int FULL = FV_X_PQ_TAIL ? WD / TPR : (WD + TPR - 1) / TPR, TW = FV_X_PQ_TAIL ? WD - FULL * TPR : 0;
+    constexpr int PS = G::CH * G::PV;   // plane stride
     const int row = tid / TPR, c0 = tid % TPR;
     const float* x = xr + row * G::SX + c0;
     float* d = v + row * G::PV + c0;
-    float a[SLOTS][7];
+    auto load7 = [&](const float* __restrict__ xp, float (&a)[7]) __attribute__((always_inline)) {
+        a[0] = xp[0];
+        a[1] = xp[G::PX];
+        a[2] = xp[2 * G::PX];
+        a[3] = xp[3 * G::PX];
+        a[4] = xp[DX];
+        a[5] = xp[G::PX + DX];
+        a[6] = xp[2 * G::PX + DX];
+    };
+    auto xform7 = [&](const float (&a)[7], float* __restrict__ dp) __attribute__((always_inline)) {
+        const float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], x4 = a[4], x5 = a[5], x6 = a[6];
+        const float eh = fmaf(4.0f, x0, fmaf(-5.0f, x2, x4)), oh = fmaf(4.0f, x1, fmaf(-5.0f, x3, x5));          // a = 1/2
+        const float e1 = fmaf(-4.25f, x2, x4) + x0, o1 = fmaf(-4.25f, x3, x5) + x1;                              // a = 1
+        const float e2 = fmaf(0.25f, x0, fmaf(-1.25f, x2, x4)), o2 = fmaf(0.25f, x1, fmaf(-1.25f, x3, x5));      // a = 2
+        dp[0] = fmaf(0.5f, eh, oh);
+        dp[PS] = fmaf(-0.5f, eh, oh);
+        dp[2 * PS] = o1 + e1;
+        dp[3 * PS] = o1 - e1;
+        dp[4 * PS] = fmaf(2.0f, e2, o2);
+        dp[5 * PS] = fmaf(-2.0f, e2, o2);
+        dp[6 * PS] = fmaf(5.25f, x2 - x4, x6 - x0);
+    };
+    float a[FULL > 0 ? FULL : 1][7], t[7];
 #pragma unroll
-    for (int j = 0; j < SLOTS; ++j) {
-        a[j][0] = x[TPR * j];
-        a[j][1] = x[G::PX + TPR * j];
-        a[j][2] = x[2 * G::PX + TPR * j];
-        a[j][3] = x[3 * G::PX + TPR * j];
-        a[j][4] = x[TPR * j + DX];
-        a[j][5] = x[G::PX + TPR * j + DX];
-        a[j][6] = x[2 * G::PX + TPR * j + DX];
-    }
+    for (int j = 0; j < FULL; ++j) load7(x + TPR * j, a[j]);
+    const bool tail = TW > 0 && tid < G::CH * TW;
+    const int tr = TW > 0 ? tid / (TW > 0 ? TW : 1) : 0, tc = FULL * TPR + tid - tr * TW;
+    if (tail) load7(xr + tr * G::SX + tc, t);
 #pragma unroll
-    for (int j = 0; j < SLOTS; ++j) {
-        if (TPR * (j + 1) <= WD || c0 + TPR * j < WD) {
-            const float x0 = a[j][0], x1 = a[j][1], x2 = a[j][2], x3 = a[j][3], x4 = a[j][4], x5 = a[j][5], x6 = a[j][6];
-            const float eh = fmaf(4.0f, x0, fmaf(-5.0f, x2, x4)), oh = fmaf(4.0f, x1, fmaf(-5.0f, x3, x5));          // a = 1/2
-            const float e1 = fmaf(-4.25f, x2, x4) + x0, o1 = fmaf(-4.25f, x3, x5) + x1;                              // a = 1
-            const float e2 = fmaf(0.25f, x0, fmaf(-1.25f, x2, x4)), o2 = fmaf(0.25f, x1, fmaf(-1.25f, x3, x5));      // a = 2
-            constexpr int PS = G::CH * G::PV;   // plane stride
-            d[TPR * j] = fmaf(0.5f, eh, oh);
-            d[PS + TPR * j] = fmaf(-0.5f, eh, oh);
-            d[2 * PS + TPR * j] = o1 + e1;
-            d[3 * PS + TPR * j] = o1 - e1;
-            d[4 * PS + TPR * j] = fmaf(2.0f, e2, o2);
-            d[5 * PS + TPR * j] = fmaf(-2.0f, e2, o2);
-            d[6 * PS + TPR * j] = fmaf(5.25f, x2 - x4, x6 - x0);
-        }
-    }
+    for (int j = 0; j < FULL; ++j)
+        if (FV_X_PQ_TAIL || TPR * (j + 1) <= WD || c0 + TPR * j < WD) xform7(a[j], d + TPR * j);
+    if (tail) xform7(t, v + tr * G::PV + tc);
 }
 
 // MFMA loop over one 8-channel chunk: NF weight fragments (taps 2 f, 2 f + 1 x k-steps 0, 1), four 16x16x4 MFMAs each, ordered (tap, ks) =
