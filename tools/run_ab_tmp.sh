@@ -1,5 +1,5 @@
-mkdir -p gpurun_out/k3
-for r in 1 2; do
-  python tools/probe_pair_wino.py 32 16 2>/dev/null | grep -v "k=3" | sed 's/^/tail1 /'
-  FV_LIB_PATH=$PWD/vocoder_amd/csrc/libfishvoc_x_pqtail0.so python tools/probe_pair_wino.py 32 16 2>/dev/null | grep -v "k=3" | sed 's/^/tail0 /'
-done | tee gpurun_out/k3/probe_pqtail.txt
+mkdir -p gpurun_out/aa
+for r in 1 2 3; do
+  python tools/ab_bigvgan.py 2 2>/dev/null | grep -E "round|serialized" | sed 's/^/full    /'
+  FV_X_ABL_AA_SNAKE=1 python tools/ab_bigvgan.py 2 2>/dev/null | grep -E "round|serialized" | sed 's/^/no-aa   /'
+done | tee gpurun_out/aa/ablation.txt

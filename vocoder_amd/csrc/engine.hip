@@ -996,7 +996,10 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 const float* src = n == 0 ? S : XB(bj);
                 const bool last = n == FV_MAX_DILATIONS - 1;
                 const float* c1_in = src;
-                if (ups.bigvgan) {
+                // FV_X_ABL_AA_SNAKE=1 (timing experiment, wrong results): the stand-alone activation passes in front of the k = 7 / 11 convs are skipped — what a
+                // step would take if that activation were free, i.e. the ceiling of ANY fusion of it into a producer or consumer (LOG R5.14)
+                static const bool abl_aa = std::getenv("FV_X_ABL_AA_SNAKE") != nullptr;
+                if (ups.bigvgan && !abl_aa) {
                     FV_PROF(bs, "aa_snake", 60.0 * B * ch * t, 8.0 * B * ch * t,
                             launch_aa_snake(src, XA(bj), br.act[2 * n].d_alpha, br.act[2 * n].d_inv_beta,
                                             br.act[2 * n].d_up, br.act[2 * n].d_down, B, ch, t, bs));
@@ -1013,7 +1016,7 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 if ((st = conv_layer_run(br.c1[n], r, bs))) return st;
                 if (dbg_here && n == dbg_pair && dbg_half == 0) break;
                 const float* c2_in = XT(bj);
-                if (ups.bigvgan) {
+                if (ups.bigvgan && !abl_aa) {
                     FV_PROF(bs, "aa_snake", 60.0 * B * ch * t, 8.0 * B * ch * t,
                             launch_aa_snake(XT(bj), XA(bj), br.act[2 * n + 1].d_alpha, br.act[2 * n + 1].d_inv_beta,
                                             br.act[2 * n + 1].d_up, br.act[2 * n + 1].d_down, B, ch, t, bs));
