@@ -763,8 +763,8 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
                 const long long nt44 = (nq + 15) / 16;
                 const long long wgs16 = (long long)r.batch * (L.M / 16) * nt44;
                 if (knobs().lat_wino44 < 2 || 2 * wgs16 >= (long long)knobs().lat_wino44 * num_cus()) {
-                    int rows44 = (wgs16 / 2) * 3 >= 4LL * num_cus() ? 32 : 16;
-                    if (const char* v = std::getenv("FV_X_LAT44_ROWS")) { if (std::atoi(v) > 0) rows44 = std::atoi(v); }
+                    // (32 rows everywhere — stage 0 of a single clip: 88 workgroups — measured the same p50: profiles/r05q_ab_lat_wino44_rows.txt)
+                    const int rows44 = (wgs16 / 2) * 3 >= 4LL * num_cus() ? 32 : 16;
                     p.wp = L.d_wpq16;
                     p.m_blks = L.M / rows44;
                     p.n_tiles = (int)nt44;
