@@ -219,7 +219,8 @@ FV_API fv_status fv_set_conv_algorithm(fv_engine* e, int32_t algo);
 FV_API fv_status fv_set_batch_invariant(fv_engine* e, int32_t enable);
 
 /* hipGraph replay of the static launch sequence (on by default; a call with the same buffers / shape / stream as an
- * earlier one replays a captured graph).  enable = 0 makes every fv_forward* enqueue its kernels eagerly — what a server
+ * earlier one replays a captured graph; calls on the null stream are captured on a stream the engine owns and replayed on the null stream).
+ * enable = 0 makes every fv_forward* enqueue its kernels eagerly — what a server
  * that never sees the same (buffers, batch, frames) twice gets.  May be called at any time.  No reference counterpart. */
 FV_API fv_status fv_set_graph_replay(fv_engine* e, int32_t enable);
 

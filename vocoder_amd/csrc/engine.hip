@@ -477,6 +477,7 @@ struct fv_engine {
     bool use_graph = true;        // FV_NO_GRAPH=1 disables hipGraph replay
     bool branch_streams = true;   // FV_SINGLE_STREAM=1 runs the ResBlock branches back to back on the caller's stream
     std::vector<hipStream_t> bstreams;   // nk-1 auxiliary streams (branch 0 runs on the caller's stream)
+    hipStream_t null_capture = nullptr;   // calls on the legacy default stream: the launch sequence is captured here, the graph is launched on stream 0
     std::vector<hipEvent_t> bev_fork, bev_last;
     fv_status ensure_branch_streams(int nk);
 
@@ -638,6 +639,7 @@ struct fv_engine {
             (void)hipGraphDestroy(g.graph);
         }
         for (auto st : bstreams) (void)hipStreamDestroy(st);
+        if (null_capture) (void)hipStreamDestroy(null_capture);
         for (auto e : bev_fork) (void)hipEventDestroy(e);
         for (auto e : bev_last) (void)hipEventDestroy(e);
         ups.destroy();
@@ -1741,8 +1743,11 @@ static fv_status forward_common(fv_engine* e, const float* d_in, const float* d_
     // hipGraph replay: a forward is ~110 launches plus fork/join events; at small batch the host launch cost dominates
     // (p50 clip latency).  The launch sequence is static for a given (pointers, batch, frames, stream), so the second
     // consecutive call with the same key is stream-captured (including the branch streams) and later calls replay it.
+    // The legacy default stream (0: where the reference's own call runs, test.py:88-90) cannot be captured, but an instantiated graph can be launched on
+    // it: the sequence is captured on an engine-owned stream and replayed on stream 0 — without the two cross-stream waits a redirect through a side
+    // stream costs every call (single clip: ~0.04 ms of 0.75).
     fv_engine::GraphKey key{d_in, d_out, d_workspace, d_template, d_noise, batch, t_in, s};
-    const bool graphable = e->use_graph && !e->profiling && s != nullptr;
+    const bool graphable = e->use_graph && !e->profiling;
     if (graphable) {
         for (auto& g : e->graphs)
             if (g.key == key) {
@@ -1750,11 +1755,19 @@ static fv_status forward_common(fv_engine* e, const float* d_in, const float* d_
                 return FV_OK;
             }
         if (e->have_last && e->last_key == key) {
-            hipError_t be = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            hipStream_t cs = s;
+            if (!cs) {
+                if (!e->null_capture && hipStreamCreateWithFlags(&e->null_capture, hipStreamNonBlocking) != hipSuccess) {
+                    (void)hipGetLastError();
+                    e->null_capture = nullptr;
+                }
+                cs = e->null_capture;
+            }
+            hipError_t be = cs ? hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) : hipErrorInvalidValue;
             if (be == hipSuccess) {
-                fv_status st = e->run_model(d_in, d_out, batch, t_in, ws, s);
+                fv_status st = e->run_model(d_in, d_out, batch, t_in, ws, cs);
                 hipGraph_t graph = nullptr;
-                hipError_t ee = hipStreamEndCapture(s, &graph);
+                hipError_t ee = hipStreamEndCapture(cs, &graph);
                 if (st == FV_OK && ee == hipSuccess && graph) {
                     hipGraphExec_t exec = nullptr;
                     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 from typing import Mapping
 
@@ -10,6 +11,8 @@ import torch
 
 from . import _lib
 from ._lib import FishVocError, check  # noqa: F401
+
+_SIDE_STREAM_FOR_DEFAULT = os.environ.get("FV_DEFAULT_STREAM_SIDE", "0") == "1"   # experiments: see Engine.forward
 
 
 def _require_cuda(x: torch.Tensor, what: str) -> None:
@@ -261,9 +264,9 @@ class Engine:
                 self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
             cur = torch.cuda.current_stream(x.device)
             run = cur
-            if cur.cuda_stream == 0:
-                # The legacy default stream cannot be stream-captured, which would rule out the engine's hipGraph
-                # replay.  Run on an engine-owned side stream, ordered after / before the caller's stream.
+            if cur.cuda_stream == 0 and _SIDE_STREAM_FOR_DEFAULT:
+                # FV_DEFAULT_STREAM_SIDE=1 (A/B runs): the round-4 route for calls on the legacy default stream — an engine-owned side stream,
+                # ordered after / before the caller's.  The library now captures such calls on a stream of its own and replays on stream 0.
                 if self._side is None or self._side.device != x.device:
                     self._side = torch.cuda.Stream(x.device)
                 run = self._side
