@@ -501,6 +501,48 @@ def test_winograd_latency_conv_with_heavy_tailed_weights_against_the_float64_sum
     assert ew <= 4.0 * ed + 1e-6 * max(scale, 1.0), (ew, ed)
 
 
+SPLITK_DIRECT_CASES = [
+    # (cin, cout, k, stride / None, B, T): the few-tap convs of a single-clip forward — conv_pre (k = 7), the polyphase upsamplers (two taps per phase,
+    # one for k = stride) — at ragged lengths, channel counts that leave a part-filled last chunk, one and two clips
+    (80, 512, 7, None, 1, 86), (80, 96, 7, None, 2, 33), (100, 64, 7, None, 1, 5), (512, 256, 16, 8, 1, 86), (256, 128, 16, 8, 1, 200), (72, 40, 16, 8, 2, 31),
+    (64, 32, 4, 2, 1, 700), (32, 16, 4, 2, 1, 1500), (48, 24, 2, 2, 1, 257),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,u,B,T", SPLITK_DIRECT_CASES)
+def test_split_k_launches_with_operands_straight_from_global_memory(cin, cout, k, u, B, T, monkeypatch):
+    """conv_mfma_splitk_direct_kernel (conv_mfma_impl.h, round 5): the few-tap split-K launches of a single clip without the LDS staging — against the CPU
+    oracle, and bit for bit against the LDS-staged kernel (FV_SPLITK_DIRECT=0): the same products in the same order.  Reference: hifigan.py:164-187, 226-231."""
+    from vocoder_amd import _lib
+    rng = np.random.default_rng(cin * 131 + cout * 7 + k + T)
+    x = rng.normal(size=(B, cin, T)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    if u is None:
+        w = (rng.normal(size=(cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+        kw = dict(padding=(k - 1) // 2, pre_act=_lib.FV_ACT_NONE)
+        ref = orc.conv1d(x, w, b, padding=(k - 1) // 2)
+    else:
+        w = (rng.normal(size=(cin, cout, k)) / np.sqrt(cin * k / u)).astype(np.float32)
+        kw = dict(transposed=True, stride=u, padding=(k - u) // 2, pre_act=_lib.FV_ACT_SILU)
+        ref = orc.conv_transpose1d(orc.silu(x), w, b, stride=u, padding=(k - u) // 2)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FV_SPLITK_DIRECT", mode)
+        _lib.reload_env()
+        try:
+            outs[mode] = _run(w, b, x, None, **kw)
+            name = _lib.last_kernel()
+            assert "splitK" in name, name
+            ks = int(name.split(" k=")[1].split()[0])   # taps of the GEMM view (polyphase: k / stride, or k scattered)
+            assert name.endswith(" direct") == (mode == "1" and ks in (1, 2, 7)), (name, mode)
+            print(mode, name)
+        finally:
+            monkeypatch.delenv("FV_SPLITK_DIRECT")
+            _lib.reload_env()
+    _check(outs["1"], ref)
+    assert np.array_equal(outs["1"], outs["0"])
+
+
 def test_winograd_conv_offsets_beyond_2_gib(monkeypatch):
     """One batch item of 2.2 GB (C = 128, T = 4.3 M samples: byte offsets past 2^31, under the 4 GiB addressing span conv_layer_run
     enforces): the Winograd kernel (staging offsets, SGPR row offsets of its epilogue) against the direct-sum kernel on the same

@@ -561,7 +561,13 @@ static fv_status conv_layer_run_f16x3(const ConvLayer& L, const ConvRun& r, Conv
 // operand once, the folded weights once — DESIGN.md §5).  One copy, so that a change to the accounting reaches every kernel family.
 static fv_status finish_conv_launch(const ConvLayer& L, const ConvRun& r, long long tout, hipStream_t stream, int prof_idx, const char* name,
                                     long long grid, const char* tags = "", bool three_inputs = false) {
-    set_last_kernel(name);
+    if (tags[0]) {
+        char full[160];
+        std::snprintf(full, sizeof(full), "%s%s", name, tags);
+        set_last_kernel(full);
+    } else {
+        set_last_kernel(name);
+    }
     if (prof_idx >= 0) {
         const double macs = (double)L.c_in * L.c_out * L.k * (L.transposed ? (double)r.t_in : (double)tout) * r.batch;
         double elems = (double)L.c_in * r.t_in + (double)L.c_out * tout;
@@ -863,8 +869,11 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     char name[96];
     std::snprintf(name, sizeof(name), "conv_mfma<%s k=%d d=%d tile=%s>", specialised ? "spec" : "generic", L.ks, L.dil,
                   kTileNames[cfg]);
+    // (split-K launches whose B operands come straight from global memory — conv_mfma_splitk_direct_kernel — carry " direct": the rule of launch_cfg())
+    const bool direct = specialised && (cfg == TILE_SPLITK_32x64 || cfg == TILE_SPLITK_32x32) && knobs().splitk_direct &&
+                        splitk_direct_shape(L.ks, L.dil, cfg == TILE_SPLITK_32x64 ? 2 : 1, p.x2 != nullptr);
     char tags[32];
-    std::snprintf(tags, sizeof(tags), "%s%s", L.transposed ? " convT" : "", p.x2 ? " sum3" : "");
+    std::snprintf(tags, sizeof(tags), "%s%s%s", L.transposed ? " convT" : "", p.x2 ? " sum3" : "", direct ? " direct" : "");
     return finish_conv_launch(L, r, tout, stream, prof_idx, name, (long long)launch_batch * p.m_blks * p.n_tiles, tags, p.x2 != nullptr);
 }
 

@@ -752,6 +752,151 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_splitk_kernel(const Conv
     }
 }
 
+// The same tile with the B operands loaded STRAIGHT FROM GLOBAL MEMORY (round 5): for the few-tap convs of a single-clip forward — the polyphase
+// upsamplers (two taps per phase), conv_pre — a 32-channel chunk is 4 KS MFMAs per wave, and staging its window through LDS costs the kernel one
+// workgroup barrier and one LDS round trip per 4 KS matrix instructions: the K loop of the stage-0 upsampler (16 chunks, 8 MFMAs each) ran at twice its
+// matrix time.  Here a lane requests the element its B operand needs — channel 8 (4 c + w) + 2 q + (lane >> 5), column n0 + (lane & 31) + 32 jn + j D —
+// one dword per MFMA, PF chunks ahead in a register ring (range-checked by the chunk's buffer descriptor: rows past C_in and columns outside [0, T_in)
+// return 0 = the conv's zero padding after the activation); no LDS, no barrier until the reduction of the four waves' K shares.  SUM3: the three branch
+// tensors are requested side by side and averaged on arrival.  The pre-activation runs per operand (a window element is the operand of up to KS taps).
+// (which launches take it: splitk_direct_pf() / splitk_direct_shape() in fv_internal.h — conv_layer.hip names the launch by the same rule)
+template <int KS, int DIL, int NT, bool SUM3>
+constexpr bool splitk_direct_ok = splitk_direct_shape(KS, DIL, NT, SUM3);
+
+template <int KS, int DIL, int NT, bool SUM3 = false>
+__global__ __launch_bounds__(256, 2) void conv_mfma_splitk_direct_kernel(const ConvParams p) {
+    constexpr int NW = 4;
+    constexpr int N_BLK = NT * 32;
+    constexpr int KSS = 4 * KS;              // k-steps (MFMAs per n-tile) per wave and 32-channel chunk
+    constexpr int NB = KSS * NT;             // B operands per wave and chunk
+    __shared__ float red[NW - 1][NT * 16][64];   // [wave-1][acc register][lane]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int n_tile = bid % p.n_tiles;
+    bid /= p.n_tiles;
+    const int m_blk = bid % p.m_blks;
+    const int b = bid / p.m_blks;
+    const int n0 = n_tile * N_BLK;
+    const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
+    const float* __restrict__ xb2 = SUM3 ? p.x2 + (long long)b * p.x_bstride : nullptr;
+    const float* __restrict__ xb3 = SUM3 ? p.x3 + (long long)b * p.x_bstride : nullptr;
+
+    f32x16 acc[1][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    // byte offset of operand (tap j, k-step q, n-tile jn) inside the wave's 8-row sub-chunk; 0xFFFFFFFF outside [0, Tin)
+    unsigned bvo[NB];
+    {
+        const int khalf = lane >> 5, col = lane & 31;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int sj = i / NT, jn = i % NT, j = sj >> 2, q = sj & 3;
+            const int t = n0 - p.pad_l + jn * 32 + col + j * DIL;
+            bvo[i] = (t >= 0 && t < p.Tin) ? (unsigned)((2 * q + khalf) * p.Tin + t) * 4u : 0xFFFFFFFFu;
+        }
+    }
+    // prefetch distance in chunks (both operands), by the registers a ring slot takes: NB (x 3: SUM3) operands + KS weight float4s
+    constexpr int PF = splitk_direct_pf(KS, NT, SUM3);
+    static_assert(PF > 0, "see splitk_direct_ok");
+    constexpr int RING = PF + 1;
+    float bq[RING][NB];
+    float bq2[SUM3 ? RING : 1][SUM3 ? NB : 1], bq3[SUM3 ? RING : 1][SUM3 ? NB : 1];
+    f32x4 aq[RING][KS];
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+    const int wvoff = lane * 16;
+    const int wtile_b = __builtin_amdgcn_readfirstlane(m_blk * p.nchunk * KS * 1024);
+    const int nchunks = (p.Cin + 8 * NW - 1) / (8 * NW);
+    const int last = nchunks - 1;
+    auto load_a = [&](int c, int j) __attribute__((always_inline)) {
+        const int soff = __builtin_amdgcn_readfirstlane(wtile_b + ((c * NW + wave) * KS + j) * 1024);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, soff, 0));
+    };
+    // descriptors of the wave's sub-chunk of chunk c: rows 8 (4 c + w) ... of the item, as many as C_in leaves (none past the last chunk)
+    auto rsrc_of = [&](const float* __restrict__ base, int c) __attribute__((always_inline)) {
+        const int r0 = 8 * (c * NW + wave);
+        const int rows = p.Cin - r0 > 0 ? p.Cin - r0 : 0;
+        return uniform_rsrc(base + (long long)(rows ? r0 : 0) * p.Tin, (unsigned)(rows * p.Tin) * 4u);
+    };
+    // operand idx of chunk c -> slot SL: B operands first (x, then x2, x3), the KS weight float4s last
+    constexpr int NL = (SUM3 ? 3 : 1) * NB + KS;
+    auto issue_load = [&](auto sl_c, auto idx_c, const __amdgpu_buffer_rsrc_t& r1, const __amdgpu_buffer_rsrc_t& r2, const __amdgpu_buffer_rsrc_t& r3,
+                          int cn) __attribute__((always_inline)) {
+        constexpr int SL = decltype(sl_c)::value, idx = decltype(idx_c)::value;
+        if constexpr (idx < NB) {
+            bq[SL][idx] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, bvo[idx], 0, 0));
+        } else if constexpr (SUM3 && idx < 2 * NB) {
+            bq2[SL][idx - NB] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, bvo[idx - NB], 0, 0));
+        } else if constexpr (SUM3 && idx < 3 * NB) {
+            bq3[SL][idx - 2 * NB] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r3, bvo[idx - 2 * NB], 0, 0));
+        } else if constexpr (idx < NL) {
+            aq[SL][idx - (NL - KS)] = load_a(cn, idx - (NL - KS));
+        }
+    };
+    static_for<PF>([&](auto d_c) {
+        constexpr int d = decltype(d_c)::value;
+        const __amdgpu_buffer_rsrc_t r1 = rsrc_of(xb, d), r2 = rsrc_of(SUM3 ? xb2 : xb, d), r3 = rsrc_of(SUM3 ? xb3 : xb, d);
+        static_for<NL>([&](auto i_c) { issue_load(d_c, i_c, r1, r2, r3, d <= last ? d : last); });
+    });
+    for (int c0 = 0; c0 < nchunks; c0 += RING) {
+        static_for<RING>([&](auto slot_c) __attribute__((always_inline)) {
+            constexpr int S = decltype(slot_c)::value;        // ring slot of chunk c
+            constexpr int SN = (S + PF) % RING;               // slot of chunk c + PF (the one chunk c - 1 used)
+            const int c = c0 + S;
+            if (c < nchunks) {
+                float bv[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    float v = bq[S][i];
+                    if constexpr (SUM3) v = ((v + bq2[S][i]) + bq3[S][i]) * (1.0f / 3.0f);
+                    bv[i] = v;
+                }
+                act_apply_all(bv, p.pre_act, p.slope);
+                const int cx = c + PF;
+                const __amdgpu_buffer_rsrc_t r1 = rsrc_of(xb, cx), r2 = rsrc_of(SUM3 ? xb2 : xb, cx), r3 = rsrc_of(SUM3 ? xb3 : xb, cx);
+                const int cn = cx <= last ? cx : last;
+                constexpr int LPS = (NL + KSS - 1) / KSS;     // loads of chunk c + PF requested per k-step, between the MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<KSS>([&](auto sj_c) __attribute__((always_inline)) {
+                    constexpr int sj = decltype(sj_c)::value;
+                    static_for<LPS>([&](auto l_c) {
+                        constexpr int idx = sj * LPS + decltype(l_c)::value;
+                        if constexpr (idx < NL) issue_load(std::integral_constant<int, SN>{}, std::integral_constant<int, idx>{}, r1, r2, r3, cn);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn)
+                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[S][sj >> 2][sj & 3], bv[sj * NT + jn], acc[0][jn], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        });
+    }
+
+    // reduce the partial tiles
+    if (wave > 0) {
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave - 1][jn * 16 + r][lane] = acc[0][jn][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][jn][r] += red[w][jn * 16 + r][lane];
+        conv_epilogue<1, NT>(p, acc, b, m_blk, n0 + (lane & 31), lane);
+    }
+}
+
 template <int KS, int DIL, int WM, int WN, int MT, int NT>
 inline void launch_one(const ConvParams& p, int batch, hipStream_t s) {
     const int grid = batch * p.m_blks * p.n_tiles;
@@ -783,6 +928,18 @@ inline bool launch_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
             if constexpr (KS == 1) { launch_one<KS, DIL, 4, 1, 2, 2>(p, batch, s); return true; }
             return false;
         case TILE_SPLITK_32x64:
+            if constexpr (splitk_direct_ok<KS, DIL, 2, true> && KS != 7) {
+                if (knobs().splitk_direct && p.x2) {
+                    hipLaunchKernelGGL((conv_mfma_splitk_direct_kernel<KS, DIL, 2, true>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
+                    return true;
+                }
+            }
+            if constexpr (splitk_direct_ok<KS, DIL, 2, false>) {
+                if (knobs().splitk_direct && !p.x2) {
+                    hipLaunchKernelGGL((conv_mfma_splitk_direct_kernel<KS, DIL, 2>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
+                    return true;
+                }
+            }
             if constexpr (KS == 1 || KS == 2 || KS == 4) {
                 if (p.x2) {
                     hipLaunchKernelGGL((conv_mfma_splitk_kernel<KS, DIL, 2, 4, true>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
@@ -792,6 +949,18 @@ inline bool launch_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
             hipLaunchKernelGGL((conv_mfma_splitk_kernel<KS, DIL, 2, 4>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
             return true;
         case TILE_SPLITK_32x32:
+            if constexpr (splitk_direct_ok<KS, DIL, 1, true> && KS != 7) {
+                if (knobs().splitk_direct && p.x2) {
+                    hipLaunchKernelGGL((conv_mfma_splitk_direct_kernel<KS, DIL, 1, true>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
+                    return true;
+                }
+            }
+            if constexpr (splitk_direct_ok<KS, DIL, 1, false>) {
+                if (knobs().splitk_direct && !p.x2) {
+                    hipLaunchKernelGGL((conv_mfma_splitk_direct_kernel<KS, DIL, 1>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);
+                    return true;
+                }
+            }
             if constexpr (KS == 1 || KS == 2 || KS == 4) {
                 if (p.x2) {
                     hipLaunchKernelGGL((conv_mfma_splitk_kernel<KS, DIL, 1, 4, true>), dim3(batch * p.m_blks * p.n_tiles), dim3(256), 0, s, p);

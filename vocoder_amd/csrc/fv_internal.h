@@ -38,6 +38,7 @@ struct Knobs {
     int wino4 = 1;        // FV_WINO4: 1 = the quad-lattice kernels (conv_wino44_impl.h / conv_wino4_impl.h) for k = 7 / 11 where the Winograd path is taken and the layer has whole 64-row blocks, 0 = F(2,3) everywhere
     int lat_wino44 = 1;   // FV_LAT_WINO44: 1 = launches below the Winograd gate at k = 7 / 11 run F(4,4) tap groups (conv_wino_lat44_impl.h), 0 = F(2,3) (conv_wino_lat_impl.h);
                           //   n >= 2: ... only launches of >= n / 2 workgroups per CU in its 16-row tiling (experiments)
+    int splitk_direct = 1;   // FV_SPLITK_DIRECT: 1 = the few-tap split-K launches (conv_pre, the upsamplers of a single clip) load their B operands straight from global memory (conv_mfma_splitk_direct_kernel), 0 = staged through LDS
     int wino_lat = 1;     // FV_WINO_LAT: 0 = launches below the Winograd gate run the direct split-K kernels, 1 = the Winograd latency kernel
     int pair_wino = 1;    // FV_PAIR_WINO: 0 = the fused (c1, c2) pairs run direct sums (resblock_pair.hip), 1 = Winograd tap groups where a kernel exists
 };
@@ -278,6 +279,19 @@ bool launch_amp_conv(const ConvLayer& L, const float* x, float* y, const float* 
                      const float* up_taps, const float* down_taps, int batch, int t, int out_mode, float out_scale, hipStream_t s);
 
 // Tile configurations (block = 4 waves): rows = WM*MT*32, cols = WN*NT*32.
+// conv_mfma_splitk_direct_kernel (conv_mfma_impl.h): registers of one ring slot — 4 KS NT operands (x 3: SUM3) + KS weight float4s — decide the prefetch
+// distance in chunks; 0 = the rings would spill and the launch stays on the LDS-staged split-K kernel.  Few-tap convs only (conv_pre, the polyphase
+// upsamplers): every other single-clip conv is on the Winograd latency kernels.  KS = 4 — the k = 4, stride-2 upsampler at C = 128: four chunks, 2.7
+// workgroups per CU — measured 21.1 us this way against 18.4 staged through LDS: with few chunks and several waves per SIMD the per-operand loads cost more
+// issue than the barriers they replace.
+constexpr int splitk_direct_pf(int ks, int nt, bool sum3) {
+    const int r = 4 * ks * nt * (sum3 ? 3 : 1) + 4 * ks;
+    return r <= 32 ? 3 : r <= 48 ? 2 : r <= 56 ? 1 : 0;
+}
+constexpr bool splitk_direct_shape(int ks, int dil, int nt, bool sum3) {
+    return (ks == 1 || ks == 2 || ks == 7) && dil == 1 && splitk_direct_pf(ks, nt, sum3) > 0;
+}
+
 enum TileCfg : int { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2, TILE_128x64 = 3, TILE_32x128 = 4, TILE_64x128 = 5, TILE_SPLITK_32x64 = 6, TILE_SPLITK_32x32 = 7, TILE_256x64 = 8, TILE_256x32 = 9, TILE_128x96 = 10, TILE_COUNT };
 void tile_dims(int cfg, int* m_blk, int* n_blk);
 // conv_wino_impl.h: Winograd F(2,3) variant of the dilated "same" convs; tiles = output rows x output PAIRS per workgroup
