@@ -201,6 +201,7 @@ class Engine:
     def set_graph_replay(self, enable: bool) -> None:
         """hipGraph replay of repeated identical calls (default on); off = every forward enqueues its kernels eagerly."""
         check(self._lib.fv_set_graph_replay(self._h, int(bool(enable))))
+        self._replay = bool(enable)
 
     def set_conv_algorithm(self, algo: str) -> None:
         """Which fp32 sums the ResBlock / AMPBlock convs form (include/fishvoc.h ``fv_conv_algo``); changes the last bits of the output, not its parity.
@@ -264,9 +265,10 @@ class Engine:
                 self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
             cur = torch.cuda.current_stream(x.device)
             run = cur
-            if cur.cuda_stream == 0 and _SIDE_STREAM_FOR_DEFAULT:
-                # FV_DEFAULT_STREAM_SIDE=1 (A/B runs): the round-4 route for calls on the legacy default stream — an engine-owned side stream,
-                # ordered after / before the caller's.  The library now captures such calls on a stream of its own and replays on stream 0.
+            if cur.cuda_stream == 0 and (_SIDE_STREAM_FOR_DEFAULT or not getattr(self, "_replay", True)):
+                # Calls on the legacy default stream: the library captures them on a stream of its own and replays the graph on stream 0 (round 5).
+                # With replay switched OFF the kernels go to an engine-owned side stream, ordered after / before the caller's: a single clip's ~80 eager
+                # launches on the null stream itself measured 0.95 ms against 0.84 this way.  FV_DEFAULT_STREAM_SIDE=1 forces the side stream (A/B runs).
                 if self._side is None or self._side.device != x.device:
                     self._side = torch.cuda.Stream(x.device)
                 run = self._side
