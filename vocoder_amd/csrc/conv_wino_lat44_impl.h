@@ -36,14 +36,14 @@ struct WL4Geom {
     static constexpr int PS = 8 * PV;                         // V plane [channel][column]
     static constexpr int WAVE_F = X_F + 7 * PS;
     static constexpr int NSLOT = (8 * NP + 63) / 64;          // staged elements per lane and block
-    static constexpr int TCG = (WD + 15) / 16;                // transform: 16-column groups
+    static constexpr int NTR = (8 * WD + 63) / 64;            // transform: slots of 64 lattice elements per block
 #ifndef FV_X_LAT44_RING
 #define FV_X_LAT44_RING 7
 #endif
     static constexpr int NEED = (FV_X_LAT44_RING + MT - 1) / MT;
     static constexpr int MU = (NEED + 1 + NF - 1) / NF;       // blocks per unrolled loop iteration
     static constexpr int RA = MU * NF;                        // ring slots (fragments), prefetch distance RA - 1
-    static_assert(PX >= WR && PV >= WD && 16 * TCG <= PV, "plane strides");
+    static_assert(PX >= WR && PV >= WD, "plane strides");
     static_assert(4 * 4 * 4 * MT * 64 <= 4 * WAVE_F, "the exchange buffer fits the planes");
     static constexpr int a_of(int v) { return v % 7; }
     static constexpr int off_of(int v, int s) { return (v % 7) * PS + 4 * s * PV + (v / 7) * DIL; }
@@ -113,9 +113,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_lat44_kernel(const ConvParam
 
     const int krow = lane >> 4, col = lane & 15;
     const float* bl = V + krow * PV + col;                   // B operand: channel row 4 s + krow, quad column col (+ the tap's offset)
-    // transform slots: lanes 0-15 / 16-31 / ... = channel rows krow (+ 4), 16 consecutive columns: conflict-free with SX, PV == 16 (mod 32)
-    const float* xl = X + krow * SX + col;
-    float* vl = V + krow * PV + col;
+    // transform slots: lattice element e = lane + 64 g of the block's [8 channel rows][WD columns]
+    int txo[G::NTR], tvo[G::NTR];
+#pragma unroll
+    for (int g = 0; g < G::NTR; ++g) {
+        int e = lane + 64 * g;
+        e = e < 8 * G::WD ? e : 8 * G::WD - 1;
+        const int tr = e / G::WD, tc = e - tr * G::WD;
+        txo[g] = tr * SX + tc;
+        tvo[g] = tr * PV + tc;
+    }
 
     if (nsteps > 0) {
         load_block(wave);
@@ -144,24 +151,26 @@ __global__ __launch_bounds__(256, 2) void conv_wino_lat44_kernel(const ConvParam
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    // X -> seven V planes (the previous block's matrix instructions have issued their last LDS read)
+                    // X -> seven V planes (the previous block's matrix instructions have issued their last LDS read).  The block's 8 x WD lattice elements are
+                    // flattened over the lanes: NTR slots of 64 (WD = 17 ... 26: three or four) instead of two 16-column groups per row half whose second
+                    // one holds 1 ... 10 live columns
 #pragma unroll
-                    for (int g = 0; g < 2 * G::TCG; ++g) {
-                        const int cg = g >> 1;
-                        if (16 * (cg + 1) <= G::WD || 16 * cg + col < G::WD) {
-                            const int ro = (4 * (g & 1)) * SX + 16 * cg, wo = (4 * (g & 1)) * PV + 16 * cg;
-                            const float x0 = xl[ro], x1 = xl[ro + PX], x2 = xl[ro + 2 * PX], x3 = xl[ro + 3 * PX];
-                            const float x4 = xl[ro + DIL], x5 = xl[ro + PX + DIL], x6 = xl[ro + 2 * PX + DIL];
+                    for (int g = 0; g < G::NTR; ++g) {
+                        if (64 * (g + 1) <= 8 * G::WD || 64 * g + lane < 8 * G::WD) {
+                            const float* xp = X + txo[g];
+                            float* vp = V + tvo[g];
+                            const float x0 = xp[0], x1 = xp[PX], x2 = xp[2 * PX], x3 = xp[3 * PX];
+                            const float x4 = xp[DIL], x5 = xp[PX + DIL], x6 = xp[2 * PX + DIL];
                             const float eh = fmaf(4.0f, x0, fmaf(-5.0f, x2, x4)), oh = fmaf(4.0f, x1, fmaf(-5.0f, x3, x5));          // a = 1/2
                             const float e1 = fmaf(-4.25f, x2, x4) + x0, o1 = fmaf(-4.25f, x3, x5) + x1;                              // a = 1
                             const float e2 = fmaf(0.25f, x0, fmaf(-1.25f, x2, x4)), o2 = fmaf(0.25f, x1, fmaf(-1.25f, x3, x5));      // a = 2
-                            vl[wo] = fmaf(0.5f, eh, oh);
-                            vl[PS + wo] = fmaf(-0.5f, eh, oh);
-                            vl[2 * PS + wo] = o1 + e1;
-                            vl[3 * PS + wo] = o1 - e1;
-                            vl[4 * PS + wo] = fmaf(2.0f, e2, o2);
-                            vl[5 * PS + wo] = fmaf(-2.0f, e2, o2);
-                            vl[6 * PS + wo] = fmaf(5.25f, x2 - x4, x6 - x0);
+                            vp[0] = fmaf(0.5f, eh, oh);
+                            vp[PS] = fmaf(-0.5f, eh, oh);
+                            vp[2 * PS] = o1 + e1;
+                            vp[3 * PS] = o1 - e1;
+                            vp[4 * PS] = fmaf(2.0f, e2, o2);
+                            vp[5 * PS] = fmaf(-2.0f, e2, o2);
+                            vp[6 * PS] = fmaf(5.25f, x2 - x4, x6 - x0);
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
