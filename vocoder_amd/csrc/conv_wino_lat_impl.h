@@ -27,7 +27,13 @@ struct WLGeom {
     static constexpr int NP = 2 * DIL * NQ;                   // staged positions per channel row
     static constexpr int PW = pw_up(DIL * NQ, 32, 16);        // plane row stride == 16 (mod 32): the 16x16x4 B read (two channel rows per 32 lanes)
     static constexpr int PLANE = 8 * PW;                      // one plane of the wave's 8-channel block: [ch][PW]
-    static constexpr int WAVE_F = 6 * PLANE;                  // planes d0 d1 d2 d3 E O
+    // planes d0 d1 d2 d3 E O; k = 3 with the register transform (K3R): E O only — a third of the LDS, so that more of a single clip's concurrent
+    // workgroups (three branches: ~5 per CU wanted, the k = 7 / 11 kernels hold 53 - 61 KB each) are resident together
+    static constexpr bool K3R = KS == 3 && FV_X_PW_K3_REG != 0;
+    static constexpr int EOP = K3R ? 0 : 4;                   // plane index of E (O follows)
+    static constexpr int WAVE_F = (K3R ? 2 : 6) * PLANE;
+    static constexpr int XCH_F = 4 * 4 * 2 * NT * MT * 64;    // the reduction's exchange buffer
+    static constexpr int LDS_F = 4 * WAVE_F > XCH_F ? 4 * WAVE_F : XCH_F;
     static constexpr int NSLOT = (8 * NP + 63) / 64;          // staged elements per lane and block
     static constexpr int TCG = (WD + 15) / 16;                // transform: 16-column groups
     // weight ring: RA = MU NF fragments (MU = blocks per unrolled loop iteration), prefetch distance RA - 1 fragments of 4 MT NT MFMAs each:
@@ -49,12 +55,12 @@ struct WLGeom {
 };
 
 // The workgroup's work as a device function (tools/experiments/conv_wino_lat3.hip runs the same-depth convs of a stage's three ResBlock
-// branches through it in one launch).  lds: 4 * WLGeom::WAVE_F floats.  wg = workgroup index inside the layer's grid.
+// branches through it in one launch).  lds: WLGeom::LDS_F floats.  wg = workgroup index inside the layer's grid.
 template <int KS, int DIL, int NT, int MT>
 __device__ __forceinline__ void wino_lat_body(const ConvParams& p, float* __restrict__ lds, int wg) {
     using G = WLGeom<KS, DIL, NT, MT>;
     constexpr int NF = G::NF, NSLOT = G::NSLOT, PW = G::PW, PLANE = G::PLANE, MU = G::MU, RA = G::RA;
-    constexpr bool K3R = KS == 3 && FV_X_PW_K3_REG != 0;   // the Winograd input transform in registers
+    constexpr bool K3R = G::K3R;   // the Winograd input transform in registers
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,7 +89,7 @@ __device__ __forceinline__ void wino_lat_body(const ConvParams& p, float* __rest
         const int q = n / DIL;
         const int t = 2 * DIL * q + (n - q * DIL) + half * DIL - p.pad_l;
         voff[i] = (t >= 0 && t < Tin) ? (unsigned)(row * Tin + t) * 4u : 0xFFFFFFFFu;
-        loff[i] = (4 + half) * PLANE + row * PW + cc;
+        loff[i] = (G::EOP + half) * PLANE + row * PW + cc;
     }
     const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(p.x + (long long)b * p.x_bstride, (unsigned)(p.x_bstride * 4));
     float sv[NSLOT];
@@ -158,7 +164,7 @@ __device__ __forceinline__ void wino_lat_body(const ConvParams& p, float* __rest
                         for (int q = 0; q < 2; ++q)
 #pragma unroll
                             for (int jn = 0; jn < NT; ++jn) {
-                                const float* e = bl + 4 * PLANE + (4 * q) * PW + 16 * jn;
+                                const float* e = bl + G::EOP * PLANE + (4 * q) * PW + 16 * jn;
                                 const float E = e[0], E1 = e[DIL], O = e[PLANE], O1 = e[PLANE + DIL];
                                 dk3[q][0][jn] = E - E1;
                                 dk3[q][1][jn] = O + E1;
@@ -297,7 +303,7 @@ __device__ __forceinline__ void wino_lat_body(const ConvParams& p, float* __rest
 
 template <int KS, int DIL, int NT, int MT>
 __global__ __launch_bounds__(256, 2) void conv_wino_lat_kernel(const ConvParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * WLGeom<KS, DIL, NT, MT>::WAVE_F];
+    __shared__ __attribute__((aligned(16))) float lds[WLGeom<KS, DIL, NT, MT>::LDS_F];
     wino_lat_body<KS, DIL, NT, MT>(p, lds, (int)blockIdx.x);
 }
 
