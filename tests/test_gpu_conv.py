@@ -416,19 +416,63 @@ def test_winograd_f44_conv_matches_oracle(rows, monkeypatch):
             res = rng.normal(size=ref.shape).astype(np.float32)
             y = _run(w, b, x, res, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
             want = f"conv_wino44<k={k} d={d} tile={rows if c % 128 == 0 else 64}x32q>"
-            assert _lib.last_kernel() == want, (_lib.last_kernel(), want)
+            assert _lib.last_kernel() in (want, want + " flat"), (_lib.last_kernel(), want)
             _check(y, ref + res)
             y2 = _run(w, None, x, None, dilation=d, padding=pad)
-            assert _lib.last_kernel() == want
+            assert _lib.last_kernel() in (want, want + " flat")
             _check(y2, orc.conv1d(x, w, None, dilation=d, padding=pad))
             if T in (517, 300, 700, 19):
                 y3 = _run(w, b, x, None, dilation=d, padding=pad, pre_act=_lib.FV_ACT_LEAKY_RELU, post_act=_lib.FV_ACT_SILU, act_slope=0.1)
-                assert _lib.last_kernel() == want
+                assert _lib.last_kernel() in (want, want + " flat")
                 _check(y3, orc.silu(orc.conv1d(np.where(x >= 0, x, np.float32(0.1) * x), w, b, dilation=d, padding=pad)))
     finally:
         monkeypatch.delenv("FV_WINO")
         monkeypatch.delenv("FV_WINO44_ROWS")
         _lib.reload_env()
+
+
+FLAT_CASES = [
+    # (C, k, dil, B, T): batches whose clips are not a whole number of 32-column tiles — the flattened column axis needs fewer tiles than per-clip tiling
+    (256, 11, 1, 4, 688), (256, 7, 1, 3, 688), (128, 7, 3, 3, 300), (128, 11, 5, 5, 260), (128, 11, 1, 2, 516), (384, 7, 5, 6, 130), (128, 11, 3, 7, 40),
+    # ... and shapes the flattened instances do not cover (64-row workgroups; rows that are no whole quads at D = 1): per-clip tiles under either setting
+    (64, 11, 5, 5, 260), (192, 7, 5, 6, 130), (128, 11, 1, 2, 517),
+]
+
+
+@pytest.mark.parametrize("c,k,d,B,T", FLAT_CASES)
+def test_winograd_f44_flattened_columns_equal_per_clip_tiles(c, k, d, B, T, monkeypatch):
+    """conv_wino44 over ONE axis of all clips' quad columns (each clip followed by NG D columns of its own halo; conv_layer.hip) against the same kernel
+    tiling every clip on its own (FV_WINO44_FLAT=0): bit for bit — an output's sum does not depend on the tile it sits in — and against the CPU oracle;
+    with and without the residual (the row-split 16-byte epilogue at D = 1, the lean one at D > 1)."""
+    from vocoder_amd import _lib
+    rng = np.random.default_rng(c * 1000 + k * 7 + d + T + B)
+    x = rng.normal(size=(B, c, T)).astype(np.float32)
+    w = (rng.normal(size=(c, c, k)) / np.sqrt(c * k)).astype(np.float32)
+    b = rng.normal(size=c).astype(np.float32)
+    pad = (k - 1) * d // 2
+    ref = orc.conv1d(orc.silu(x), w, b, dilation=d, padding=pad)
+    res = rng.normal(size=ref.shape).astype(np.float32)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FV_WINO", "2")
+        monkeypatch.setenv("FV_WINO44_FLAT", mode)
+        _lib.reload_env()
+        try:
+            y = _run(w, b, x, res, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
+            name = _lib.last_kernel()
+            assert name.startswith("conv_wino44<"), name
+            covered = c % 128 == 0 and (d != 1 or T % 4 == 0)   # (128-row workgroups; D = 1: the row-split epilogue's whole quads)
+            assert name.endswith(" flat") == (mode == "1" and covered), (name, mode)
+            y2 = _run(w, b, x, None, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU, post_act=_lib.FV_ACT_SILU)
+            got[mode] = (y, y2)
+        finally:
+            monkeypatch.delenv("FV_WINO")
+            monkeypatch.delenv("FV_WINO44_FLAT")
+            _lib.reload_env()
+    _check(got["1"][0], ref + res)
+    _check(got["1"][1], orc.silu(ref))
+    assert np.array_equal(got["1"][0], got["0"][0])
+    assert np.array_equal(got["1"][1], got["0"][1])
 
 
 LAT_CASES = [

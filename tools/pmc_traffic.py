@@ -95,7 +95,7 @@ def bench_key(label: str):
     m = re.search(r"pair_wino<k=(\d+) d=(\d+) C=(\d+)> grid=(\d+)", label)
     if m:   # (the launch's grid is rounded up to a multiple of the 8 XCDs: key_of sees the rounded count)
         return f"pair_wino k={m.group(1)} d={m.group(2)} C={m.group(3)} grid={(int(m.group(4)) + 7) // 8 * 8}"
-    m = re.search(r"conv_wino44<k=(\d+) d=(\d+) tile=(\w+)> cin=(\d+) cout=(\d+) grid=(\d+)", label)
+    m = re.search(r"conv_wino44<k=(\d+) d=(\d+) tile=(\w+)> cin=(\d+) cout=(\d+)(?: flat)? grid=(\d+)", label)
     if m:
         c64 = " c64" if (m.group(4), m.group(5)) == ("64", "64") else ""
         return f"conv_wino44 k={m.group(1)} d={m.group(2)} tile={m.group(3)}{c64} grid={(int(m.group(6)) + 7) // 8 * 8}"

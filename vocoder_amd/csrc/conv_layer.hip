@@ -739,8 +739,37 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
                     p.wp = L.d_wpw44;
                     p.m_blks = L.M / rows44;
                     p.n_tiles = (int)((nq + 31) / 32);
-                    launched = L.ks == 7 ? launch_conv_wino44_k7(p, rows44, r.batch, stream) : launch_conv_wino44_k11(p, rows44, r.batch, stream);
+                    // Flattened column axis (round 5): a clip whose quad columns are not a whole number of 32-column tiles pads every clip's last tile (T = 688:
+                    // 172 columns = 5.4 tiles, 10 % of the launch's products on padding).  The tiles may instead run over ONE axis of all clips' columns, each clip's
+                    // nq columns followed by NG D columns of its own halo (the last outputs' tap groups reach n + NG D: with that gap no window ever holds another
+                    // clip's columns; the gap columns' outputs lie past T and are not stored).  Every output is the same sum in the same order — tile membership
+                    // does not enter it: bit-identical, batch-invariant.  Taken when it needs fewer tiles, for the lean operand set, whole chunks, and tensors whose
+                    // clips all sit inside one 4 GiB descriptor.
+                    int launch_batch44 = r.batch;
+                    // (instances exist for 128-row workgroups with the activation known at compile time: D = 1 with the row-split epilogue, D = 3 / 5 behind a SiLU —
+                    //  what the headline's C = 256 stage launches; the launcher declines anything else and the per-clip tiling below takes over)
+                    const int n_tiles_clip = p.n_tiles;
+                    if (knobs().wino44_flat && r.batch > 1 && rows44 == 128 && !r.gamma && r.out_mode == OUT_SET && p.acc_scale == 1.0f && L.c_in % 32 == 0 &&
+                        (r.pre_act == FV_ACT_SILU || (r.pre_act == FV_ACT_NONE && L.dil == 1))) {
+                        const long long gap = (long long)((L.ks + 3) / 4) * L.dil, S = nq + gap;
+                        const long long tiles_flat = (r.batch * S - gap + 31) / 32;
+                        const long long span_x = (long long)r.batch * p.x_bstride * 4, span_y = (long long)r.batch * p.y_bstride * 4;
+                        if (tiles_flat < (long long)r.batch * p.n_tiles && span_x < (1LL << 32) && span_y < (1LL << 32)) {
+                            p.col_S = (int)S;
+                            p.col_batch = r.batch;
+                            p.n_tiles = (int)tiles_flat;
+                            launch_batch44 = 1;
+                        }
+                    }
+                    launched = L.ks == 7 ? launch_conv_wino44_k7(p, rows44, launch_batch44, stream) : launch_conv_wino44_k11(p, rows44, launch_batch44, stream);
+                    if (!launched && p.col_S) {   // (no flattened instance for this operand set — unaligned rows at D = 1: the row-split epilogue does not apply)
+                        p.col_S = p.col_batch = 0;
+                        p.n_tiles = n_tiles_clip;
+                        launch_batch44 = r.batch;
+                        launched = L.ks == 7 ? launch_conv_wino44_k7(p, rows44, launch_batch44, stream) : launch_conv_wino44_k11(p, rows44, launch_batch44, stream);
+                    }
                     std::snprintf(name, sizeof(name), "conv_wino44<k=%d d=%d tile=%dx32q>", L.ks, L.dil, rows44);
+                    if (launched) return finish_conv_launch(L, r, tout, stream, prof_idx, name, (long long)launch_batch44 * p.m_blks * p.n_tiles, p.col_S ? " flat" : "");
                 } else if (form == 43) {   // (k = 7 / 11 only — k = 3: 6 products per quad against 8, and F(2,3) measured faster: LOG R4.14)
                     p.wp = L.d_wpw4;
                     p.m_blks = L.M / 64;

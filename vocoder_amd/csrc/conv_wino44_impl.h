@@ -69,7 +69,7 @@ struct Wino44Geom {
 // (leaky-ReLU: RefineGAN).  With the switch gone the staging is one basic block, and the compiler's vmcnt bookkeeping across it stays exact (round 5).
 // QR (D = 1 only): the row-split epilogue with 16-byte stores; the host launches it when the layer qualifies (wino44_quad_rows) — an instance of its own: with
 // both lean epilogues in one kernel the register allocator spills 40 - 70 values.
-template <int KS, int DIL, int VAR, int MT, int PRE, bool QR = false>
+template <int KS, int DIL, int VAR, int MT, int PRE, bool QR = false, bool FLAT = false>
 __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_wino44_kernel(const ConvParams p) {
     static_assert(!QR || DIL == 1, "the row-split epilogue needs contiguous quads");
     using G = Wino44Geom<KS, DIL>;
@@ -109,14 +109,24 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
         int e = lane + 64 * i;
         e = e < RPW * WR ? e : RPW * WR - 1;
         const int rr = e / WR, c = e - rr * WR;
-        const int n = n0 + c;
+        int n = n0 + c;
+        // flattened column axis (p.col_S > 0, b == 0): virtual column -> (clip, quad column); a clip's columns are followed by NG D columns of its own halo —
+        // its last outputs' tap groups read those, never the next clip's first columns — see conv_layer.hip
+        int xbo = 0;
+        bool bok = true;
+        if constexpr (FLAT) {
+            const int bb = n / p.col_S;
+            n -= bb * p.col_S;
+            xbo = bb * (int)p.x_bstride;
+            bok = bb < p.col_batch;
+        }
         const int q = n / DIL;
         const int t0 = 4 * DIL * q + (n - q * DIL) - p.pad_l;
         const int row = wave * RPW + rr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int t = t0 + j * DIL;
-            vo[i][j] = (t >= 0 && t < p.Tin) ? (unsigned)(row * p.Tin + t) * 4u : 0xFFFFFFFFu;
+            vo[i][j] = (bok && t >= 0 && t < p.Tin) ? (unsigned)(xbo + row * p.Tin + t) * 4u : 0xFFFFFFFFu;
         }
         lo[i] = row * ROW + c;
     }
@@ -132,7 +142,9 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
         const int cbase = c * CH;
         const long long span = p.x_bstride - (long long)cbase * p.Tin;
         const long long rows = (long long)(p.Cin - cbase) * p.Tin;
-        const long long lim = rows < span ? rows : span;
+        // (flattened columns: the descriptor spans the clips a tile may touch — whole chunks only, host-checked: a part-filled last chunk would read the
+        //  next clip's rows where the per-clip form reads zeros)
+        const long long lim = FLAT ? (rows > 0 ? (long long)p.col_batch * p.x_bstride - (long long)cbase * p.Tin : 0) : (rows < span ? rows : span);
         const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(xb + (long long)(lim > 0 ? cbase : 0) * p.Tin, lim > 0 ? (unsigned)(lim * 4) : 0u);
 #pragma unroll
         for (int i = 0; i < NE; ++i)
@@ -296,7 +308,15 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
     //       keeps  y0: s + m1,  y1: d/2 + m1        sends  y2: s/4 + m1,  y3: d/8 + m1 + m(∞)
     //   half 1 (m(-1) m(2) m(-2), its part of m(∞)):      s = m(2) + m(-2),     d = m(2) - m(-2)
     //       sends  y0: s + m(-1),  y1: 2 d - m(-1)  keeps  y2: 4 s + m(-1),  y3: 8 d - m(-1) + m(∞) ----
-    const int n = n0 + (lane & 31);
+    int n = n0 + (lane & 31);
+    int ybo = 0;                    // flattened columns: the clip's offset in y / the residual (elements); a column past the last clip gets a position past every row's end
+    if constexpr (FLAT) {
+        const int bb = n / p.col_S;
+        n -= bb * p.col_S;
+        ybo = bb * (int)p.y_bstride;
+        if (bb >= p.col_batch) n = 1 << 26;
+    }
+    const unsigned yspan = (unsigned)((FLAT ? (long long)p.col_batch * p.y_bstride : p.y_bstride) * 4);
     const int q = n / DIL;
     const int ta = 4 * DIL * q + (n - q * DIL) + 2 * h * DIL, tb = ta + DIL;   // half 0: t0, t0 + D; half 1: t0 + 2D, t0 + 3D
     const float* pa = xs + (wave ^ 1) * 2048 + lane;          // partner's partial sum of this half's first output
@@ -310,13 +330,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
     // Same sums in the same order as the split by outputs: y_j = (this half's partial) + (the partner's), fp32 addition commutes.
     if constexpr (QR) {
         {
-            const unsigned span = (unsigned)(p.y_bstride * 4);
+            const unsigned span = yspan;
             const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
             const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
             const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(p.bias, (unsigned)(p.M * 4));
             const int mrow = 4 * (lane >> 5);
             const int t4 = 4 * n;                                    // first of the quad's four samples
-            const unsigned vq = t4 < p.N ? (unsigned)(mrow * p.N + t4) * 4u : 0xFFFFFFFFu;
+            const unsigned vq = t4 < p.N ? (unsigned)(ybo + mrow * p.N + t4) * 4u : 0xFFFFFFFFu;
             const bool has_res = p.res != nullptr;
             const float* pq = xs + (wave ^ 1) * 2048 + lane;        // partner's partials of the rows this half keeps: [kept register][output] x 64 lanes
 #pragma unroll
@@ -433,13 +453,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
         __syncthreads();
         if (lean) {
             // all bias and residual operands are requested before the partner's planes are read back
-            const unsigned span = (unsigned)(p.y_bstride * 4);
+            const unsigned span = yspan;
             const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
             const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
             const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(p.bias, (unsigned)(p.M * 4));
             const int mrow = 4 * (lane >> 5);                                   // lane part of the row; + mt * 32 + (r & 3) + 8 * (r >> 2) in SGPRs
-            const unsigned va = ta < p.N ? (unsigned)(mrow * p.N + ta) * 4u : 0xFFFFFFFFu;
-            const unsigned vb = tb < p.N ? (unsigned)(mrow * p.N + tb) * 4u : 0xFFFFFFFFu;
+            const unsigned va = ta < p.N ? (unsigned)(ybo + mrow * p.N + ta) * 4u : 0xFFFFFFFFu;
+            const unsigned vb = tb < p.N ? (unsigned)(ybo + mrow * p.N + tb) * 4u : 0xFFFFFFFFu;
             float bias[16], ra[16], rb[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -520,6 +540,26 @@ inline bool launch_wino44_kc(const ConvParams& p0, int batch, hipStream_t s) {
     ConvParams p = p0;
     p.wg_total = batch * p.m_blks * p.n_tiles;
     const int grid = (p.wg_total + 7) / 8 * 8;
+    // flattened column axis (p.col_S > 0; conv_layer.hip offers it to wino44_flat_instance() shapes only): instances of their own — the per-clip kernels are
+    // at their register limits, two more live values spilled 54 - 184 registers in several of them
+    if constexpr (MT == 2 && VAR == 0 && PRE != 2) {
+        if (p.col_S > 0) {
+            switch (p.dil) {
+                case 1:
+                    if (!wino44_quad_rows(p)) return false;
+                    hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, VAR, MT, PRE, true, true>), dim3(grid), dim3(256), 0, s, p);
+                    return true;
+                case 3:
+                    if constexpr (PRE == 1) { hipLaunchKernelGGL((conv_wino44_kernel<KS, 3, VAR, MT, PRE, false, true>), dim3(grid), dim3(256), 0, s, p); return true; }
+                    return false;
+                case 5:
+                    if constexpr (PRE == 1) { hipLaunchKernelGGL((conv_wino44_kernel<KS, 5, VAR, MT, PRE, false, true>), dim3(grid), dim3(256), 0, s, p); return true; }
+                    return false;
+                default: return false;
+            }
+        }
+    }
+    if (p.col_S > 0) return false;
     switch (p.dil) {
         case 1:
             if (wino44_quad_rows(p)) hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, VAR, MT, PRE, true>), dim3(grid), dim3(256), 0, s, p);

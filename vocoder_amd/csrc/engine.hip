@@ -80,6 +80,7 @@ static const Knobs* load_knobs() {
     if (const char* v = std::getenv("FV_WINO_LAT")) k->wino_lat = std::atoi(v);
     if (const char* v = std::getenv("FV_LAT_WINO44")) k->lat_wino44 = std::atoi(v);
     if (const char* v = std::getenv("FV_SPLITK_DIRECT")) k->splitk_direct = std::atoi(v);
+    if (const char* v = std::getenv("FV_WINO44_FLAT")) k->wino44_flat = std::atoi(v);
     if (const char* v = std::getenv("FV_VEC_STORE")) k->vec_store = std::atoi(v);
     if (const char* v = std::getenv("FV_PAIR_WINO44")) k->pair_wino44 = std::atoi(v);
     return k;

@@ -39,6 +39,7 @@ struct Knobs {
     int lat_wino44 = 1;   // FV_LAT_WINO44: 1 = launches below the Winograd gate at k = 7 / 11 run F(4,4) tap groups (conv_wino_lat44_impl.h), 0 = F(2,3) (conv_wino_lat_impl.h);
                           //   n >= 2: ... only launches of >= n / 2 workgroups per CU in its 16-row tiling (experiments)
     int splitk_direct = 1;   // FV_SPLITK_DIRECT: 1 = the few-tap split-K launches (conv_pre, the upsamplers of a single clip) load their B operands straight from global memory (conv_mfma_splitk_direct_kernel), 0 = staged through LDS
+    int wino44_flat = 1;  // FV_WINO44_FLAT: 1 = conv_wino44 tiles a flattened (clip, quad column) axis where that needs fewer 32-column tiles than tiling every clip on its own (T = 688: 5.4 tiles per clip), 0 = per clip
     int wino_lat = 1;     // FV_WINO_LAT: 0 = launches below the Winograd gate run the direct split-K kernels, 1 = the Winograd latency kernel
     int pair_wino = 1;    // FV_PAIR_WINO: 0 = the fused (c1, c2) pairs run direct sums (resblock_pair.hip), 1 = Winograd tap groups where a kernel exists
 };
@@ -144,6 +145,7 @@ struct ConvParams {
     int xcd_rows;        // gemm_pw.hip: row groups the 8 XCDs split the m-tiles into (1, 2, 4 or 8)
     int wg_total;        // conv_wino_impl.h: workgroups of the launch (the grid is rounded up to a multiple of the 8 XCDs)
     int vec_store;       // conv_epilogue: stride-8 polyphase transposed conv whose output quads can go out as 16-byte stores
+    int col_S, col_batch;   // conv_wino44_impl.h: > 0 = the launch's quad columns run over a flattened (clip, column) axis with col_S columns per clip, col_batch clips (grid batch 1)
 #if defined(FV_X_SPLITK_TS) || defined(FV_X_CONV_TS)
     long long* dbg_ts;   // experiment: per-workgroup phase time stamps (split-K kernel / tiled conv kernel)
 #endif
