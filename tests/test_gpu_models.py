@@ -1307,3 +1307,13 @@ def test_batch_invariant_mode_refuses_the_launch_dependent_pointwise_fallback():
     torch.cuda.synchronize()
     assert bool(torch.isfinite(y).all())
     assert float((y[:8] - y_small).abs().max()) <= 2e-5 and float((y[-1] - y_small[0]).abs().max()) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_graft_entry_build_then_smoke_in_one_process():
+    """`__graft_entry__.build()` followed by `smoke()` in ONE interpreter — the order in which the library and torch come into the process must not matter
+    (round 5: with the library opened first, its HIP runtime was a second copy next to torch's and found no device)."""
+    import subprocess, sys, os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], capture_output=True, text=True, cwd=repo, timeout=900)
+    assert r.returncode == 0 and "smoke OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -25,6 +25,17 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.fv_abi_version() == _lib.FV_ABI_VERSION
 
 
+def test_loading_the_library_brings_torch_in_first():
+    """One HIP runtime per process: torch's wheel carries its own libamdhip64, and libfishvoc_hip.so must bind to that copy — `_lib.lib()` imports torch
+    before it opens the library (loaded the other way round, the system runtime arrives as a second one and its first hipMalloc finds no device once torch
+    has initialised it: `build()` followed by `smoke()` in one process).  Checked in a fresh interpreter."""
+    import subprocess
+    code = ("import sys; from vocoder_amd import _lib; assert 'torch' not in sys.modules; _lib.lib(); assert 'torch' in sys.modules; "
+            "m = open('/proc/self/maps').read(); n = len({l.split()[-1] for l in m.splitlines() if 'libamdhip64' in l}); assert n == 1, n; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_config_struct_layout_matches_header():
     # int32 fields only, so sizeof is a good canary for drift between fishvoc.h and the ctypes mirror
     assert ctypes.sizeof(_lib.UpsamplerConfig) == 4 * (2 + 8 + 8 + 1 + 8 + 24 + 5 + 2)

@@ -104,6 +104,10 @@ def lib() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C vocoder_amd/csrc`). "
             "vocoder_amd has no CPU fallback.")
+    # torch first: its wheel carries its own HIP runtime (torch/lib/libamdhip64.so), and the process must end up with ONE — loaded after torch, this
+    # library's libamdhip64.so.7 dependency resolves to the copy torch already mapped; loaded before it, the system runtime comes in as a second one and
+    # its first hipMalloc fails with "no ROCm-capable device is detected" once torch has initialised the device (build() followed by smoke() in one process)
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, cp = ctypes.c_void_p, ctypes.c_char_p
     fp = ctypes.POINTER(ctypes.c_float)
