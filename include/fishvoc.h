@@ -196,7 +196,7 @@ FV_API fv_status fv_set_precision(fv_engine* e, int32_t precision);
  *   FV_CONV_ALGO_AUTO      per launch, whatever is fastest.  The dilated k = 3 / 7 / 11 ResBlock / AMPBlock convs: launches that fill the chip (>= one
  *                          workgroup per CU: depends on batch size, clip length and the device's CU count) run the throughput Winograd kernels — F(4,4) tap
  *                          groups on the quad lattice for k = 7 / 11 on layers of whole 64-row tiles, F(2,3) on the pair lattice otherwise; launches below
- *                          that gate (single clips, small batches) run the Winograd LATENCY kernel (F(2,3), K split over the waves), direct split-K sums
+ *                          that gate (single clips, small batches) run the Winograd LATENCY kernels (F(4,4) for k = 7 / 11, F(2,3) for k = 3; K split over the waves), direct split-K sums
  *                          where it has no instance; the fused (c1, c2) pairs of the narrow stages use Winograd whenever a kernel exists.  Default.
  *   FV_CONV_ALGO_DIRECT    direct sums everywhere.
  *   FV_CONV_ALGO_WINOGRAD  the throughput Winograd kernels wherever one exists, whatever the launch size (never the latency kernel: single clips are

@@ -206,9 +206,9 @@ class Engine:
     def set_conv_algorithm(self, algo: str) -> None:
         """Which fp32 sums the ResBlock / AMPBlock convs form (include/fishvoc.h ``fv_conv_algo``); changes the last bits of the output, not its parity.
         "auto": per launch, fastest — the throughput Winograd kernels (F(4,4) quad lattice for k = 7 / 11 on whole 64-row tiles, F(2,3) pair lattice
-        otherwise) for launches of >= one workgroup per CU, the Winograd LATENCY kernel (F(2,3), K split over the waves) below that gate, Winograd pairs on
+        otherwise) for launches of >= one workgroup per CU, the Winograd LATENCY kernels (F(4,4) for k = 7 / 11, F(2,3) for k = 3; K split over the waves) below that gate, Winograd pairs on
         the narrow stages; "direct": direct sums everywhere; "winograd": the throughput Winograd kernels whatever the launch size — it bypasses the
-        latency kernel, so single clips run slower than under "auto"."""
+        latency kernels, so single clips run slower than under "auto"."""
         check(self._lib.fv_set_conv_algorithm(self._h, _lib.CONV_ALGOS[algo]))
 
     def set_batch_invariant(self, enable: bool) -> None:
