@@ -434,6 +434,7 @@ def test_winograd_f44_conv_matches_oracle(rows, monkeypatch):
 FLAT_CASES = [
     # (C, k, dil, B, T): batches whose clips are not a whole number of 32-column tiles — the flattened column axis needs fewer tiles than per-clip tiling
     (256, 11, 1, 4, 688), (256, 7, 1, 3, 688), (128, 7, 3, 3, 300), (128, 11, 5, 5, 260), (128, 11, 1, 2, 516), (384, 7, 5, 6, 130), (128, 11, 3, 7, 40),
+    (128, 11, 1, 4, 4), (256, 7, 3, 5, 8), (128, 7, 5, 3, 1), (128, 11, 5, 9, 23),   # clips shorter than a tile, than one 4 D block, one sample
     # ... and shapes the flattened instances do not cover (64-row workgroups; rows that are no whole quads at D = 1): per-clip tiles under either setting
     (64, 11, 5, 5, 260), (192, 7, 5, 6, 130), (128, 11, 1, 2, 517),
 ]
