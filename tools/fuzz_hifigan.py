@@ -28,18 +28,20 @@ def random_case(rng, large=False):
 
 
 def run(n_cases=30, seed=0, verbose=True, large=False, model="hifigan"):
-    """model: "hifigan" (a third of the cases with the use_template=True branch) or "bigvgan"."""
+    """model: "hifigan" or "bigvgan"; a third of the cases of either take the use_template=True branch."""
     rng = np.random.default_rng(seed)
     worst = 0.0
     for i in range(n_cases):
         cfg, B, T = random_case(rng, large)
         tmpl = None
+        cfg["use_template"] = bool(rng.random() < 0.34)
         if model == "bigvgan":
             sd = syn.bigvgan_state_dict(cfg, seed * 1000 + i)
             mel = syn.synthetic_mel(B, cfg["num_mels"], T, seed + i)
-            ref = orc.bigvgan_forward(sd, cfg, mel)
+            if cfg["use_template"]:
+                tmpl = syn.synthetic_template(B, T, cfg["hop_length"], seed + i + 5)
+            ref = orc.bigvgan_forward(sd, cfg, mel, template=tmpl)
         else:
-            cfg["use_template"] = bool(rng.random() < 0.34)
             sd = syn.hifigan_state_dict(cfg, seed * 1000 + i)
             mel = syn.synthetic_mel(B, cfg["num_mels"], T, seed + i)
             if cfg["use_template"]:

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # FV_LIB_PATH points the loader at an experimental build (A/B kernel variants); default = the in-tree library
 LIB_PATH = os.environ.get("FV_LIB_PATH") or os.path.join(CSRC, "libfishvoc_hip.so")
 
-FV_ABI_VERSION = 4
+FV_ABI_VERSION = 5
 FV_MAX_STAGES = 8
 FV_MAX_KERNELS = 8
 FV_MAX_DILATIONS = 3
@@ -28,6 +28,7 @@ FV_CONV_ALGO_AUTO, FV_CONV_ALGO_DIRECT, FV_CONV_ALGO_WINOGRAD = 0, 1, 2
 CONV_ALGOS = {"auto": FV_CONV_ALGO_AUTO, "direct": FV_CONV_ALGO_DIRECT, "winograd": FV_CONV_ALGO_WINOGRAD}
 FV_ISTFT_SAME, FV_ISTFT_CENTER = 0, 1
 FV_ACT_NONE, FV_ACT_SILU, FV_ACT_LEAKY_RELU, FV_ACT_GELU, FV_ACT_TANH, FV_ACT_LOG_CLAMP = 0, 1, 2, 3, 4, 5
+FV_POST_ACT_DEFAULT, FV_POST_ACT_IDENTITY = 0, -1   # fv_upsampler_config.post_activation (ABI 5): 0 = reference default SiLU, -1 = nn.Identity
 
 EXPORTS = (
     "fv_create", "fv_load_weight", "fv_finalize", "fv_destroy", "fv_output_length", "fv_output_channels",
@@ -35,7 +36,7 @@ EXPORTS = (
     "fv_conv_forward", "fv_conv_destroy", "fv_last_error", "fv_abi_version", "fv_last_kernel",
     "fv_profile_begin", "fv_profile_end", "fv_conv_pair_forward", "fv_forward_template",
     "fv_set_precision", "fv_conv_set_precision", "fv_refinegan_noise_elems", "fv_forward_refinegan",
-    "fv_set_graph_replay", "fv_reload_env", "fv_set_conv_algorithm", "fv_set_batch_invariant", "fv_conv_set_algorithm",
+    "fv_set_graph_replay", "fv_get_graph_replay", "fv_reload_env", "fv_set_conv_algorithm", "fv_set_batch_invariant", "fv_conv_set_algorithm",
 )
 
 _i32 = ctypes.c_int32
@@ -151,6 +152,8 @@ def lib() -> ctypes.CDLL:
     L.fv_reload_env.restype = None
     L.fv_set_graph_replay.argtypes = [vp, _i32]
     L.fv_set_graph_replay.restype = _i32
+    L.fv_get_graph_replay.argtypes = [vp]
+    L.fv_get_graph_replay.restype = _i32
     L.fv_set_conv_algorithm.argtypes = [vp, _i32]
     L.fv_set_conv_algorithm.restype = _i32
     L.fv_set_batch_invariant.argtypes = [vp, _i32]

@@ -331,9 +331,20 @@ struct IstftHeadModel {
     // torch.istft(center=True) raises "window overlap add min" when the overlap-added window^2 is below 1e-11 anywhere in the samples
     // it keeps (vocos 0.0.2 ISTFT.forward falls back to it for padding="center").  The envelope's edge regions repeat for every T
     // beyond a few window lengths, so a short frame count decides it.
+    // The answer depends only on min(T, Tc_max) and the fixed window: cached per value (it ran on every call, replayed ones too).
+    mutable std::vector<signed char> env_ok_cache;   // by Tc: 0 unknown, 1 ok, -1 not ok (a forward holds the engine: no concurrent writers)
     bool center_envelope_ok(int T) const {
         const int N = cfg.n_fft, hop = cfg.hop_length;
-        const int Tc = std::min(T, 2 * ((N + hop - 1) / hop) + 2);
+        const int Tc_max = 2 * ((N + hop - 1) / hop) + 2;
+        const int Tc = std::min(T, Tc_max);
+        if (env_ok_cache.empty()) env_ok_cache.assign((size_t)Tc_max + 1, 0);
+        if (Tc >= 0 && env_ok_cache[(size_t)Tc]) return env_ok_cache[(size_t)Tc] > 0;
+        const bool ok = center_envelope_compute(Tc);
+        if (Tc >= 0) env_ok_cache[(size_t)Tc] = ok ? 1 : -1;
+        return ok;
+    }
+    bool center_envelope_compute(int Tc) const {
+        const int N = cfg.n_fft, hop = cfg.hop_length;
         const int64_t L = (int64_t)(Tc - 1) * hop;
         for (int64_t q = 0; q < L; ++q) {
             const int64_t pos = q + N / 2;   // position in the un-trimmed overlap-add
@@ -1325,8 +1336,8 @@ static fv_status validate_ups(const fv_upsampler_config& c) {
         set_error("invalid num_mels / upsample_initial_channel / pre,post kernel sizes (must be odd)");
         return FV_ERR_INVALID;
     }
-    if (c.post_activation != FV_ACT_NONE && c.post_activation != FV_ACT_SILU && c.post_activation != FV_ACT_LEAKY_RELU &&
-        c.post_activation != FV_ACT_GELU && c.post_activation != FV_ACT_TANH) {
+    if (c.post_activation != FV_POST_ACT_DEFAULT && c.post_activation != FV_POST_ACT_IDENTITY && c.post_activation != FV_ACT_SILU &&
+        c.post_activation != FV_ACT_LEAKY_RELU && c.post_activation != FV_ACT_GELU && c.post_activation != FV_ACT_TANH) {
         set_error("post_activation %d: only nn.Identity / nn.SiLU / nn.LeakyReLU / nn.ReLU / nn.GELU / nn.Tanh have a kernel form", c.post_activation);
         return FV_ERR_UNSUPPORTED;
     }
@@ -1430,6 +1441,9 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
         return FV_ERR_INVALID;
     }
     e->cfg = *cfg;
+    // ABI 5: 0 (a zero-initialised struct) is the reference default SiLU, -1 nn.Identity; inside the engine the field is a plain fv_act
+    if (e->cfg.ups.post_activation == FV_POST_ACT_DEFAULT) e->cfg.ups.post_activation = FV_ACT_SILU;
+    else if (e->cfg.ups.post_activation == FV_POST_ACT_IDENTITY) e->cfg.ups.post_activation = FV_ACT_NONE;
     if (const char* v = std::getenv("FV_NO_PAIR_FUSION")) e->fuse_pairs = !(v[0] == '1');
     if (const char* v = std::getenv("FV_PAIR_MAXC")) e->pair_max_c = std::atoi(v);
     if (const char* v = std::getenv("FV_CHAIN_MAX_C")) e->chain_max_c = std::atoi(v);
@@ -1524,6 +1538,8 @@ FV_API fv_status fv_set_graph_replay(fv_engine* e, int32_t enable) {
     e->use_graph = enable != 0;
     return FV_OK;
 }
+
+FV_API int32_t fv_get_graph_replay(const fv_engine* e) { return e && e->use_graph ? 1 : 0; }
 
 FV_API fv_status fv_finalize(fv_engine* e) {
     if (!e) {
@@ -1701,6 +1717,14 @@ static fv_status forward_common(fv_engine* e, const float* d_in, const float* d_
     if (batch < 1 || t_in < 1) {
         set_error("fv_forward: empty input (batch=%d, t_in=%d)", batch, t_in);
         return FV_ERR_INVALID;
+    }
+    {
+        const fv_engine::TilePlan tp = e->tile_plan(t_in);
+        if (tp.n > 1 && (long long)batch * tp.n > (1 << 24)) {
+            set_error("fv_forward: %d clips x %d time tiles of %d frames exceed 2^24 tiles per call: split the batch (or raise FV_TILE_FRAMES)", batch,
+                      tp.n, tp.L);
+            return FV_ERR_UNSUPPORTED;
+        }
     }
     const size_t need = fv_workspace_bytes(e, batch, t_in);
     if (e->cfg.model == FV_MODEL_REFINEGAN && need == 0) {
@@ -2092,6 +2116,14 @@ fv_engine::TilePlan fv_engine::tile_plan(int t_in) const {
     if (tile_frames_override > 0) limit = std::min(limit, std::max(tile_frames_override, 4 * reach));
     if (limit <= 0 || t_in <= limit) return p;
     if (limit < 4 * reach) return p;   // (a model whose reach does not fit the span: the per-layer check reports it)
+    // The gather / scatter address tiles and clips at exactly frames x hop samples.  A transposed conv with odd (kernel - rate) yields
+    // T u + 1 samples per stage (ConvLayer::out_len), so the model's rows would be longer than that: such a generator is not tiled
+    //  — the clip runs whole, and past the addressing span the per-layer check refuses it by name.
+    {
+        const int64_t lout = fv_output_length(this, limit), clip_out = fv_output_length(this, t_in);
+        const int64_t hop = limit > 0 ? lout / limit : 0;
+        if (hop < 1 || lout != hop * limit || clip_out != hop * (int64_t)t_in) return p;
+    }
     p.halo = reach;
     p.L = limit;
     p.stride = p.L - 2 * p.halo;

@@ -1228,25 +1228,30 @@ fv_status launch_adain(const float* x, const float* noise, const float* w, float
 //   gather : tiles[(b * n + i)][c][l] = x[b][c][a_i * hop + l]
 //   scatter: y[b][c][lo_i * hop ...) = tiles[(b * n + i)][c][(lo_i - a_i) * hop ...), the frames [lo_i, hi_i) tile i contributes
 // ---------------------------------------------------------------------------------------------
+static constexpr long long kMaxGridZ = 65535;
 __global__ __launch_bounds__(256) void gather_tiles_kernel(const float* __restrict__ x, float* __restrict__ tiles, int C, long long T,
-                                                           int n, long long L, int stride, int hop, long long Tf) {
+                                                           int n, long long L, int stride, int hop, long long Tf, int bi0) {
     const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
     if (l >= L) return;
-    const int c = blockIdx.y, bi = blockIdx.z, b = bi / n, i = bi % n;
+    const int c = blockIdx.y, bi = bi0 + blockIdx.z, b = bi / n, i = bi % n;
     long long a = (long long)i * stride;
     if (a > Tf - L / hop) a = Tf - L / hop;
     tiles[((long long)bi * C + c) * L + l] = x[((long long)b * C + c) * T + a * hop + l];
 }
 fv_status launch_gather_tiles(const float* x, float* tiles, int B, int C, int T, int n, int L, int stride, int hop, hipStream_t s) {
     const long long Ls = (long long)L * hop;
-    hipLaunchKernelGGL(gather_tiles_kernel, dim3((unsigned)((Ls + 255) / 256), C, B * n), dim3(256), 0, s, x, tiles, C, (long long)T * hop, n,
-                       Ls, stride, hop, (long long)T);
-    FV_HIP_CHECK(hipGetLastError());
+    // gridDim.z is limited to 65 535: (clip, tile) items in chunks of that (a long clip with a short tile and a moderate batch)
+    for (long long bi0 = 0; bi0 < (long long)B * n; bi0 += kMaxGridZ) {
+        const unsigned nz = (unsigned)std::min<long long>(kMaxGridZ, (long long)B * n - bi0);
+        hipLaunchKernelGGL(gather_tiles_kernel, dim3((unsigned)((Ls + 255) / 256), C, nz), dim3(256), 0, s, x, tiles, C, (long long)T * hop, n,
+                           Ls, stride, hop, (long long)T, (int)bi0);
+        FV_HIP_CHECK(hipGetLastError());
+    }
     return FV_OK;
 }
 __global__ __launch_bounds__(256) void scatter_tiles_kernel(const float* __restrict__ tiles, float* __restrict__ y, int C, long long T,
-                                                            int n, long long L, int stride, int halo, int hop, long long Tf) {
-    const int c = blockIdx.y, bi = blockIdx.z, b = bi / n, i = bi % n;
+                                                            int n, long long L, int stride, int halo, int hop, long long Tf, int bi0) {
+    const int c = blockIdx.y, bi = bi0 + blockIdx.z, b = bi / n, i = bi % n;
     const long long Lf = L / hop;
     long long a = (long long)i * stride;
     if (a > Tf - Lf) a = Tf - Lf;
@@ -1258,9 +1263,12 @@ __global__ __launch_bounds__(256) void scatter_tiles_kernel(const float* __restr
 }
 fv_status launch_scatter_tiles(const float* tiles, float* y, int B, int C, int T, int n, int L, int stride, int halo, int hop, hipStream_t s) {
     const long long Ls = (long long)L * hop;
-    hipLaunchKernelGGL(scatter_tiles_kernel, dim3((unsigned)((Ls + 255) / 256), C, B * n), dim3(256), 0, s, tiles, y, C, (long long)T * hop, n,
-                       Ls, stride, halo, hop, (long long)T);
-    FV_HIP_CHECK(hipGetLastError());
+    for (long long bi0 = 0; bi0 < (long long)B * n; bi0 += kMaxGridZ) {
+        const unsigned nz = (unsigned)std::min<long long>(kMaxGridZ, (long long)B * n - bi0);
+        hipLaunchKernelGGL(scatter_tiles_kernel, dim3((unsigned)((Ls + 255) / 256), C, nz), dim3(256), 0, s, tiles, y, C, (long long)T * hop, n,
+                           Ls, stride, halo, hop, (long long)T, (int)bi0);
+        FV_HIP_CHECK(hipGetLastError());
+    }
     return FV_OK;
 }
 

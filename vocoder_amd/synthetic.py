@@ -47,6 +47,17 @@ def _put_wn(sd, prefix, rng, shape, fan_in, gain, bias_len, bias_std=0.05):
     sd[f"{prefix}.parametrizations.weight.original1"] = v
 
 
+def _put_noise_convs(sd, rng, c0, rates):
+    """noise_convs.{i}: Conv1d(1, C_i, 2 s, stride s, padding s // 2) with s = prod(rates[i + 1:]); Conv1d(1, C, 1) for the last
+    stage (hifigan.py:192-204, bigvgan.py:311-324).  Plain convs: no weight norm."""
+    for i in range(len(rates)):
+        ch = c0 // 2 ** (i + 1)
+        s_f0 = int(np.prod(rates[i + 1:])) if i + 1 < len(rates) else 1
+        k = 2 * s_f0 if i + 1 < len(rates) else 1
+        sd[f"noise_convs.{i}.weight"] = rng.normal(0.0, 0.5 / sqrt(k), size=(ch, 1, k)).astype(np.float32)
+        sd[f"noise_convs.{i}.bias"] = rng.normal(0.0, 0.05, size=ch).astype(np.float32)
+
+
 def hifigan_state_dict(cfg: dict, seed: int = 0) -> dict:
     """State dict for HiFiGANGenerator(**cfg) (use_template=False), reference key order
     (/root/reference/fish_vocoder/modules/generators/hifigan.py:158-224)."""
@@ -57,13 +68,7 @@ def hifigan_state_dict(cfg: dict, seed: int = 0) -> dict:
     pk, qk = cfg.get("pre_conv_kernel_size", 7), cfg.get("post_conv_kernel_size", 7)
     _put_wn(sd, "conv_pre", rng, (c0, nm, pk), nm * pk, 0.35, c0)
     if cfg.get("use_template", False):   # reference key order: conv_pre, noise_convs, ups, resblocks, conv_post
-        rates = list(cfg["upsample_rates"])
-        for i in range(len(rates)):
-            ch = c0 // 2 ** (i + 1)
-            s_f0 = int(np.prod(rates[i + 1:])) if i + 1 < len(rates) else 1
-            k = 2 * s_f0 if i + 1 < len(rates) else 1
-            sd[f"noise_convs.{i}.weight"] = rng.normal(0.0, 0.5 / sqrt(k), size=(ch, 1, k)).astype(np.float32)
-            sd[f"noise_convs.{i}.bias"] = rng.normal(0.0, 0.05, size=ch).astype(np.float32)
+        _put_noise_convs(sd, rng, c0, list(cfg["upsample_rates"]))
     for i, (u, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
         cin, cout = c0 // 2**i, c0 // 2 ** (i + 1)
         # ConvTranspose1d weight is (C_in, C_out, k): weight-norm dim 0 = C_in
@@ -91,6 +96,8 @@ def bigvgan_state_dict(cfg: dict, seed: int = 0, with_filters: bool = True, post
     pk, qk = cfg.get("pre_conv_kernel_size", 7), cfg.get("post_conv_kernel_size", 7)
     nk = len(cfg["resblock_kernel_sizes"])
     _put_wn(sd, "conv_pre", rng, (c0, nm, pk), nm * pk, 0.35, c0)
+    if cfg.get("use_template", False):   # reference key order: conv_pre, noise_convs, ups, ... (bigvgan.py:291-328)
+        _put_noise_convs(sd, rng, c0, list(cfg["upsample_rates"]))
     for i, (u, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
         cin, cout = c0 // 2**i, c0 // 2 ** (i + 1)
         _put_wn(sd, f"ups.{i}", rng, (cin, cout, k), cin * max(k // u, 1), 1.0, cout)
