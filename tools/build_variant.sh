@@ -14,7 +14,7 @@ for tu in $TUS; do
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done
-for o in build/*.o; do
+for o in $(make -s print-objs); do
   b=$(basename $o .o)
   if echo " $TUS " | grep -q " $b "; then objs="$objs build_$NAME/$b.o"; else objs="$objs $o"; fi
 done

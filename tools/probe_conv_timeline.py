@@ -49,3 +49,32 @@ cnt = np.array([np.sum(cu == c) for c in ucu])
 print(f"  CUs seen {len(ucu)}; workgroups per CU min {cnt.min()} mean {cnt.mean():.2f} max {cnt.max()}")
 ends = np.array([end[cu == c].max() for c in ucu])
 print("  last end per CU           ", pct(ends))
+# Are the co-resident workgroups of a CU in lock-step?  For every workgroup: the partner on the same CU whose life overlaps its own the longest; the
+# offset between the two "chunk c staged" stamp trains, folded into one chunk period (0 = they stage together, 0.5 = perfectly alternating).
+if nch > 3:
+    offs, ovl = [], []
+    for c in ucu:
+        idx = np.where(cu == c)[0]
+        for i in idx:
+            best, bo = -1, 0.0
+            for j in idx:
+                if j == i:
+                    continue
+                o = min(end[i], end[j]) - max(start[i], start[j])
+                if o > bo:
+                    best, bo = j, o
+            if best < 0:
+                continue
+            ti, tj = t[i, 1:1 + nch], t[best, 1:1 + nch]
+            per_i = np.median(np.diff(ti))
+            m = nch // 2
+            d = np.abs(tj - ti[m]).min()
+            offs.append((d % per_i) / per_i)
+            ovl.append(bo / (end[i] - start[i]))
+    offs = np.minimum(offs, 1.0 - np.array(offs))
+    print(f"  partner stamp offset / chunk period (0 = lock-step, 0.5 = alternating): p10 {np.percentile(offs, 10):.2f} p50 {np.percentile(offs, 50):.2f} p90 {np.percentile(offs, 90):.2f}; "
+          f"life overlap with that partner p50 {np.percentile(ovl, 50):.2f}")
+    # chunk period of the workgroups by partner offset: in lock-step the two waves of a SIMD stage together and share the pipe in between
+    per_wg = np.median(np.diff(t[:, 1:1 + nch], axis=1), axis=1)
+    print("  workgroups per CU over time: max concurrent", max(int(sum((start[cu == c] <= tt) & (end[cu == c] > tt))) for c in ucu[:8] for tt in np.linspace(0, end.max(), 50)))
+    print("  chunk period by launch order (first 512 / rest): p50 %.2f / %.2f" % (np.percentile(per_wg[np.argsort(start)[:512]], 50), np.percentile(per_wg[np.argsort(start)[512:]], 50) if len(per_wg) > 512 else float("nan")))

@@ -156,7 +156,7 @@ fv_status conv_layer_create(ConvLayer& L, bool transposed, int c_in, int c_out, 
         L.wino = true;
         const bool quad_layer = c_in >= 64 && c_in % 8 == 0 && c_out % 64 == 0 && k >= 7;
         const bool use_f44 = quad_layer && knobs().wino4 && knobs().wino44;
-        const bool use_f43 = quad_layer && knobs().wino4 && !knobs().wino44;
+        const bool use_f43 = quad_layer && knobs().wino4 && !knobs().wino44 && have_conv_wino4();
         const int ng = (k + 1) / 4, ns = (k - 3) / 4;
         const int nv = 4 * ng + 2 * ns;
         std::vector<float> ww((size_t)c_out * c_in * nv);

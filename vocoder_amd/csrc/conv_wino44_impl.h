@@ -91,6 +91,15 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
     const int n0 = n_tile * NBQ;
     const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
 
+#ifdef FV_X_CONV_TS
+    if (p.dbg_ts && threadIdx.x == 0) p.dbg_ts[(long long)blockIdx.x * 16 + 15] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);   // HW_ID, XCC_ID
+#endif
+#ifdef FV_X_W44_STAGGER   // experiment (LOG R6.x): the first round's second workgroup of every CU starts FV_X_W44_STAGGER x 3.4 us late
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll
+        for (int i = 0; i < FV_X_W44_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     FV_CV_STAMP(0);
     f32x16 acc[MT][4];
 #pragma unroll
@@ -151,15 +160,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
 #pragma unroll
             for (int j = 0; j < 4; ++j) sx[j * NE + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, vo[i][j], 0, 0));
     };
-#ifndef FV_X_W44_ABL
-#define FV_X_W44_ABL 0   // timing ablations (WRONG results; tools/probe_w44_ablation.py, LOG R5.x): 1 no transform arithmetic, 2 no scratch exchange,
-#endif                   // 4 one B read per step, 8 no plane writes, 16 no weight loads in the loop, 32 no pre-activation, 64 no activation loads after chunk 0,
-                         // 128 one store / residual load of every sixteen, 256 no post-activation
-    constexpr int ABL = FV_X_W44_ABL;
+    // store_chunk: one chunk staged as a PHASE of its own (activation -> raw phases to the scratch columns -> neighbours back -> seven planes).  Since round 6
+    // only chunk 0 of a workgroup (and every chunk of the PRE == 2 instances, whose run-time activation switch would put branches into the matrix loop) is
+    // staged this way; the others are staged piece by piece INSIDE the previous chunk's matrix loop (stage_A / stage_R / stage_T below).
     auto store_chunk = [&](float* dst, float (&sx)[4 * NE]) {
-        if constexpr (!(ABL & 32) && PRE != 0) act_apply_all(sx, PRE == 1 ? (int)FV_ACT_SILU : p.pre_act, p.slope);   // act(0) == 0 keeps the zero padding
+        if constexpr (PRE != 0) act_apply_all(sx, PRE == 1 ? (int)FV_ACT_SILU : p.pre_act, p.slope);   // act(0) == 0 keeps the zero padding
         float x4[NE], x5[NE], x6[NE];
-        if constexpr (!(ABL & 2)) {
 #pragma unroll
         for (int i = 0; i < NE; ++i)
 #pragma unroll
@@ -175,41 +181,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
             x5[i] = dst[lo[i] + G::X_OFF + WR + DIL];
             x6[i] = dst[lo[i] + G::X_OFF + 2 * WR + DIL];
         }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                x4[i] = sx[i];
-                x5[i] = sx[NE + i];
-                x6[i] = sx[2 * NE + i];
-            }
-        }
-        if constexpr ((ABL & 1) != 0) {
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                if constexpr (!(ABL & 8)) {
-                    dst[lo[i]] = sx[i];
-                    dst[lo[i] + WR] = sx[NE + i];
-                    dst[lo[i] + 2 * WR] = sx[2 * NE + i];
-                    dst[lo[i] + 3 * WR] = sx[3 * NE + i];
-                    dst[lo[i] + 4 * WR] = x4[i];
-                    dst[lo[i] + 5 * WR] = x5[i];
-                    dst[lo[i] + G::V_INF] = x6[i];
-                } else if (p.Tin < 0) {
-                    dst[lo[i]] = sx[i] + sx[NE + i] + sx[2 * NE + i] + sx[3 * NE + i] + x4[i] + x5[i] + x6[i];
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const float x0 = sx[i], x1 = sx[NE + i], x2 = sx[2 * NE + i], x3 = sx[3 * NE + i];
             const float eh = fmaf(4.0f, x0, fmaf(-5.0f, x2, x4[i])), oh = fmaf(4.0f, x1, fmaf(-5.0f, x3, x5[i]));          // a = 1/2
             const float e1 = fmaf(-4.25f, x2, x4[i]) + x0, o1 = fmaf(-4.25f, x3, x5[i]) + x1;                                // a = 1
             const float e2 = fmaf(0.25f, x0, fmaf(-1.25f, x2, x4[i])), o2 = fmaf(0.25f, x1, fmaf(-1.25f, x3, x5[i]));        // a = 2
-            if constexpr ((ABL & 8) != 0) {
-                if (p.Tin < 0) dst[lo[i]] = eh + oh + e1 + o1 + e2 + o2 + x6[i];
-                continue;
-            }
             dst[lo[i]] = fmaf(0.5f, eh, oh);
             dst[lo[i] + WR] = fmaf(-0.5f, eh, oh);
             dst[lo[i] + 2 * WR] = o1 + e1;
@@ -218,6 +195,53 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
             dst[lo[i] + 5 * WR] = fmaf(-2.0f, e2, o2);
             dst[lo[i] + G::V_INF] = fmaf(5.25f, x2 - x4[i], x6[i] - x0);
         }
+    };
+    // The same staging in three pieces per lattice element, issued as short bursts between the MFMAs of the PREVIOUS chunk's matrix loop (round 6).  Why: a
+    // vector instruction costs the matrix pipe ~4 cycles when it comes from the wave that owns the MFMA stream, in a burst, and 12 - 16 when it comes from the
+    // partner wave of the SIMD between that wave's MFMAs (tools/ubench/mfma_mix.hip, LOG R3.1) — and a staging PHASE is exactly that: while one workgroup
+    // stages, the other workgroup of the CU is in its matrix loop (profiles/r06b_w44_timeline.txt: co-resident workgroups alternate, chunk period 11.0 us
+    // for 2 x 4.8 us of MFMAs).  It also takes the staging latency (LDS round trip of the neighbour columns, the barrier) off a lone workgroup's path.
+    //   A_i: activation of the element's four samples, raw phases X0..X2 -> scratch columns        (step i)
+    //   R_i: neighbours x4 x5 x6 (column + D of the same row, written by this wave: in-order LDS)    (step NE + i)
+    //   T_i: transform, seven planes -> the OTHER chunk buffer                                      (step NE + 1 + i)
+#ifndef FV_X_W44_INLOOP
+#define FV_X_W44_INLOOP 1
+#endif
+    constexpr bool INLOOP = FV_X_W44_INLOOP && PRE != 2 && !(FLAT && DIL == 3 && PRE == 1);   // (the flattened D = 3 instance behind a SiLU spills 219 registers with the pieces in its loop)
+    [[maybe_unused]] float xn[NE][3];
+    auto stage_A = [&](float* dst, float (&sx)[4 * NE], auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if constexpr (PRE == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sx[j * NE + i] = sx[j * NE + i] * __builtin_amdgcn_rcpf(1.0f + __expf(-sx[j * NE + i]));   // silu(0) == 0 keeps the zero padding
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dst[lo[i] + G::X_OFF + j * WR] = sx[j * NE + i];
+    };
+    auto stage_R = [&](const float* dst, auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if constexpr (i == 0) {   // (every A piece precedes the first R piece in program order; the fences keep the compiler from reordering across them)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        xn[i][0] = dst[lo[i] + G::X_OFF + DIL];
+        xn[i][1] = dst[lo[i] + G::X_OFF + WR + DIL];
+        xn[i][2] = dst[lo[i] + G::X_OFF + 2 * WR + DIL];
+    };
+    auto stage_T = [&](float* dst, const float (&sx)[4 * NE], auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        const float x0 = sx[i], x1 = sx[NE + i], x2 = sx[2 * NE + i], x3 = sx[3 * NE + i], x4 = xn[i][0], x5 = xn[i][1], x6 = xn[i][2];
+        const float eh = fmaf(4.0f, x0, fmaf(-5.0f, x2, x4)), oh = fmaf(4.0f, x1, fmaf(-5.0f, x3, x5));          // a = 1/2
+        const float e1 = fmaf(-4.25f, x2, x4) + x0, o1 = fmaf(-4.25f, x3, x5) + x1;                              // a = 1
+        const float e2 = fmaf(0.25f, x0, fmaf(-1.25f, x2, x4)), o2 = fmaf(0.25f, x1, fmaf(-1.25f, x3, x5));      // a = 2
+        dst[lo[i]] = fmaf(0.5f, eh, oh);
+        dst[lo[i] + WR] = fmaf(-0.5f, eh, oh);
+        dst[lo[i] + 2 * WR] = o1 + e1;
+        dst[lo[i] + 3 * WR] = o1 - e1;
+        dst[lo[i] + 4 * WR] = fmaf(2.0f, e2, o2);
+        dst[lo[i] + 5 * WR] = fmaf(-2.0f, e2, o2);
+        dst[lo[i] + G::V_INF] = fmaf(5.25f, x2 - x4, x6 - x0);
     };
 
     const int mt0 = (m_blk * 2 + wm) * MT;   // first 32-row tile of this wave
@@ -240,22 +264,11 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
     float4 aq[MT][DA + 1];
     float b_cur[4], b_nxt[4];
     // chunks in pairs (the two register sets alternate at compile time): p.nchunk is a multiple of four 8-channel blocks — the packed weights of the padding are zero
-    const int nch = C64 ? 8 / SUBS : (p.nchunk / SUBS + 1) / 2 * 2;   // (compile-time counts for C = 128 / 256 too: no difference in the step)
-    // (the same issue order as around the loop's back edge — set a, weight prefetch, set b: where the two paths into the loop header disagree the compiler
-    //  assumes the worst of both and waits for set b at the end of the first staging phase)
-    load_chunk(0, sx_a);
-#pragma unroll
-    for (int d = 0; d < DA; ++d)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) aq[i][d] = load_a(i, d * 1024);
-    __builtin_amdgcn_sched_barrier(0);
-    load_chunk(1, sx_b);
-    __builtin_amdgcn_sched_barrier(0);
-    auto chunk_body = [&](int c, float (&sx)[4 * NE]) __attribute__((always_inline)) {
-        float* xsb = xs + (c & 1) * (CH * ROW);
-        store_chunk(xsb, sx);
-        __syncthreads();
-        if (c < 12) FV_CV_STAMP(1 + c);
+    int nch = C64 ? 8 / SUBS : (p.nchunk / SUBS + 1) / 2 * 2;   // (compile-time counts for C = 128 / 256 too: no difference in the step)
+    if constexpr (C64 && INLOOP) asm volatile("" : "+s"(nch));   // (opaque: fully unrolled, the in-loop staging pieces of four chunk pairs cost these instances 24 spilt registers)
+    static_assert(!INLOOP || STEPS >= 2 * NE + 1, "the in-loop staging needs 2 NE + 1 matrix steps per chunk");
+    // One matrix step.  STG (INLOOP only): the staging pieces of chunk c + 1 that ride in this chunk's steps.
+    auto mfma_loop = [&](int c, float* xsb, float* xsn, [[maybe_unused]] float (&sxn)[4 * NE]) __attribute__((always_inline)) {
         const int gchunk_b = __builtin_amdgcn_readfirstlane((c * STEPS + DA) * 1024);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b_cur[j] = xsb[b_lane_g + G::off_of(0, j)];
@@ -275,12 +288,21 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
                     }
                 }
                 // one weight fragment per row tile (DA fragments ahead) and the next step's operands, spread over this step's MFMAs
-                if (m < MT && (!(ABL & 16) || st == 0)) aq[m][DA] = load_a(m, gchunk_b + st * 1024);
+                if (m < MT) aq[m][DA] = load_a(m, gchunk_b + st * 1024);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (j < NM_n && (j * NM) / 4 == m && m < NM && (!(ABL & 4) || j == 0))
+                    if (j < NM_n && (j * NM) / 4 == m && m < NM)
                         b_nxt[j] = xsb[(G::shared_of(v_n) ? b_lane_s : b_lane_g) + sub_n * kChunk * ROW + G::off_of(v_n, j)];
                 if (m < NM) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (INLOOP) {
+                    // the next chunk's staging, one burst per step behind the step's second MFMA group (the wave's own MFMAs of this step are in flight)
+                    if (m == 1) {
+                        if constexpr (st < NE) stage_A(xsn, sxn, std::integral_constant<int, st>{});
+                        if constexpr (st >= NE && st < 2 * NE) stage_R(xsn, std::integral_constant<int, st - NE>{});
+                        if constexpr (st > NE && st <= 2 * NE) stage_T(xsn, sxn, std::integral_constant<int, st - NE - 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -289,16 +311,63 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
                 for (int d = 0; d < DA; ++d) aq[i][d] = aq[i][d + 1];
             if constexpr (st + 1 < STEPS) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b_cur[j] = ((ABL & 4) && j > 0) ? b_nxt[0] : b_nxt[j];
+                for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];
             }
         });
-        // the chunk after next, behind every weight request of this loop (see sx_a / sx_b above)
-        if constexpr (!(ABL & 64)) load_chunk(c + 2, sx);
-        __builtin_amdgcn_sched_barrier(0);
     };
-    for (int c = 0; c < nch; c += 2) {
-        chunk_body(c, sx_a);
-        chunk_body(c + 1, sx_b);
+    if constexpr (INLOOP) {
+        // Register sets: sx_t holds chunk 0 (staged as a phase before the first matrix loop; dead afterwards — the accumulators are not live yet), sx_b the odd
+        // chunks, sx_a the even ones from chunk 2 on.  Chunk c + 1 is staged inside chunk c's matrix loop; the set it frees is reloaded with chunk c + 3 behind
+        // that loop's last weight request (loads return in order: LOG R5.2), two matrix loops before it is needed.
+        float sx_t[4 * NE];
+        load_chunk(0, sx_t);
+#pragma unroll
+        for (int d = 0; d < DA; ++d)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) aq[i][d] = load_a(i, d * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(1, sx_b);
+        load_chunk(2, sx_a);
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(xs, sx_t);
+        auto chunk_body = [&](int c, float (&sxn)[4 * NE]) __attribute__((always_inline)) {
+            float* xsb = xs + (c & 1) * (CH * ROW);
+            float* xsn = xs + ((c + 1) & 1) * (CH * ROW);
+            __syncthreads();   // chunk c is staged (by every wave, in the previous loop); every wave is past its reads of the other buffer (chunk c - 1)
+            if (c < 12) FV_CV_STAMP(1 + c);
+            mfma_loop(c, xsb, xsn, sxn);
+            load_chunk(c + 3, sxn);   // (past the layer's last chunk: an empty descriptor, zeros — the piece staged from it lands in the buffer nobody reads)
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int c = 0; c < nch; c += 2) {
+            chunk_body(c, sx_b);
+            chunk_body(c + 1, sx_a);
+        }
+    } else {
+        // (the same issue order as around the loop's back edge — set a, weight prefetch, set b: where the two paths into the loop header disagree the compiler
+        //  assumes the worst of both and waits for set b at the end of the first staging phase)
+        load_chunk(0, sx_a);
+#pragma unroll
+        for (int d = 0; d < DA; ++d)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) aq[i][d] = load_a(i, d * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(1, sx_b);
+        __builtin_amdgcn_sched_barrier(0);
+        auto chunk_body = [&](int c, float (&sx)[4 * NE]) __attribute__((always_inline)) {
+            float* xsb = xs + (c & 1) * (CH * ROW);
+            store_chunk(xsb, sx);
+            __syncthreads();
+            if (c < 12) FV_CV_STAMP(1 + c);
+            mfma_loop(c, xsb, xsb, sx);
+            // the chunk after next, behind every weight request of this loop (see sx_a / sx_b above)
+            load_chunk(c + 2, sx);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int c = 0; c < nch; c += 2) {
+            chunk_body(c, sx_a);
+            chunk_body(c + 1, sx_b);
+        }
     }
 
     FV_CV_STAMP(13);
@@ -339,9 +408,21 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
             const unsigned vq = t4 < p.N ? (unsigned)(ybo + mrow * p.N + t4) * 4u : 0xFFFFFFFFu;
             const bool has_res = p.res != nullptr;
             const float* pq = xs + (wave ^ 1) * 2048 + lane;        // partner's partials of the rows this half keeps: [kept register][output] x 64 lanes
+            // Round 6: the bias and residual operands of every row of a tile are requested at once, before the tile's exchange barriers — the epilogue used to
+            // request four rows, wait, store, four times per launch: ~9 us of a lone workgroup's life, 19 us beside a partner in its matrix loop
+            // (profiles/r06b_w44_timeline.txt), most of it memory latency.  The weight ring and the staging sets are dead by now.
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int mt = mt0 + i;
+                // (a tile's eight rows: requested before the tile's exchange, consumed behind its two barriers — both tiles at once spilt 32 registers)
+                float biasq[1][8];
+                u32x4 rqq[1][8];
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int row_s = mt * 32 + (rr & 3) + 8 * (2 * h + (rr >> 2));
+                    biasq[0][rr] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, mrow * 4, row_s * 4, 0));
+                    if (has_res) rqq[0][rr] = __builtin_amdgcn_raw_buffer_load_b128(rrs, vq, (int)((unsigned)row_s * (unsigned)p.N * 4u), 0);
+                }
                 __syncthreads();
                 // partial sums of all four outputs, in place: register r of accumulator plane j becomes y_j's partial; the registers of the OTHER half's rows go
                 // to the exchange area (H at compile time under a wave-uniform branch: no selects, no copies)
@@ -384,29 +465,22 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
                     constexpr int H = decltype(h_c)::value;
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
-                        float bias[4];
-                        u32x4 rq[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int row_s = mt * 32 + k + 8 * (2 * H + g);
-                            bias[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, mrow * 4, row_s * 4, 0));
-                            if (has_res) rq[k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, vq, (int)((unsigned)row_s * (unsigned)p.N * 4u), 0);
-                        }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int rr = 4 * g + k, r = 8 * H + rr;
                             const int row_s = mt * 32 + k + 8 * (2 * H + g);
+                            const float bias_k = biasq[0][rr];
                             float o[4];
                             // (the split by outputs forms  own + partner  in half 0 for j = 0, 1 and in half 1 for j = 2, 3: the same two addends)
-                            o[0] = fmaf(acc[i][0][r] + pq[(rr * 4 + 0) * 64], 1.0f, bias[k]);
-                            o[1] = fmaf(acc[i][1][r] + pq[(rr * 4 + 1) * 64], 1.0f, bias[k]);
-                            o[2] = fmaf(acc[i][2][r] + pq[(rr * 4 + 2) * 64], 1.0f, bias[k]);
-                            o[3] = fmaf(acc[i][3][r] + pq[(rr * 4 + 3) * 64], 1.0f, bias[k]);
+                            o[0] = fmaf(acc[i][0][r] + pq[(rr * 4 + 0) * 64], 1.0f, bias_k);
+                            o[1] = fmaf(acc[i][1][r] + pq[(rr * 4 + 1) * 64], 1.0f, bias_k);
+                            o[2] = fmaf(acc[i][2][r] + pq[(rr * 4 + 2) * 64], 1.0f, bias_k);
+                            o[3] = fmaf(acc[i][3][r] + pq[(rr * 4 + 3) * 64], 1.0f, bias_k);
                             if (has_res) {
-                                o[0] += __uint_as_float(rq[k].x);
-                                o[1] += __uint_as_float(rq[k].y);
-                                o[2] += __uint_as_float(rq[k].z);
-                                o[3] += __uint_as_float(rq[k].w);
+                                o[0] += __uint_as_float(rqq[0][rr].x);
+                                o[1] += __uint_as_float(rqq[0][rr].y);
+                                o[2] += __uint_as_float(rqq[0][rr].z);
+                                o[3] += __uint_as_float(rqq[0][rr].w);
                             }
                             act_apply_all(o, p.post_act, p.slope);
                             u32x4 v;
@@ -468,7 +542,6 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int so = (int)((unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);   // (< 4 GiB per item: conv_layer_run)
-                    if ((ABL & 128) && r > 0) { ra[r] = ra[0]; rb[r] = rb[0]; continue; }
                     ra[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, va, so, 0));
                     rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, vb, so, 0));
                 }
@@ -489,23 +562,10 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
                     ob[r] += rb[r];
                 }
             }
-            if constexpr (!(ABL & 256)) {
             act_apply_all(oa, p.post_act, p.slope);   // (c1 of a ResBlock pair carries the SiLU in front of c2: hifigan.py:104-106)
             act_apply_all(ob, p.post_act, p.slope);
-            }
-            if constexpr ((ABL & 128) != 0) {
-                float sa = 0.f, sb = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sa += oa[r];
-                    sb += ob[r];
-                }
-                oa[0] = sa;
-                ob[0] = sb;
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if ((ABL & 128) && r > 0) continue;
                 const int so = (int)((unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N * 4u);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oa[r]), yrs, va, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ob[r]), yrs, vb, so, 0);

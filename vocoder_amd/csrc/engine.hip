@@ -14,11 +14,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 
 #include "fv_internal.h"
 
@@ -523,37 +525,57 @@ struct fv_engine {
     }
     // Folded conv weight: weight-norm g * v / ||v|| over all dims but 0 (torch._weight_norm(v, g, 0); for
     // ConvTranspose1d dim 0 is C_in — SURVEY §0.4), or a plain ".weight".
-    fv_status conv_weight(const std::string& prefix, const std::vector<int64_t>& shape, std::vector<float>& w) {
-        const int64_t n0 = shape[0];
-        int64_t inner = 1;
-        for (size_t i = 1; i < shape.size(); ++i) inner *= shape[i];
+    // The lookup half (names, shapes: on the caller's thread, in state-dict order, so that error messages are deterministic) and the arithmetic half
+    // (fold_weight: any thread) are separate since round 6: fv_finalize folds, packs and uploads the layers on all host cores (run_jobs).
+    struct WeightRef {
+        const HostTensor *g = nullptr, *v = nullptr, *plain = nullptr;
+        int64_t n0 = 0, inner = 1;
+    };
+    fv_status conv_weight_ref(const std::string& prefix, const std::vector<int64_t>& shape, WeightRef& r) {
+        r.n0 = shape[0];
+        r.inner = 1;
+        for (size_t i = 1; i < shape.size(); ++i) r.inner *= shape[i];
         std::string gk = prefix + ".parametrizations.weight.original0", vk = prefix + ".parametrizations.weight.original1";
         if (!raw.count(gk) && raw.count(prefix + ".weight_g")) {
             gk = prefix + ".weight_g";
             vk = prefix + ".weight_v";
         }
         if (raw.count(gk)) {
-            const HostTensor *g, *v;
-            fv_status st = need(gk, {n0}, &g, true);
+            fv_status st = need(gk, {r.n0}, &r.g, true);
             if (st) return st;
-            st = need(vk, shape, &v);
-            if (st) return st;
-            w.resize((size_t)n0 * inner);
-            for (int64_t i = 0; i < n0; ++i) {
-                const float* vi = v->data.data() + i * inner;
-                double s = 0.0;
-                for (int64_t j = 0; j < inner; ++j) s += (double)vi[j] * vi[j];
-                const float scale = g->data[i] / (float)std::sqrt(s);
-                for (int64_t j = 0; j < inner; ++j) w[i * inner + j] = vi[j] * scale;
-            }
-            return FV_OK;
+            return need(vk, shape, &r.v);
         }
-        const HostTensor* t;
-        fv_status st = need(prefix + ".weight", shape, &t, true);
+        return need(prefix + ".weight", shape, &r.plain, true);
+    }
+    static void fold_weight(const WeightRef& r, std::vector<float>& w) {
+        if (!r.g) {
+            w = r.plain->data;
+            return;
+        }
+        w.resize((size_t)r.n0 * r.inner);
+        for (int64_t i = 0; i < r.n0; ++i) {
+            const float* vi = r.v->data.data() + i * r.inner;
+            double s = 0.0;
+            for (int64_t j = 0; j < r.inner; ++j) s += (double)vi[j] * vi[j];
+            const float scale = r.g->data[i] / (float)std::sqrt(s);
+            for (int64_t j = 0; j < r.inner; ++j) w[i * r.inner + j] = vi[j] * scale;
+        }
+    }
+    fv_status conv_weight(const std::string& prefix, const std::vector<int64_t>& shape, std::vector<float>& w) {
+        WeightRef r;
+        fv_status st = conv_weight_ref(prefix, shape, r);
         if (st) return st;
-        w = t->data;
+        fold_weight(r, w);
         return FV_OK;
     }
+    // Deferred layer builds (fold -> fragment packing in up to three forms -> upload): queued by make_conv, run by run_jobs on the host's cores.  A job
+    // touches only its own ConvLayer and tensors of `raw` (alive until fv_finalize clears it); `cost` orders the queue largest first.
+    struct BuildJob {
+        int64_t cost;
+        std::function<fv_status()> fn;
+    };
+    std::vector<BuildJob> jobs;
+    fv_status run_jobs();
     fv_status vec(const std::string& name, int64_t n, std::vector<float>& out) {
         const HostTensor* t;
         fv_status st = need(name, {n}, &t, true);
@@ -563,16 +585,24 @@ struct fv_engine {
     }
     fv_status make_conv(ConvLayer& L, const std::string& prefix, bool transposed, int c_in, int c_out, int k, int dil,
                         int padding, int stride) {
-        std::vector<float> w, b;
         const std::vector<int64_t> shape = transposed ? std::vector<int64_t>{c_in, c_out, k} : std::vector<int64_t>{c_out, c_in, k};
-        fv_status st = conv_weight(prefix, shape, w);
+        WeightRef r;
+        fv_status st = conv_weight_ref(prefix, shape, r);
         if (st) return st;
-        st = vec(prefix + ".bias", c_out, b);
+        const HostTensor* bt;
+        st = need(prefix + ".bias", {c_out}, &bt, true);
         if (st) return st;
-        st = conv_layer_create(L, transposed, c_in, c_out, k, dil, padding, stride, w.data(), b.data(),
-                               precision == FV_PRECISION_F16X3);
-        L.precision = precision;
-        return st;
+        const int prec = precision;
+        ConvLayer* Lp = &L;   // (owned by a unique_ptr'd stage / a member of the engine: the address is stable)
+        jobs.push_back({(int64_t)c_in * c_out * k, [=]() -> fv_status {
+                            std::vector<float> w;
+                            fold_weight(r, w);
+                            const fv_status s2 = conv_layer_create(*Lp, transposed, c_in, c_out, k, dil, padding, stride, w.data(), bt->data.data(),
+                                                                   prec == FV_PRECISION_F16X3);
+                            Lp->precision = prec;
+                            return s2;
+                        }});
+        return FV_OK;
     }
     fv_status make_dev_vec(const std::string& name, int64_t n, float** d) {
         std::vector<float> v;
@@ -666,6 +696,53 @@ struct fv_engine {
 static int get_padding(int k, int d = 1) { return (k * d - d) / 2; }  // hifigan.py:21-22
 // RefineGAN builds AdaIN(channels=...) without forwarding the generator's slope (refinegan.py:157,165): always 0.2
 constexpr float kAdaINSlope = 0.2f;
+
+// Engine creation is the latency of the reference's one-shot caller (test.py:31-38: build, load, ONE forward per file): the weight-norm fold and the
+// fragment packing of HiFiGAN-V1's 97 convs took ~95 ms on one host thread (profiles/r06a_engine_create_probe.txt).  The layers are independent: worker
+// threads take them largest first.  FV_BUILD_THREADS=1 is the serial path (A/B, debugging).
+fv_status fv_engine::run_jobs() {
+    if (jobs.empty()) return FV_OK;
+    std::stable_sort(jobs.begin(), jobs.end(), [](const BuildJob& a, const BuildJob& b) { return a.cost > b.cost; });
+    int nt = (int)std::thread::hardware_concurrency();
+    if (const char* v = std::getenv("FV_BUILD_THREADS")) nt = std::atoi(v);
+    nt = std::max(1, std::min({nt, 32, (int)jobs.size()}));
+    if (nt == 1) {
+        for (auto& j : jobs)
+            if (fv_status st = j.fn()) return st;
+        return FV_OK;
+    }
+    int dev = 0;
+    FV_HIP_CHECK(hipGetDevice(&dev));
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{FV_OK};
+    std::mutex mu;
+    std::string first_error;
+    auto work = [&]() {
+        if (hipSetDevice(dev) != hipSuccess) {   // (the current device is per thread)
+            failed = FV_ERR_HIP;
+            return;
+        }
+        for (size_t i; failed == FV_OK && (i = next.fetch_add(1)) < jobs.size();) {
+            const fv_status st = jobs[i].fn();
+            if (st) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (failed == FV_OK) {
+                    failed = st;
+                    first_error = g_err;   // this worker's thread-local message: handed to the caller's thread below
+                }
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (failed != FV_OK) {
+        set_error("%s", first_error.empty() ? "a layer build failed on a worker thread" : first_error.c_str());
+        return (fv_status)failed.load();
+    }
+    return FV_OK;
+}
 
 fv_status fv_engine::build_upsampler(const std::string& pfx, bool bigvgan) {
     const fv_upsampler_config& c = cfg.ups;
@@ -1564,6 +1641,8 @@ FV_API fv_status fv_finalize(fv_engine* e) {
             if (!st) st = e->build_upsampler("head.", false);
             break;
     }
+    if (!st) st = e->run_jobs();
+    e->jobs.clear();
     if (st) return st;
     // strict load: unexpected keys are an error, as load_state_dict(strict=True) (test.py:37)
     for (auto& kv : e->raw)

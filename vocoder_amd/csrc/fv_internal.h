@@ -305,6 +305,7 @@ bool launch_conv_wino_k3(const ConvParams& p, int cfg, int batch, hipStream_t s)
 bool launch_conv_wino_k7(const ConvParams& p, int cfg, int batch, hipStream_t s);
 bool launch_conv_wino_k11(const ConvParams& p, int cfg, int batch, hipStream_t s);
 // conv_wino4_impl.h: F(4,3) tap groups (k = 7 / 11), 64 rows x 32 quad columns per workgroup; p.wp = the layer's d_wpw4, p.m_blks = M / 64, p.n_tiles over quad columns
+bool have_conv_wino4();   // false in the shipped library (make ABPARTNERS=1 builds the F(4,3) kernels: conv_wino4_k{7,11}.hip / abpartner_stubs.hip)
 bool launch_conv_wino4_k7(const ConvParams& p, int batch, hipStream_t s);
 bool launch_conv_wino4_k11(const ConvParams& p, int batch, hipStream_t s);
 // conv_wino44_impl.h: F(4,4) tap groups, 64 rows x 32 quad columns per workgroup; p.wp = the layer's d_wpw44, p.m_blks = M / 64, p.n_tiles over quad columns
