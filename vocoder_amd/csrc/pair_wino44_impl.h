@@ -45,8 +45,22 @@ struct PQGeom {
     static constexpr int PV = pw_up(WD1, 32, 16);        // V row stride == 16 (mod 32): the 16x16x4 B read (two channel rows per 32 lanes)
     static constexpr int V_F = 7 * CH * PV;              // [plane][channel][column]
     static constexpr int XS = TT + 2;                    // raw-tile row stride (column TT: dump for the window's halo positions)
-    static constexpr int X_F = C * SX, XR_F = C * XS + 16;
-    static constexpr int TRASH = X_F + V_F + XR_F;
+    // Round 6 (C = 32): the transform of chunk c + 1 rides inside chunk c's matrix loop into a SECOND V buffer — one workgroup barrier per chunk instead of
+    // two, and the transform's vector instructions come from the wave that owns the MFMA stream instead of a phase of their own (conv_wino44_impl.h's in-loop
+    // staging, LOG R6.2).  The second buffer takes the raw centre tile's place in LDS (three workgroups per CU: 53.3 KB each): the residual is re-read
+    // from global memory — the lines this workgroup staged ~20 us earlier, requested before c2's loop.
+#ifndef FV_X_PQ_INLOOP
+#define FV_X_PQ_INLOOP 1
+#endif
+#ifndef FV_X_PQ_INLOOP16
+#define FV_X_PQ_INLOOP16 0
+#endif
+    static constexpr bool INLOOP = FV_X_PQ_INLOOP && (C == 32 || (FV_X_PQ_INLOOP16 && C == 16 && DIL == 1));
+    static constexpr bool XRES = !INLOOP;                // raw centre tile in LDS
+    static constexpr int NVB = INLOOP ? 2 : 1;           // V buffers
+    static constexpr int X_F = C * SX, XR_F = XRES ? C * XS + 16 : 0;
+    static constexpr int XR_OFF = X_F + NVB * V_F;
+    static constexpr int TRASH = XR_OFF + XR_F;
     static constexpr int LDS_FLOATS = TRASH + 4;
 #ifndef FV_X_PQ_DA
 #define FV_X_PQ_DA 4
@@ -63,7 +77,7 @@ struct PQGeom {
 template <class G, int C>
 __device__ __forceinline__ void pq_stage_window(const float* __restrict__ xb, int T, int t0, int wave, int lane, float* __restrict__ lds) {
     float* X = lds;
-    float* Xr = lds + G::X_F + G::V_F;
+    [[maybe_unused]] float* Xr = lds + G::XR_OFF;
     constexpr int DIL = G::DILV;
     constexpr int NFULL = G::NP1 / 64, TAILW = G::NP1 % 64, RPW = C / 4, NTAIL = (RPW * TAILW + 63) / 64;
     const int ws = t0 - G::HP;
@@ -105,7 +119,7 @@ __device__ __forceinline__ void pq_stage_window(const float* __restrict__ xb, in
             const int tpos = ws + pp;
             const bool in = ok && tpos >= 0 && tpos < T;
             x_t[j] = ok ? (row0 + rr) * G::SX + x_of(pp) : G::TRASH;
-            xr_t[j] = ok ? (row0 + rr) * G::XS + xr_of(pp) : G::TRASH - G::X_F - G::V_F;   // (Xr-relative)
+            xr_t[j] = ok ? (row0 + rr) * G::XS + xr_of(pp) : G::TRASH - G::XR_OFF;   // (Xr-relative)
             vt[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, in ? (unsigned)((row0 + rr) * T + tpos) * 4u : 0xFFFFFFFFu, 0, 0));
         }
     }
@@ -114,34 +128,47 @@ __device__ __forceinline__ void pq_stage_window(const float* __restrict__ xb, in
 #pragma unroll
         for (int i = 0; i < NFULL; ++i) {
             X[x_off[i] + rr * G::SX] = pw_silu(v[rr][i]);   // silu(0) == 0: the conv's zero padding
-            Xr[xr_off[i] + rr * G::XS] = v[rr][i];
+            if constexpr (G::XRES) Xr[xr_off[i] + rr * G::XS] = v[rr][i];
         }
     if constexpr (NTAIL > 0) {
 #pragma unroll
         for (int j = 0; j < NTAIL; ++j) {
             X[x_t[j]] = pw_silu(vt[j]);
-            Xr[xr_t[j]] = vt[j];
+            if constexpr (G::XRES) Xr[xr_t[j]] = vt[j];
         }
     }
 }
 
 // X planes of the chunk's 8 channel rows -> seven V planes [plane][channel][column] (conv_wino44_impl.h's transform: symmetric points, the
 // even / odd parts shared by +-a).  32 threads per channel row, consecutive columns.
-template <class G, int DX, int WD>
-__device__ __forceinline__ void pq_transform(const float* __restrict__ xr, float* __restrict__ v, int tid) {
-    // FULL whole slots of TPR consecutive columns per channel row; the TW columns left over (WD = 64 + D (NG - 1): 1 ... 10 of a 32-column slot) are
-    // flattened over (row, column) into the first CH * TW threads — the waves past them skip the slot instead of running it all but empty
-    // (-DFV_X_PQ_TAIL=0: the masked third slot of every wave, A/B builds)
+// FULL whole slots of TPR consecutive columns per channel row; the TW columns left over (WD = 64 + D (NG - 1): 1 ... 10 of a 32-column slot) are
+// flattened over (row, column) into the first CH * TW threads — the waves past them skip the slot instead of running it all but empty
+// (-DFV_X_PQ_TAIL=0: the masked third slot of every wave, A/B builds).
+// In pieces (round 6): load() = the 7 (FULL + 1) LDS reads, slot(j) / tail_slot() = one lattice element's 21 FMA-class instructions and seven LDS writes;
+// pq_transform() runs them as a phase, the in-loop form (PQGeom::INLOOP) spreads them over the previous chunk's matrix loop.
 #ifndef FV_X_PQ_TAIL
 #define FV_X_PQ_TAIL 1
 #endif
-    constexpr int TPR = 256 / G::CH;
-    constexpr int FULL = FV_X_PQ_TAIL ? WD / TPR : (WD + TPR - 1) / TPR, TW = FV_X_PQ_TAIL ? WD - FULL * TPR : 0;
-    constexpr int PS = G::CH * G::PV;   // plane stride
-    const int row = tid / TPR, c0 = tid % TPR;
-    const float* x = xr + row * G::SX + c0;
-    float* d = v + row * G::PV + c0;
-    auto load7 = [&](const float* __restrict__ xp, float (&a)[7]) __attribute__((always_inline)) {
+template <class G, int DX, int WD>
+struct PQXform {
+    static constexpr int TPR = 256 / G::CH;
+    static constexpr int FULL = FV_X_PQ_TAIL ? WD / TPR : (WD + TPR - 1) / TPR, TW = FV_X_PQ_TAIL ? WD - FULL * TPR : 0;
+    static constexpr int PS = G::CH * G::PV;   // plane stride
+    static constexpr int NP = 1 + FULL + (TW > 0 ? 1 : 0);   // pieces: load, FULL slots, the tail slot
+    int xo, vo, xt, vt, c0;
+    bool tail;
+    float a[FULL > 0 ? FULL : 1][7], t[7];
+    __device__ __forceinline__ void init(int tid) {
+        const int row = tid / TPR;
+        c0 = tid % TPR;
+        xo = row * G::SX + c0;
+        vo = row * G::PV + c0;
+        tail = TW > 0 && tid < G::CH * TW;
+        const int tr = TW > 0 ? tid / (TW > 0 ? TW : 1) : 0, tc = FULL * TPR + tid - tr * TW;
+        xt = tr * G::SX + tc;
+        vt = tr * G::PV + tc;
+    }
+    static __device__ __forceinline__ void load7(const float* __restrict__ xp, float (&a)[7]) {
         a[0] = xp[0];
         a[1] = xp[G::PX];
         a[2] = xp[2 * G::PX];
@@ -149,8 +176,8 @@ __device__ __forceinline__ void pq_transform(const float* __restrict__ xr, float
         a[4] = xp[DX];
         a[5] = xp[G::PX + DX];
         a[6] = xp[2 * G::PX + DX];
-    };
-    auto xform7 = [&](const float (&a)[7], float* __restrict__ dp) __attribute__((always_inline)) {
+    }
+    static __device__ __forceinline__ void xform7(const float (&a)[7], float* __restrict__ dp) {
         const float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], x4 = a[4], x5 = a[5], x6 = a[6];
         const float eh = fmaf(4.0f, x0, fmaf(-5.0f, x2, x4)), oh = fmaf(4.0f, x1, fmaf(-5.0f, x3, x5));          // a = 1/2
         const float e1 = fmaf(-4.25f, x2, x4) + x0, o1 = fmaf(-4.25f, x3, x5) + x1;                              // a = 1
@@ -162,25 +189,50 @@ __device__ __forceinline__ void pq_transform(const float* __restrict__ xr, float
         dp[4 * PS] = fmaf(2.0f, e2, o2);
         dp[5 * PS] = fmaf(-2.0f, e2, o2);
         dp[6 * PS] = fmaf(5.25f, x2 - x4, x6 - x0);
-    };
-    float a[FULL > 0 ? FULL : 1][7], t[7];
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ xr) {
 #pragma unroll
-    for (int j = 0; j < FULL; ++j) load7(x + TPR * j, a[j]);
-    const bool tail = TW > 0 && tid < G::CH * TW;
-    const int tr = TW > 0 ? tid / (TW > 0 ? TW : 1) : 0, tc = FULL * TPR + tid - tr * TW;
-    if (tail) load7(xr + tr * G::SX + tc, t);
-#pragma unroll
-    for (int j = 0; j < FULL; ++j)
-        if (FV_X_PQ_TAIL || TPR * (j + 1) <= WD || c0 + TPR * j < WD) xform7(a[j], d + TPR * j);
-    if (tail) xform7(t, v + tr * G::PV + tc);
+        for (int j = 0; j < FULL; ++j) load7(xr + xo + TPR * j, a[j]);
+        if constexpr (TW > 0) {
+            if (tail) load7(xr + xt, t);
+        }
+    }
+    template <int J>
+    __device__ __forceinline__ void slot(float* __restrict__ v) {
+        if (FV_X_PQ_TAIL || TPR * (J + 1) <= WD || c0 + TPR * J < WD) xform7(a[J], v + vo + TPR * J);
+    }
+    __device__ __forceinline__ void tail_slot(float* __restrict__ v) {
+        if constexpr (TW > 0) {
+            if (tail) xform7(t, v + vt);
+        }
+    }
+    // piece I of NP
+    template <int I>
+    __device__ __forceinline__ void piece(const float* __restrict__ xr, float* __restrict__ v) {
+        if constexpr (I == 0) load(xr);
+        else if constexpr (I <= FULL) slot<I - 1>(v);
+        else if constexpr (I == FULL + 1 && TW > 0) tail_slot(v);
+    }
+};
+
+template <class G, int DX, int WD>
+__device__ __forceinline__ void pq_transform(const float* __restrict__ xr, float* __restrict__ v, int tid) {
+    PQXform<G, DX, WD> xf;
+    xf.init(tid);
+    static_for<PQXform<G, DX, WD>::NP>([&](auto i_c) __attribute__((always_inline)) { xf.template piece<decltype(i_c)::value>(xr, v); });
 }
 
 // MFMA loop over one 8-channel chunk: NF weight fragments (taps 2 f, 2 f + 1 x k-steps 0, 1), four 16x16x4 MFMAs each, ordered (tap, ks) =
 // (0,0) (1,0) (0,1) (1,1): consecutive instructions never share an accumulator plane.  bl: the lane's base into the V planes (k-quarter
 // row and quad column folded in).  CI: chunk index at compile time (ring slots are constants).
-template <class G, int DX, int CI>
+struct PQNoHook {
+    template <class F>
+    __device__ __forceinline__ void operator()(F) const {}
+};
+// hook(f): called once per fragment behind its second MFMA — the in-loop form's transform pieces of the next chunk
+template <class G, int DX, int CI, class Hook = PQNoHook>
 __device__ __forceinline__ void pq_gemm_chunk(f32x4w (&acc)[7], const float* __restrict__ bl, const __amdgpu_buffer_rsrc_t wrs, int wvoff, int wsoff,
-                                              float4 (&aq)[G::RA]) {
+                                              float4 (&aq)[G::RA], Hook hook = Hook{}) {
     constexpr int NF = G::NF, NV = G::NV, DA = G::DA, RA = G::RA, PS = G::CH * G::PV;
     auto b_off = [](int v, int s) constexpr { return G::a_of(v) * PS + 4 * s * G::PV + G::g_of(v) * DX; };
     float b_cur[4], b_nxt[4];
@@ -214,6 +266,12 @@ __device__ __forceinline__ void pq_gemm_chunk(f32x4w (&acc)[7], const float* __r
                 if (vn < NV) b_nxt[h] = bl[b_off(vn, s)];
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (!std::is_same<Hook, PQNoHook>::value) {
+                if (h == 1) {
+                    hook(f_c);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (f + 1 < NF) {
@@ -232,17 +290,20 @@ __device__ __forceinline__ void pq_output_transform(const f32x4w (&m)[7], f32x4w
     y[3] = ((0.125f * dh + d1) + 8.0f * d2) + m[6];
 }
 
-template <int KS, int DIL, int C>
 #ifndef FV_X_PQ_OCC
 #define FV_X_PQ_OCC 3
 #endif
-__global__ __launch_bounds__(256, FV_X_PQ_OCC) void pair_wino44_kernel(const PairParams p) {
+#ifndef FV_X_PQ_OCC_D1
+#define FV_X_PQ_OCC_D1 FV_X_PQ_OCC
+#endif
+template <int KS, int DIL, int C>
+__global__ __launch_bounds__(256, (PQGeom<KS, DIL, C>::INLOOP && DIL == 1 ? FV_X_PQ_OCC_D1 : FV_X_PQ_OCC)) void pair_wino44_kernel(const PairParams p) {
     using G = PQGeom<KS, DIL, C>;
     constexpr int DA = G::DA, NCHK = G::NCHK, NF = G::NF;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* X = lds;
     float* V = lds + G::X_F;
-    float* Xr = lds + G::X_F + G::V_F;
+    [[maybe_unused]] float* Xr = lds + G::XR_OFF;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,13 +344,47 @@ __global__ __launch_bounds__(256, FV_X_PQ_OCC) void pair_wino44_kernel(const Pai
     __syncthreads();
 
     // ---- c1 ----
-    static_for<NCHK>([&](auto c_c) __attribute__((always_inline)) {
-        constexpr int c = decltype(c_c)::value;
-        pq_transform<G, DIL, G::WD1>(X + c * G::CH * G::SX, V, tid);
+    // in-loop form: chunk 0 transformed as a phase, chunk c + 1 in pieces behind the MFMAs of chunk c's fragments 0 (the LDS reads), 2, 2 + PSTR, ... (one
+    // lattice element each) into the other V buffer; one barrier per chunk.  The last chunk needs none behind it: the X planes were last read before the
+    // previous barrier (c1's epilogue overwrites them), and c2's first transform writes the buffer the last chunk does not read.
+    auto conv_loop = [&](auto dx_c, auto wd_c, auto ci0_c, const __amdgpu_buffer_rsrc_t wrs, int wsoff) __attribute__((always_inline)) {
+        constexpr int DX = decltype(dx_c)::value, WDc = decltype(wd_c)::value, CI0 = decltype(ci0_c)::value;
+        using XF = PQXform<G, DX, WDc>;
+        constexpr int PSTR = (NF - 2) / (XF::NP - 1) > 0 ? (NF - 2) / (XF::NP - 1) : 1;
+        static_assert(2 + (XF::NP - 2) * PSTR <= NF - 1, "every transform piece needs a fragment of its own");
+        XF xf;
+        xf.init(tid);
+        static_for<XF::NP>([&](auto i_c) __attribute__((always_inline)) { xf.template piece<decltype(i_c)::value>(X, V); });
         __syncthreads();
-        pq_gemm_chunk<G, DIL, c>(acc, bl, w1rs, wvoff, wbase, aq);
-        __syncthreads();   // the V buffer (next transform) and the X planes (c1 epilogue) are free again
-    });
+        static_for<NCHK>([&](auto c_c) __attribute__((always_inline)) {
+            constexpr int c = decltype(c_c)::value;
+            if constexpr (c + 1 < NCHK) {
+                const float* xn = X + (c + 1) * G::CH * G::SX;
+                float* vn = V + ((c + 1) & 1) * G::V_F;
+                auto hook = [&](auto f_c) __attribute__((always_inline)) {
+                    constexpr int f = decltype(f_c)::value;
+                    if constexpr (f == 0) xf.template piece<0>(xn, vn);
+                    else if constexpr (f >= 2 && (f - 2) % PSTR == 0 && (f - 2) / PSTR + 1 < XF::NP) xf.template piece<(f - 2) / PSTR + 1>(xn, vn);
+                };
+                pq_gemm_chunk<G, DX, CI0 + c>(acc, bl + (c & 1) * G::V_F, wrs, wvoff, wsoff, aq, hook);
+                __syncthreads();   // chunk c + 1 is transformed; every wave is past its reads of chunk c
+            } else {
+                pq_gemm_chunk<G, DX, CI0 + c>(acc, bl + (c & 1) * G::V_F, wrs, wvoff, wsoff, aq);
+            }
+        });
+    };
+    if constexpr (G::INLOOP) {
+        static_assert(NCHK % 2 == 0, "c2's first transform must land in the buffer c1's last chunk does not read");
+        conv_loop(std::integral_constant<int, DIL>{}, std::integral_constant<int, G::WD1>{}, std::integral_constant<int, 0>{}, w1rs, wbase);
+    } else {
+        static_for<NCHK>([&](auto c_c) __attribute__((always_inline)) {
+            constexpr int c = decltype(c_c)::value;
+            pq_transform<G, DIL, G::WD1>(X + c * G::CH * G::SX, V, tid);
+            __syncthreads();
+            pq_gemm_chunk<G, DIL, c>(acc, bl, w1rs, wvoff, wbase, aq);
+            __syncthreads();   // the V buffer (next transform) and the X planes (c1 epilogue) are free again
+        });
+    }
     // c2's first weight fragments travel while the epilogue runs (the ring holds c1's overrun fragments: zeros, never used).  c1 consumed
     // NCHK * NF fragments: c2's fragment f sits in slot (NCHK * NF + f) % RA
     constexpr int S2 = NCHK * NF;
@@ -317,49 +412,87 @@ __global__ __launch_bounds__(256, FV_X_PQ_OCC) void pair_wino44_kernel(const Pai
         }
     }
     init_acc(p.b2);
+    // the last epilogue's addresses; without the raw tile in LDS (in-loop form) the residual is requested now, from the lines phase 0 staged, and arrives
+    // during c2's loop
+    const int tl = 4 * ncol;
+    const int t = t0 + tl;
+    const int row0 = 16 * wm + 4 * krow;
+    const bool pair8 = (T & 1) == 0 && ((unsigned long long)p.y & 7ull) == 0;
+    unsigned va[2], vb[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {              // outputs (0, 1) and (2, 3)
+        const int tlh = tl + 2 * hh;
+        const bool ok0 = tlh < G::TT && t + 2 * hh < T, ok1 = tlh + 1 < G::TT && t + 2 * hh + 1 < T;
+        va[hh] = ok0 ? (unsigned)(row0 * T + t + 2 * hh) * 4u : 0xFFFFFFFFu;
+        vb[hh] = ok1 ? (unsigned)(row0 * T + t + 2 * hh + 1) * 4u : 0xFFFFFFFFu;
+    }
+    [[maybe_unused]] float rx0[2][4], rx1[2][4];
+    if constexpr (!G::XRES) {
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)(C * T) * 4u, 0x00020000);
+        if ((T & 1) == 0 && ((unsigned long long)p.x & 7ull) == 0) {   // (an even T: both samples of a half are inside the clip or outside it)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, va[hh], __builtin_amdgcn_readfirstlane(rg * T * 4), 0);
+                    rx0[hh][rg] = __uint_as_float(v.x);
+                    rx1[hh][rg] = __uint_as_float(v.y);
+                }
+        } else {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int so = __builtin_amdgcn_readfirstlane(rg * T * 4);
+                    rx0[hh][rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, va[hh], so, 0));
+                    rx1[hh][rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, vb[hh], so, 0));
+                }
+        }
+    }
     __syncthreads();
 
     // ---- c2 (dilation 1) ----
-    static_for<NCHK>([&](auto c_c) __attribute__((always_inline)) {
-        constexpr int c = decltype(c_c)::value;
-        pq_transform<G, 1, G::WD2>(X + c * G::CH * G::SX, V, tid);
-        __syncthreads();
-        pq_gemm_chunk<G, 1, NCHK + c>(acc, bl, w2rs, wvoff, wbase - S2 * 1024, aq);
-        if (c + 1 < NCHK) __syncthreads();
-    });
+    if constexpr (G::INLOOP) {
+        conv_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, G::WD2>{}, std::integral_constant<int, NCHK>{}, w2rs, wbase - S2 * 1024);
+    } else {
+        static_for<NCHK>([&](auto c_c) __attribute__((always_inline)) {
+            constexpr int c = decltype(c_c)::value;
+            pq_transform<G, 1, G::WD2>(X + c * G::CH * G::SX, V, tid);
+            __syncthreads();
+            pq_gemm_chunk<G, 1, NCHK + c>(acc, bl, w2rs, wvoff, wbase - S2 * 1024, aq);
+            if (c + 1 < NCHK) __syncthreads();
+        });
+    }
 
-    // ---- c2 epilogue: + raw x (LDS) -> y; the lane's four outputs are consecutive samples, stored as two 8-byte halves (TT is even, so a half is
-    // inside the tile or outside it) ----
+    // ---- c2 epilogue: + raw x (LDS; in-loop form: the registers requested above) -> y; the lane's four outputs are consecutive samples, stored as two
+    // 8-byte halves (TT is even, so a half is inside the tile or outside it) ----
     {
         f32x4w y[4];
         pq_output_transform(acc, y);
-        const int tl = 4 * ncol;
-        const int t = t0 + tl;
-        const bool pair8 = (T & 1) == 0 && ((unsigned long long)p.y & 7ull) == 0;
         const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)b * C * T), 0, (unsigned)(C * T) * 4u, 0x00020000);
-        const int row0 = 16 * wm + 4 * krow;
         const bool accum = p.out_mode == OUT_ACCUM;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {          // outputs (0, 1) and (2, 3)
             const int tlh = tl + 2 * hh;
-            const bool ok0 = tlh < G::TT && t + 2 * hh < T, ok1 = tlh + 1 < G::TT && t + 2 * hh + 1 < T;
-            const unsigned va = ok0 ? (unsigned)(row0 * T + t + 2 * hh) * 4u : 0xFFFFFFFFu;
-            const unsigned vb = ok1 ? (unsigned)(row0 * T + t + 2 * hh + 1) * 4u : 0xFFFFFFFFu;
-            const float* xl = Xr + row0 * G::XS + (tlh < G::TT ? tlh : 0);
             float o0[4], o1[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const f32x2w xr = *(const f32x2w*)(xl + rg * G::XS);
-                o0[rg] = y[2 * hh][rg] + xr.x;
-                o1[rg] = y[2 * hh + 1][rg] + xr.y;
+                if constexpr (G::XRES) {
+                    const f32x2w xr = *(const f32x2w*)(Xr + row0 * G::XS + (tlh < G::TT ? tlh : 0) + rg * G::XS);
+                    o0[rg] = y[2 * hh][rg] + xr.x;
+                    o1[rg] = y[2 * hh + 1][rg] + xr.y;
+                } else {
+                    o0[rg] = y[2 * hh][rg] + rx0[hh][rg];
+                    o1[rg] = y[2 * hh + 1][rg] + rx1[hh][rg];
+                }
             }
             if (accum) {
                 float a0[4], a1[4];
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int so = __builtin_amdgcn_readfirstlane(rg * T * 4);
-                    a0[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, va, so, 0));
-                    a1[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, vb, so, 0));
+                    a0[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, va[hh], so, 0));
+                    a1[rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, vb[hh], so, 0));
                 }
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
@@ -373,14 +506,14 @@ __global__ __launch_bounds__(256, FV_X_PQ_OCC) void pair_wino44_kernel(const Pai
                     u32x2 v;
                     v.x = __float_as_uint(o0[rg]);
                     v.y = __float_as_uint(o1[rg]);
-                    __builtin_amdgcn_raw_buffer_store_b64(v, yrs, va, __builtin_amdgcn_readfirstlane(rg * T * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(v, yrs, va[hh], __builtin_amdgcn_readfirstlane(rg * T * 4), 0);
                 }
             } else {
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int so = __builtin_amdgcn_readfirstlane(rg * T * 4);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0[rg]), yrs, va, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1[rg]), yrs, vb, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0[rg]), yrs, va[hh], so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1[rg]), yrs, vb[hh], so, 0);
                 }
             }
         }
