@@ -1443,3 +1443,32 @@ def test_graft_entry_build_then_smoke_in_one_process():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], capture_output=True, text=True, cwd=repo, timeout=900)
     assert r.returncode == 0 and "smoke OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_engine_built_on_all_host_cores_equals_the_serial_build(monkeypatch):
+    """fv_finalize folds / packs / uploads the layers on the host's cores (engine.hip run_jobs; LOG R6.3: the one-shot caller of test.py:31-38 waits for
+    engine creation).  A layer's weight-norm fold (hifigan.py:94-100, folded in double) and its fragment forms are one thread's work either way, so the
+    engine built with FV_BUILD_THREADS=1 — the serial path — must give the same waveform bit for bit, for the three generator families."""
+    from vocoder_amd import _lib
+    from vocoder_amd.engine import Engine, upsampler_config
+    dev = _dev()
+    cases = []
+    cfg = dict(hop_length=64, upsample_rates=[4, 4, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4], resblock_kernel_sizes=[3, 7, 11],
+               resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=80, upsample_initial_channel=256, use_template=False, pre_conv_kernel_size=7,
+               post_conv_kernel_size=7)
+    cases.append((_lib.FV_MODEL_HIFIGAN, cfg, syn.hifigan_state_dict(cfg, 21), syn.synthetic_mel(3, 80, 41, seed=22)))
+    bcfg = dict(syn.BIGVGAN_24K)
+    cases.append((_lib.FV_MODEL_BIGVGAN, bcfg, syn.bigvgan_state_dict(bcfg, 23), syn.synthetic_mel(2, 80, 19, seed=24)))
+    outs = {}
+    for threads in ("1", None):
+        if threads is None:
+            monkeypatch.delenv("FV_BUILD_THREADS", raising=False)
+        else:
+            monkeypatch.setenv("FV_BUILD_THREADS", threads)
+        for i, (kind, c, sd, mel) in enumerate(cases):
+            eng = Engine(kind, ups=upsampler_config(**c), state_dict=sd)
+            outs[(threads, i)] = eng(torch.from_numpy(mel).to(dev)).clone()
+    torch.cuda.synchronize()
+    for i in range(len(cases)):
+        assert torch.isfinite(outs[(None, i)]).all()
+        assert torch.equal(outs[("1", i)], outs[(None, i)]), f"case {i}: the parallel build differs from the serial one"

@@ -69,7 +69,11 @@ struct Wino44Geom {
 // (leaky-ReLU: RefineGAN).  With the switch gone the staging is one basic block, and the compiler's vmcnt bookkeeping across it stays exact (round 5).
 // QR (D = 1 only): the row-split epilogue with 16-byte stores; the host launches it when the layer qualifies (wino44_quad_rows) — an instance of its own: with
 // both lean epilogues in one kernel the register allocator spills 40 - 70 values.
-template <int KS, int DIL, int VAR, int MT, int PRE, bool QR = false, bool FLAT = false>
+// PERS (round 6): a persistent grid — gridDim.x workgroups (two per CU) walk the launch's p.wg_total tiles with stride gridDim.x (tile = the workgroup index of
+// the one-tile-per-workgroup form: same (clip, row block, column tile) decomposition, neighbouring tiles of a clip still behind one L2).  What it buys is the
+// item boundary: the next tile's address plan is formed and its first activation chunk requested BEFORE the current tile's epilogue, so the ~3 us between a
+// workgroup's start and its first staged chunk (dispatch, plan, an HBM round trip) overlap the epilogue's own memory waits instead of following them.
+template <int KS, int DIL, int VAR, int MT, int PRE, bool QR = false, bool FLAT = false, bool PERS = false>
 __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_wino44_kernel(const ConvParams p) {
     static_assert(!QR || DIL == 1, "the row-split epilogue needs contiguous quads");
     using G = Wino44Geom<KS, DIL>;
@@ -82,14 +86,20 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, h = wave & 1;
     // workgroup b runs on XCD b % 8: neighbouring tiles of a clip behind one L2 (conv_wino_impl.h)
-    int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if (bid >= p.wg_total) return;
-    const int n_tile = bid % p.n_tiles;
-    bid /= p.n_tiles;
-    const int m_blk = bid % p.m_blks;
-    const int b = bid / p.m_blks;
-    const int n0 = n_tile * NBQ;
-    const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
+    int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (item >= p.wg_total) return;
+    // the tile this workgroup is on (wave-uniform; PERS: re-formed per tile)
+    int m_blk, b, n0;
+    const float* __restrict__ xb;
+    auto set_item = [&](int it) __attribute__((always_inline)) {
+        const int n_tile = it % p.n_tiles;
+        it /= p.n_tiles;
+        m_blk = it % p.m_blks;
+        b = it / p.m_blks;
+        n0 = n_tile * NBQ;
+        xb = p.x + (long long)b * p.x_bstride;
+    };
+    set_item(item);
 
 #ifdef FV_X_CONV_TS
     if (p.dbg_ts && threadIdx.x == 0) p.dbg_ts[(long long)blockIdx.x * 16 + 15] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);   // HW_ID, XCC_ID
@@ -102,17 +112,21 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
 #endif
     FV_CV_STAMP(0);
     f32x16 acc[MT][4];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][a][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][a][r] = 0.f;
+    };
+    zero_acc();
 
     // ---- staging plan (conv_wino4_impl.h): this wave owns channel rows wave * RPW .. + RPW - 1 of every chunk; lane element i = quad column
     // (lane + 64 i) % WR of row (lane + 64 i) / WR; byte offsets relative to the chunk's first row, 0xFFFFFFFF outside [0, Tin) ----
     unsigned vo[NE][4];
     int lo[NE];               // LDS float offset of (row, column) inside the chunk buffer
+    auto plan = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         int e = lane + 64 * i;
@@ -139,6 +153,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
         }
         lo[i] = row * ROW + c;
     }
+    };
+    plan();
     // Two register sets of raw activations, chunks c and c + 1 (round 5): a chunk's loads are issued at the END of the matrix loop two chunks earlier, not
     // at the start of the previous one.  Loads return in order (one vmcnt counter), so every weight fragment requested after the activation loads waits for
     // them too — HBM / MALL latency against the weights' L2 latency: at the loop's start that put the activation latency minus three steps of matrix work
@@ -147,10 +163,11 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
     float sx_a[4 * NE], sx_b[4 * NE];   // [j * NE + i]
     // (always issued, never under a branch — the compiler's vmcnt bookkeeping falls back to "wait for everything" behind a conditional load: a chunk past
     // the layer's last one gets an empty descriptor, its loads return 0 without touching memory)
+    bool live = true;   // (PERS: false once the walk is past the launch's last tile — the prefetch of "the next tile" gets an empty descriptor)
     auto load_chunk = [&](int c, float (&sx)[4 * NE]) {
         const int cbase = c * CH;
         const long long span = p.x_bstride - (long long)cbase * p.Tin;
-        const long long rows = (long long)(p.Cin - cbase) * p.Tin;
+        const long long rows = live ? (long long)(p.Cin - cbase) * p.Tin : 0;
         // (flattened columns: the descriptor spans the clips a tile may touch — whole chunks only, host-checked: a part-filled last chunk would read the
         //  next clip's rows where the per-clip form reads zeros)
         const long long lim = FLAT ? (rows > 0 ? (long long)p.col_batch * p.x_bstride - (long long)cbase * p.Tin : 0) : (rows < span ? rows : span);
@@ -209,8 +226,33 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
 #endif
     constexpr bool INLOOP = FV_X_W44_INLOOP && PRE != 2 && !(FLAT && DIL == 3 && PRE == 1);   // (the flattened D = 3 instance behind a SiLU spills 219 registers with the pieces in its loop)
     [[maybe_unused]] float xn[NE][3];
+    // FV_X_W44_SURR = N (timing experiment, LOG R6.5; results unchanged): the PRE == 0 instances of layers with one row block (M <= 128) carry, per staged
+    // sample, N v_fma_f32 (x * 1 + 0) and two v_cos_f32 in their in-loop staging piece — the vector issue of alias_free_torch's Activation1d(SnakeBeta)
+    // (38 FMA-class + 2 transcendental per output sample: small_kernels.hip aa_snake_tile) WITHOUT its LDS traffic, its halo recompute or its barriers: a
+    // lower bound of what a consumer-side fusion of that activation would cost these kernels.
+#ifndef FV_X_W44_SURR
+#define FV_X_W44_SURR 0
+#endif
+    auto surrogate = [&](float (&sx)[4 * NE], int i) __attribute__((always_inline)) {
+        if constexpr (FV_X_W44_SURR > 0 && PRE == 0) {
+            if (p.M <= 128) {
+                const float one = 1.0f, zero = 0.0f;
+#pragma unroll
+                for (int q = 0; q < FV_X_W44_SURR; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(sx[j * NE + i]) : "v"(one), "v"(zero));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float c0, c1;
+                    asm volatile("v_cos_f32 %0, %1" : "=v"(c0) : "v"(sx[j * NE + i]));
+                    asm volatile("v_cos_f32 %0, %1" : "=v"(c1) : "v"(c0));
+                }
+            }
+        }
+    };
     auto stage_A = [&](float* dst, float (&sx)[4 * NE], auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
+        surrogate(sx, i);
         if constexpr (PRE == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) sx[j * NE + i] = sx[j * NE + i] * __builtin_amdgcn_rcpf(1.0f + __expf(-sx[j * NE + i]));   // silu(0) == 0 keeps the zero padding
@@ -244,10 +286,10 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
         dst[lo[i] + G::V_INF] = fmaf(5.25f, x2 - x4, x6 - x0);
     };
 
-    const int mt0 = (m_blk * 2 + wm) * MT;   // first 32-row tile of this wave
+    int mt0 = (m_blk * 2 + wm) * MT;   // first 32-row tile of this wave
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
     const int wvoff = lane * 16;
-    const int wbase = __builtin_amdgcn_readfirstlane((mt0 * 2 + h) * (p.nchunk * NV * 1024));   // bytes per (m-tile, half): nchunk * NV fragments of 1 KiB
+    int wbase = __builtin_amdgcn_readfirstlane((mt0 * 2 + h) * (p.nchunk * NV * 1024));   // bytes per (m-tile, half): nchunk * NV fragments of 1 KiB
     const int wtile = __builtin_amdgcn_readfirstlane(2 * p.nchunk * NV * 1024);   // bytes from one 32-row tile's fragments to the next one's (same half)
     auto load_a = [&](int i, int goff_b) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wbase + i * wtile + goff_b, 0);
@@ -315,12 +357,15 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
             }
         });
     };
+    static_assert(!PERS || INLOOP, "the persistent walk is built on the in-loop staging form");
+    // Register sets: sx_t holds chunk 0 (staged as a phase before the first matrix loop; dead afterwards — the accumulators are not live yet; PERS: reloaded with
+    // the NEXT tile's chunk 0 before the epilogue), sx_b the odd chunks, sx_a the even ones from chunk 2 on.  Chunk c + 1 is staged inside chunk c's matrix
+    // loop; the set it frees is reloaded with chunk c + 3 behind that loop's last weight request (loads return in order: LOG R5.2), two matrix loops before
+    // it is needed.
+    [[maybe_unused]] float sx_t[4 * NE];
+    if constexpr (INLOOP) load_chunk(0, sx_t);
+    for (;;) {   // (one pass unless PERS)
     if constexpr (INLOOP) {
-        // Register sets: sx_t holds chunk 0 (staged as a phase before the first matrix loop; dead afterwards — the accumulators are not live yet), sx_b the odd
-        // chunks, sx_a the even ones from chunk 2 on.  Chunk c + 1 is staged inside chunk c's matrix loop; the set it frees is reloaded with chunk c + 3 behind
-        // that loop's last weight request (loads return in order: LOG R5.2), two matrix loops before it is needed.
-        float sx_t[4 * NE];
-        load_chunk(0, sx_t);
 #pragma unroll
         for (int d = 0; d < DA; ++d)
 #pragma unroll
@@ -371,13 +416,26 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
     }
 
     FV_CV_STAMP(13);
+    // the tile the epilogue stores; PERS: the walk moves on first — the next tile's plan, weights' base and first activation chunk (an empty descriptor past
+    // the last tile) are on their way while this tile's partial sums are exchanged and stored
+    const int e_n0 = n0, e_b = b, e_mt0 = mt0;
+    if constexpr (PERS) {
+        item += (int)gridDim.x;
+        live = item < p.wg_total;
+        set_item(live ? item : 0);
+        plan();
+        mt0 = (m_blk * 2 + wm) * MT;
+        wbase = __builtin_amdgcn_readfirstlane((mt0 * 2 + h) * (p.nchunk * NV * 1024));
+        load_chunk(0, sx_t);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- output transform.  y_j = sum over points a^j m(a) (+ m(∞) for j = 3); each half forms the partial sums of its planes for all four
     // outputs, keeps two of them in place (A in acc 0, B in acc 1) and passes the other two to its partner:
     //   half 0 (m(1/2) m(-1/2) m(1), its part of m(∞)):  s = m(1/2) + m(-1/2), d = m(1/2) - m(-1/2)
     //       keeps  y0: s + m1,  y1: d/2 + m1        sends  y2: s/4 + m1,  y3: d/8 + m1 + m(∞)
     //   half 1 (m(-1) m(2) m(-2), its part of m(∞)):      s = m(2) + m(-2),     d = m(2) - m(-2)
     //       sends  y0: s + m(-1),  y1: 2 d - m(-1)  keeps  y2: 4 s + m(-1),  y3: 8 d - m(-1) + m(∞) ----
-    int n = n0 + (lane & 31);
+    int n = e_n0 + (lane & 31);
     int ybo = 0;                    // flattened columns: the clip's offset in y / the residual (elements); a column past the last clip gets a position past every row's end
     if constexpr (FLAT) {
         const int bb = n / p.col_S;
@@ -400,8 +458,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
     if constexpr (QR) {
         {
             const unsigned span = yspan;
-            const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
-            const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
+            const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)e_b * p.y_bstride, span);
+            const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)e_b * p.y_bstride : p.y, span);
             const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(p.bias, (unsigned)(p.M * 4));
             const int mrow = 4 * (lane >> 5);
             const int t4 = 4 * n;                                    // first of the quad's four samples
@@ -413,7 +471,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
             // (profiles/r06b_w44_timeline.txt), most of it memory latency.  The weight ring and the staging sets are dead by now.
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int mt = mt0 + i;
+                const int mt = e_mt0 + i;
                 // (a tile's eight rows: requested before the tile's exchange, consumed behind its two barriers — both tiles at once spilt 32 registers)
                 float biasq[1][8];
                 u32x4 rqq[1][8];
@@ -494,13 +552,11 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
                 };
                 if (h == 0) phase2(std::integral_constant<int, 0>{}); else phase2(std::integral_constant<int, 1>{});
             }
-            FV_CV_STAMP(14);
-            return;
         }
-    }
+    } else {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int mt = mt0 + i;
+        const int mt = e_mt0 + i;
         __syncthreads();   // every wave is past its last operand read (i = 0: the chunk buffers become the exchange area) / past the previous tile's exchange
         {
             float* ex = xs + wave * 2048 + lane;
@@ -528,8 +584,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
         if (lean) {
             // all bias and residual operands are requested before the partner's planes are read back
             const unsigned span = yspan;
-            const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)b * p.y_bstride, span);
-            const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)b * p.y_bstride : p.y, span);
+            const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y + (long long)e_b * p.y_bstride, span);
+            const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(p.res ? p.res + (long long)e_b * p.y_bstride : p.y, span);
             const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(p.bias, (unsigned)(p.M * 4));
             const int mrow = 4 * (lane >> 5);                                   // lane part of the row; + mt * 32 + (r & 3) + 8 * (r >> 2) in SGPRs
             const unsigned va = ta < p.N ? (unsigned)(ybo + mrow * p.N + ta) * 4u : 0xFFFFFFFFu;
@@ -579,13 +635,21 @@ __global__ __launch_bounds__(256, (MT == 1 ? FV_X_WINO44_OCC : 2)) void conv_win
             }
             const int coff[2] = {ta, tb};
             const bool cok[2] = {ta < p.N, tb < p.N};
-            conv_epilogue_cols<1, 2>(p, out, b, mt, coff, cok, lane);
+            conv_epilogue_cols<1, 2>(p, out, e_b, mt, coff, cok, lane);
         }
+    }
     }
 #ifdef FV_X_CONV_TS
     __builtin_amdgcn_s_waitcnt(0);
 #endif
     FV_CV_STAMP(14);
+    if constexpr (!PERS) break;
+    else {
+        if (!live) break;
+        zero_acc();
+        __syncthreads();   // every wave is past its reads of the exchange area: the chunk buffers are free for the next tile's chunk 0
+    }
+    }   // tiles of this workgroup
 }
 
 // the row-split epilogue: whole quads per row (N % 4 == 0), 16-byte aligned rows of y and the residual, the lean operand set
@@ -620,6 +684,25 @@ inline bool launch_wino44_kc(const ConvParams& p0, int batch, hipStream_t s) {
         }
     }
     if (p.col_S > 0) return false;
+#ifndef FV_X_W44_PERS
+#define FV_X_W44_PERS 0
+#endif
+    // the persistent walk: launches of more tiles than the chip holds workgroups (the in-loop staging instances; per-clip tiling)
+    if constexpr (FV_X_W44_PERS && PRE != 2) {
+        static const bool off = std::getenv("FV_X_W44_NO_PERS") != nullptr;   // A/B runs
+        const int slots = num_cus() * (MT == 2 ? 2 : FV_X_WINO44_OCC) / 8 * 8;
+        if (!off && slots >= 8 && p.wg_total > slots) {
+            switch (p.dil) {
+                case 1:
+                    if (wino44_quad_rows(p)) hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, VAR, MT, PRE, true, false, true>), dim3(slots), dim3(256), 0, s, p);
+                    else hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, VAR, MT, PRE, false, false, true>), dim3(slots), dim3(256), 0, s, p);
+                    return true;
+                case 3: hipLaunchKernelGGL((conv_wino44_kernel<KS, 3, VAR, MT, PRE, false, false, true>), dim3(slots), dim3(256), 0, s, p); return true;
+                case 5: hipLaunchKernelGGL((conv_wino44_kernel<KS, 5, VAR, MT, PRE, false, false, true>), dim3(slots), dim3(256), 0, s, p); return true;
+                default: return false;
+            }
+        }
+    }
     switch (p.dil) {
         case 1:
             if (wino44_quad_rows(p)) hipLaunchKernelGGL((conv_wino44_kernel<KS, 1, VAR, MT, PRE, true>), dim3(grid), dim3(256), 0, s, p);

@@ -1090,7 +1090,10 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
                 const float* c1_in = src;
                 // FV_X_ABL_AA_SNAKE=1 (timing experiment, wrong results): the stand-alone activation passes in front of the k = 7 / 11 convs are skipped — what a
                 // step would take if that activation were free, i.e. the ceiling of ANY fusion of it into a producer or consumer (LOG R5.14)
-                static const bool abl_aa = std::getenv("FV_X_ABL_AA_SNAKE") != nullptr;
+                // (= 2: skipped only in front of the k = 7 / 11 convs of the one-row-block stages, C = 64 / 128 — the layers a consumer-side fusion would cover;
+                //  with -DFV_X_W44_SURR those convs carry the activation's vector issue instead: LOG R6.5)
+                static const int abl_level = std::getenv("FV_X_ABL_AA_SNAKE") ? std::atoi(std::getenv("FV_X_ABL_AA_SNAKE")) : 0;
+                const bool abl_aa = abl_level == 1 || (abl_level == 2 && (ch == 64 || ch == 128) && (br.k == 7 || br.k == 11));
                 if (ups.bigvgan && !abl_aa) {
                     FV_PROF(bs, "aa_snake", 60.0 * B * ch * t, 8.0 * B * ch * t,
                             launch_aa_snake(src, XA(bj), br.act[2 * n].d_alpha, br.act[2 * n].d_inv_beta,
