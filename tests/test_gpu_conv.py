@@ -228,6 +228,38 @@ def test_winograd_pair_matches_oracle_and_direct_pair(C, k, d, form, monkeypatch
         _lib.reload_env()
 
 
+@pytest.mark.parametrize("C,k,d", [(32, 7, 1), (32, 11, 3), (32, 11, 5), (16, 11, 1)])
+def test_winograd_pair_reads_its_residual_from_a_4_byte_aligned_input(C, k, d):
+    """pair_wino44 at C = 32 re-reads the residual x from global memory (round 6: the second V buffer took the raw tile's place in LDS; hifigan.py:107
+    `x = xt + x`) — as 8-byte loads when T is even and x is 8-byte aligned, as dwords otherwise.  The same clip from a buffer that starts 4 bytes off an
+    8-byte boundary must give the same bits (even T: the stores stay 8-byte, only the residual path changes), and both must match the oracle."""
+    from vocoder_amd.engine import FusedConv
+    rng = np.random.default_rng(11 * C + k + d)
+    B, T = 2, 1302
+    w1 = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    w2 = (rng.normal(size=(C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    b1 = rng.normal(size=C).astype(np.float32)
+    b2 = rng.normal(size=C).astype(np.float32)
+    x = rng.normal(size=(B, C, T)).astype(np.float32)
+    c1 = FusedConv(w1, b1, dilation=d, padding=(k * d - d) // 2)
+    c2 = FusedConv(w2, b2, padding=(k - 1) // 2)
+    xa = torch.from_numpy(x).to(_dev())
+    flat = torch.zeros(B * C * T + 3, device=_dev())
+    off = 1 if flat.data_ptr() % 8 == 0 else 2        # (the view below starts 4 bytes past an 8-byte boundary either way)
+    if (flat.data_ptr() + 4 * off) % 8 == 0:
+        off += 1
+    xm = flat[off:off + B * C * T].view(B, C, T)
+    xm.copy_(xa)
+    assert xm.is_contiguous() and xm.data_ptr() % 8 == 4
+    ya = c1.pair(c2, xa)
+    ym = c1.pair(c2, xm)
+    torch.cuda.synchronize()
+    assert _last_kernel().startswith("pair_wino44<"), _last_kernel()
+    assert torch.equal(ya, ym)
+    xt = orc.conv1d(orc.silu(x), w1, b1, dilation=d, padding=(k * d - d) // 2)
+    _check(ya.cpu().numpy(), x + orc.conv1d(orc.silu(xt), w2, b2, padding=(k - 1) // 2))
+
+
 def test_fused_pair_rejects_unsupported_shapes():
     from vocoder_amd.engine import FusedConv, FishVocError
     w = np.zeros((64, 64, 5), np.float32)

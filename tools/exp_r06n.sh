@@ -1,0 +1,10 @@
+set -x
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r06n; mkdir -p $O; cd $R
+for r in 1 2; do
+  python tools/probe_w44_ablation.py da3 >> $O/w44_standalone.txt 2>&1
+  FV_LIB_PATH=$R/vocoder_amd/csrc/libfishvoc_x_da4.so python tools/probe_w44_ablation.py da4 >> $O/w44_standalone.txt 2>&1
+  FV_LIB_PATH=$R/vocoder_amd/csrc/libfishvoc_x_da5.so python tools/probe_w44_ablation.py da5 >> $O/w44_standalone.txt 2>&1
+done
+grep -v amdgpu.ids $O/w44_standalone.txt
+bash tools/ab_libs.sh "x_da4 x_da5 base" 3 > $O/ab_step.txt 2>&1
+cat $O/ab_step.txt
