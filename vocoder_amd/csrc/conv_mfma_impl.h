@@ -247,7 +247,12 @@ constexpr int subs_for(int ks, int w) {
 // the way into LDS instead of by a pass of its own (mean_of_three_kernel: 4 tensors of HBM traffic, 65 us per wide stage at B = 32,
 // ~10 us of launch + dependency per stage for a single clip).  Two more staging register sets: two workgroups per CU.
 template <int KS, int DIL, int WM, int WN, int MT, int NT, bool SUM3 = false>
-__global__ __launch_bounds__(256, (SUM3 || NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))) void conv_mfma_kernel(const ConvParams p) {
+#ifndef FV_X_SUM3_OCC
+#define FV_X_SUM3_OCC 0
+#endif
+// (FV_X_SUM3_OCC=1, experiment: asks for four / three workgroups per CU in the narrow SUM3 tiles — the HBM-bound last upsamplers are bound by bytes in flight.
+//  Measured nothing on top of dropping the flat-mode row plan from these instances, which already took the 64 x 128 tile from two to three: LOG R6.12)
+__global__ __launch_bounds__(256, (SUM3 ? (FV_X_SUM3_OCC && MT * NT == 1 ? 4 : (FV_X_SUM3_OCC && MT * NT == 2 ? 3 : 2)) : (NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4)))) void conv_mfma_kernel(const ConvParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int N_BLK = WN * NT * 32;
     constexpr int SPAN = (KS - 1) * DIL;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256, (SUM3 || NT >= 4 ? 2 : (MT * NT >= 4 ? 3 : 4))
     const int b = bid / p.m_blks;      // 0 in flat mode (the grid then has no batch factor)
     const int n0 = n_tile * N_BLK;
     const float* __restrict__ xb = p.x + (long long)b * p.x_bstride;
-    const bool flat = KS == 1 && p.flat;
+    const bool flat = KS == 1 && !SUM3 && p.flat;   // (SUM3: never flat — the transposed convs that use it have a halo; the row plan of flat mode is dead code there)
 
 #ifdef FV_X_CONV_TS
 #define FV_CV_STAMP(i) do { if (p.dbg_ts && threadIdx.x == 0) p.dbg_ts[(long long)blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)

@@ -107,23 +107,42 @@ __global__ __launch_bounds__(POST_TT / 4) void conv_post_kernel(const float* __r
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < Cin; c0 += NARROW_CH) {
         __syncthreads();
+        // RB rows are requested together and activated behind ONE wave-uniform switch (round 6).  The per-element form — load (three loads with SUM3), the
+        // run-time activation switch, store — compiled to a wait behind every element's loads: 80 dependent round trips per thread and slab with three
+        // dwords in flight each, 2.6 TB/s on the headline's last launch (110 us alone on the critical path: LOG R6.11).  Same arithmetic per element.
+        constexpr int NI = (PITCH + NTHR - 1) / NTHR, RB = 4;
+        static_assert(NARROW_CH % RB == 0, "whole row batches");
 #pragma unroll
-        for (int r = 0; r < NARROW_CH; ++r) {
-            const int ci = c0 + r;
+        for (int r0 = 0; r0 < NARROW_CH; r0 += RB) {
+            float v[RB * NI];
+            [[maybe_unused]] float v2[SUM3 ? RB * NI : 1], v3[SUM3 ? RB * NI : 1];
 #pragma unroll
-            for (int i = 0; i < (PITCH + NTHR - 1) / NTHR; ++i) {
-                const int col = tid + i * NTHR;
-                const int t = t0 - LEAD + col;
-                const bool ok = ci < Cin && t >= 0 && t < T;
-                const unsigned off = ok ? (unsigned)(ci * T + t) * 4u : 0xFFFFFFFFu;
-                float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
-                if constexpr (SUM3) {
-                    const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs2, off, 0, 0));
-                    const float v3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs3, off, 0, 0));
-                    v = ((v + v2) + v3) * (1.0f / 3.0f);
+            for (int rr = 0; rr < RB; ++rr) {
+                const int ci = c0 + r0 + rr;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int t = t0 - LEAD + tid + i * NTHR;
+                    const bool ok = ci < Cin && t >= 0 && t < T;
+                    const unsigned off = ok ? (unsigned)(ci * T + t) * 4u : 0xFFFFFFFFu;
+                    v[rr * NI + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
+                    if constexpr (SUM3) {
+                        v2[rr * NI + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs2, off, 0, 0));
+                        v3[rr * NI + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs3, off, 0, 0));
+                    }
                 }
-                if (col < PITCH) xs[r][col] = pre_act == FV_ACT_SILU ? v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) : act_apply(v, pre_act, slope);
             }
+            if constexpr (SUM3) {
+#pragma unroll
+                for (int q = 0; q < RB * NI; ++q) v[q] = ((v[q] + v2[q]) + v3[q]) * (1.0f / 3.0f);
+            }
+            act_apply_all(v, pre_act, slope);
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int col = tid + i * NTHR;
+                    if (col < PITCH) xs[r0 + rr][col] = v[rr * NI + i];
+                }
         }
         __syncthreads();
 #pragma unroll
