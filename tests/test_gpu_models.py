@@ -1057,6 +1057,7 @@ def test_bigvgan_fused_amp_convs_equal_the_activation_plus_conv_launches(maxk, m
     cfg = dict(syn.BIGVGAN_24K)
     sd = syn.bigvgan_state_dict(cfg, 3)
     monkeypatch.setenv("FV_AMP_MAXK", maxk)
+    monkeypatch.setenv("FV_AMP_MAXC", "64")   # (the default fuses at C = 32 only since round 6, LOG R6.13: both widths of amp_conv stay covered here)
     fused = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=sd)
     monkeypatch.setenv("FV_NO_AMP_FUSION", "1")
     plain = Engine(_lib.FV_MODEL_BIGVGAN, ups=upsampler_config(**cfg), state_dict=sd)
@@ -1065,7 +1066,8 @@ def test_bigvgan_fused_amp_convs_equal_the_activation_plus_conv_launches(maxk, m
     ya, yb = fused(x), plain(x)
     torch.cuda.synchronize()
     prof = fused.profile(x, repeats=1)
-    assert any(r["kernel"].startswith("amp_conv<k=3") for r in prof)
+    assert any(r["kernel"].startswith("amp_conv<k=3") and "C=64" in r["kernel"] for r in prof)
+    assert any(r["kernel"].startswith("amp_conv<k=3") and "C=32" in r["kernel"] for r in prof)
     assert any(r["kernel"].startswith("amp_conv<k=11") for r in prof) == (maxk == "11")
     assert torch.equal(ya, yb), float((ya - yb).abs().max())
     for B, T in ((2, 7), (1, 1), (3, 19)):                                       # short clips: both sequence ends inside one tile

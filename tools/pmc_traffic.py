@@ -31,7 +31,8 @@ def key_of(kernel_name: str, grid_threads: int):
         ks, dil, wm, wn, nt = map(int, m.groups())
         return f"conv_wino k={ks} d={dil} tile={wm * 32}x{wn * nt * 32}p grid={blocks}"
     # (KS, DIL, VAR: 1 = the 64-channel layers, MT [, PRE, QR: round 5 — the activation in front and the row-split epilogue do not change the key]): 64 MT rows x 32 quad columns
-    m = re.search(r"conv_wino44_kernel<(\d+), (\d+), (\d+), (\d+)(?:, \d+)?(?:, (?:true|false))?>", kernel_name)
+    # (round 6: any number of trailing flags — QR, FLAT, PERS: with two of them the old pattern stopped matching and the dominant key kept a stale entry)
+    m = re.search(r"conv_wino44_kernel<(\d+), (\d+), (\d+), (\d+)(?:, \d+)?(?:, (?:true|false))*>", kernel_name)
     if m:
         return f"conv_wino44 k={m.group(1)} d={m.group(2)} tile={64 * int(m.group(4))}x32q{' c64' if m.group(3) == '1' else ''} grid={blocks}"
     m = re.search(r"conv_wino4_kernel<(\d+), (\d+), (\d+), (true|false)>", kernel_name)   # (KS, DIL, WM, C64): tile = rows x QUAD columns, 128 WM threads

@@ -5,7 +5,7 @@ where per-kernel durations / counters must not overlap):
 Defaults to the BASELINE batch of the model (32 / 64 / 128)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-os.environ.setdefault("FV_SINGLE_STREAM", "1")
+os.environ.setdefault("FV_SINGLE_STREAM", "2")   # one stream, tree form: the kernel instances of the shipped step (LOG R6.9)
 os.environ.setdefault("FV_NO_GRAPH", "1")
 import torch
 from vocoder_amd import _lib, synthetic as syn

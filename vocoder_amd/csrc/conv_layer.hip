@@ -834,6 +834,11 @@ fv_status conv_layer_run(const ConvLayer& L, const ConvRun& r, hipStream_t strea
     // the stage-0 upsampler of a 1 s clip: 87 GEMM columns per item fill two thirds of a 128-column tile — 128 x 96 tiles (four waves
     // along M, three n-tiles each; instantiated for the two-tap polyphase convs only)
     if ((cfg == TILE_128x128 || cfg == TILE_128x64) && L.ks == 2 && L.M >= 128 && p.N > 64 && p.N <= 96) cfg = TILE_128x96;
+    // 256 x 64 tiles for the two-tap polyphase upsamplers with whole 256-row blocks (round 6, LOG R6.14): the staged window (three inputs + SiLU behind the
+    // stack-mean) serves twice the rows — HiFiGAN-V1's stage-1 upsampler (1024 GEMM rows) 230 -> 217 us, alone on the step's critical path; same sums per
+    // output (chunk, tap, channel pair order does not depend on the tile).  FV_X_UPS_TILE256=0: the 128-row tiles (A/B runs)
+    static const int ups256 = std::getenv("FV_X_UPS_TILE256") ? std::atoi(std::getenv("FV_X_UPS_TILE256")) : 1;
+    if (ups256 && L.transposed && L.ks == 2 && L.M % 256 == 0 && p.N > 96 && (cfg == TILE_128x128 || cfg == TILE_128x64)) cfg = TILE_256x64;
     // the last, HBM-bound upsampler (C -> C / 2 with C / 2 * stride <= 32 rows): 32 x 128 tiles (HiFiGAN step -0.06 ms; for the
     // stride-1 convs of that width — BigVGAN's last stage — the 32 x 512 tile stays: +0.26 ms with the small one)
     if (cfg == TILE_32x512 && L.transposed) cfg = TILE_32x128;

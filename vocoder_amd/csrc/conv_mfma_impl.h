@@ -930,7 +930,7 @@ inline bool launch_cfg(const ConvParams& p, int cfg, int batch, hipStream_t s) {
             if constexpr (KS == 2) { launch_one<KS, DIL, 4, 1, 1, 3>(p, batch, s); return true; }
             return false;
         case TILE_256x64:
-            if constexpr (KS == 1) { launch_one<KS, DIL, 4, 1, 2, 2>(p, batch, s); return true; }
+            if constexpr (KS == 1 || KS == 2) { launch_one<KS, DIL, 4, 1, 2, 2>(p, batch, s); return true; }   // (KS == 2: the stride-8 upsamplers, 1024 / 2048 GEMM rows)
             return false;
         case TILE_SPLITK_32x64:
             if constexpr (splitk_direct_ok<KS, DIL, 2, true> && KS != 7) {

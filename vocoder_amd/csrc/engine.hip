@@ -467,7 +467,9 @@ struct fv_engine {
     // Serialized, amp_conv equals conv + aa_snake within 5 % everywhere, but the separate activation pass is HBM-bound work that the
     // other branches' MFMA-bound convs overlap, while the fused one is VALU work inside an MFMA kernel (12 - 20 cycles of matrix
     // time per VALU instruction of a co-resident wave, tools/ubench/mfma_mix.hip) — so only the shortest convs fuse by default.
-    int fuse_amp_max_c = 64, fuse_amp_max_k = 3;   // FV_AMP_MAXC / FV_AMP_MAXK override (experiments, tests)
+    // Round 6: with the unfused convs on Winograd tap groups the fused form lost its margin — BigVGAN-24k B = 64, interleaved: fused at C <= 64 25.98 - 26.04 ms,
+    // at C = 32 only 25.85 - 25.93, nowhere 25.79 - 25.93 (profiles/r06v_bigvgan_amp_fusion.txt): C = 32 stays fused (its launches are the HBM-bound ones).
+    int fuse_amp_max_c = 32, fuse_amp_max_k = 3;   // FV_AMP_MAXC / FV_AMP_MAXK override (experiments, tests)
     struct GraphKey {
         const void* in;
         void* out;
@@ -490,7 +492,8 @@ struct fv_engine {
     GraphKey last_key{};
     bool have_last = false;
     bool use_graph = true;        // FV_NO_GRAPH=1 disables hipGraph replay
-    bool branch_streams = true;   // FV_SINGLE_STREAM=1 runs the ResBlock branches back to back on the caller's stream
+    bool branch_streams = true;   // FV_SINGLE_STREAM=1 runs the ResBlock branches back to back on the caller's stream (the chain form of the branch mean)
+    bool single_tree = false;     // FV_SINGLE_STREAM=2: one stream too, but the TREE form — the kernel instances of the shipped three-stream step, launch by launch (rocprofv3 / PMC passes: tools/probe_model.py)
     std::vector<hipStream_t> bstreams;   // nk-1 auxiliary streams (branch 0 runs on the caller's stream)
     hipStream_t null_capture = nullptr;   // calls on the legacy default stream: the launch sequence is captured here, the graph is launched on stream 0
     std::vector<hipEvent_t> bev_fork, bev_last;
@@ -1011,7 +1014,7 @@ fv_status fv_engine::run_upsampler(const float* d_in, float* d_out, int B, int T
         // branches back to back, each into its own buffers — so that the table holds the kernel instances the shipped step launches: the chain's last
         // epilogues accumulate (the slow general epilogue of conv_wino44: 321 against 265 us for the dominant layer) and its upsamplers read one tensor,
         // neither of which the three-stream step ever runs.
-        const bool tree = (multi || profiling) && nk == 3 && !(mean_env && mean_env[0] == 'c') && stg->ch > chain_max_c;
+        const bool tree = (multi || profiling || single_tree) && nk == 3 && !(mean_env && mean_env[0] == 'c') && stg->ch > chain_max_c;
         const bool order_desc = true;
         for (int jj = 0; jj < nk; ++jj) {
             const int j = (tree && order_desc) ? nk - 1 - jj : jj;
@@ -1536,7 +1539,10 @@ FV_API fv_status fv_create(const fv_config* cfg, fv_engine** out) {
     if (const char* v = std::getenv("FV_NO_AMP_FUSION")) e->fuse_amp_convs = !(v[0] == '1');
     if (const char* v = std::getenv("FV_AMP_MAXC")) e->fuse_amp_max_c = std::atoi(v);
     if (const char* v = std::getenv("FV_AMP_MAXK")) e->fuse_amp_max_k = std::atoi(v);
-    if (const char* v = std::getenv("FV_SINGLE_STREAM")) e->branch_streams = !(v[0] == '1');
+    if (const char* v = std::getenv("FV_SINGLE_STREAM")) {
+        e->branch_streams = !(v[0] == '1' || v[0] == '2');
+        e->single_tree = v[0] == '2';
+    }
     if (const char* v = std::getenv("FV_NO_GRAPH")) e->use_graph = !(v[0] == '1');
     if (std::getenv("FV_DEBUG_STOP")) e->use_graph = false;   // the early return leaves forked branch streams unjoined: not capturable
     if (const char* v = std::getenv("FV_TILE_FRAMES")) e->tile_frames_override = std::atoi(v);
