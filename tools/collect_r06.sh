@@ -19,8 +19,9 @@ for m in hifigan bigvgan vocos; do
   python $R/tools/pmc_summary.py $O/pmc_${m}_FETCH_SIZE $O/pmc_${m}_WRITE_SIZE 2 $O/${m}_hbm_traffic.json > $O/${m}_hbm_traffic.txt 2>&1
 done
 python $R/tools/pmc_traffic.py $O/pmc_hifigan_FETCH_SIZE $O/pmc_hifigan_WRITE_SIZE $O/traffic.json --build $TAG
-# ... merged into profiles/traffic.json of this copy first, so that the bench line below finds its dominant kernel in it
-python $R/tools/pmc_traffic.py $O/pmc_hifigan_FETCH_SIZE $O/pmc_hifigan_WRITE_SIZE $R/profiles/traffic.json --merge --build $TAG; cp $R/profiles/traffic.json $O/traffic_merged.json
+# ... and becomes profiles/traffic.json of this copy, so that the bench line below finds its dominant kernel in it
+# (written FRESH from this build's passes, not merged into the previous file: a key that no longer matches must show up as a missing entry, not as an old one — LOG R6.15)
+cp $O/traffic.json $R/profiles/traffic.json; cp $O/traffic.json $O/traffic_merged.json
 cd $R
 timeout 1200 python bench.py --profile-json $O/bench_kernels_hipevents.json > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.err
 # how `roofline.traffic` was measured, with the by-kernel tables of the three configs
