@@ -20,8 +20,8 @@ w("```bash\ncd /tmp && export TMPDIR=/tmp\nR=/root/repo\nfor m in hifigan bigvga
   "    rocprofv3 --kernel-trace --pmc $c --output-format csv -d out/pmc_${m}_$c -- python $R/tools/probe_model.py $m $B 2\n"
   "  done\n"
   "  python $R/tools/pmc_summary.py out/pmc_${m}_FETCH_SIZE out/pmc_${m}_WRITE_SIZE 2 out/${m}_hbm_traffic.json\ndone\n"
-  "python $R/tools/pmc_traffic.py out/pmc_hifigan_FETCH_SIZE out/pmc_hifigan_WRITE_SIZE $R/profiles/traffic.json --merge --build " + tag + "\n```\n")
-w("`tools/probe_model.py <model> <batch> 2` runs two forwards of the BASELINE configuration in profile mode (single stream, eager: every launch its own row). "
+  "python $R/tools/pmc_traffic.py out/pmc_hifigan_FETCH_SIZE out/pmc_hifigan_WRITE_SIZE $R/profiles/traffic.json --build " + tag + "   # written fresh, not merged (LOG R6.15)\n```\n")
+w("`tools/probe_model.py <model> <batch> 2` runs two forwards of the BASELINE configuration on ONE stream without graphs, in the TREE form of the branch mean (`FV_SINGLE_STREAM=2`: the kernel instances of the shipped three-stream step, every launch its own row). "
   "`--pmc` is combined with `--kernel-trace` only (no `--sys-trace` / hip / hsa / memory-copy domains).\n")
 w("## Counter correction (`/opt/skills/guides/MI355X_MICROARCH.md`, HBM / rocprofv3 section; re-calibrated with `tools/pmc_calib.hip`)\n")
 w("* `FETCH_SIZE` and `WRITE_SIZE` are reported in **KB**;\n* on gfx950 `FETCH_SIZE` counts **half** of the bytes read: bytes read = `FETCH_SIZE x 1024 x 2`;\n"
